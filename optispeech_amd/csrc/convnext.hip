@@ -1,0 +1,382 @@
+// HBM-bound halves of the ConvNeXt block and the LayerNorm family (reference rows A1a, A2, A4, A11):
+//   dwconv7 + bias + LayerNorm(C) fused forward      <- generator/modules/convnext.py:36-38
+//   LayerNorm forward / backward (eps argument)       <- convnext.py:85,102; modules/layers.py:26-45; wavenext:84
+//   depthwise-conv backward (dx, dw, db)              <- autograd of convnext.py:36
+//
+// Layout: channels-last (B, T, C) f32, C % 4 == 0, C <= 1024.  One 64-lane wavefront owns one frame at a
+// time: lane l holds channels {256k + 4l .. 256k + 4l + 3}, so every global access is a coalesced float4 row
+// segment (1 KiB per wave instruction) and the LayerNorm statistics are intra-wave shuffles (no LDS, no barrier).
+// A wave walks a run of FRAMES consecutive frames of one utterance with the 7-row window in registers, so each
+// input row is fetched (7 + FRAMES - 1) / FRAMES times (from L2) instead of 7.
+// Algorithmic HBM bytes per frame: forward 2*C*4 (+C*4 when xhat is saved for training); see DESIGN.md.
+#include "osp_common.h"
+
+#define FRAMES 8
+#define MAXCH 4   // chunks of 256 channels per lane => C <= 1024
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+// ------------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dw,
+                                                             const float* __restrict__ dwb, const float* __restrict__ lnw,
+                                                             const float* __restrict__ lnb, float eps,
+                                                             float* __restrict__ h, float* __restrict__ xhat,
+                                                             float* __restrict__ rstd_out, int B, int T, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int runs_per_utt = (T + FRAMES - 1) / FRAMES;
+    const int run = blockIdx.x * 4 + wave;
+    if (run >= B * runs_per_utt) return;
+    const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FRAMES;
+    const float* xb = x + (int64_t)b * T * C;
+    bool act[NCH];
+    float4 w[NCH][7], bias[NCH], gw[NCH], gb[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = k * 256 + lane * 4;
+        act[k] = ch < C;
+        if (act[k]) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) w[k][j] = *reinterpret_cast<const float4*>(dw + (int64_t)j * C + ch);
+            bias[k] = *reinterpret_cast<const float4*>(dwb + ch);
+            gw[k] = *reinterpret_cast<const float4*>(lnw + ch);
+            gb[k] = *reinterpret_cast<const float4*>(lnb + ch);
+        }
+    }
+    // sliding window: win[k][j] = x[t + j - 3]
+    float4 win[NCH][7];
+    auto ldrow = [&](int k, int t) -> float4 {
+        if (!act[k] || t < 0 || t >= T) return f4zero();
+        return *reinterpret_cast<const float4*>(xb + (int64_t)t * C + k * 256 + lane * 4);
+    };
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) win[k][j + 1] = ldrow(k, t0 + j - 3);
+    const float invC = 1.0f / (float)C;
+    for (int f = 0; f < FRAMES; ++f) {
+        const int t = t0 + f;
+        if (t >= T) break;
+        float4 c[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) win[k][j] = win[k][j + 1];
+            win[k][6] = ldrow(k, t + 3);
+            float4 a = act[k] ? bias[k] : f4zero();
+            if (act[k]) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) a = f4fma(w[k][j], win[k][j], a);
+            }
+            c[k] = a;
+            s += f4sum(a);
+        }
+        const float mean = wave_sum(s) * invC;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (act[k]) {
+                c[k].x -= mean; c[k].y -= mean; c[k].z -= mean; c[k].w -= mean;
+                v += c[k].x * c[k].x + c[k].y * c[k].y + c[k].z * c[k].z + c[k].w * c[k].w;
+            }
+        const float rstd = rsqrtf(wave_sum(v) * invC + eps);
+        const int64_t row = ((int64_t)b * T + t) * C;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (act[k]) {
+                const float4 n = make_float4(c[k].x * rstd, c[k].y * rstd, c[k].z * rstd, c[k].w * rstd);
+                const int ch = k * 256 + lane * 4;
+                if (xhat) *reinterpret_cast<float4*>(xhat + row + ch) = n;
+                *reinterpret_cast<float4*>(h + row + ch) = f4fma(n, gw[k], gb[k]);
+            }
+        if (rstd_out && lane == 0) rstd_out[(int64_t)b * T + t] = rstd;
+    }
+}
+
+extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* dwb, const float* lnw,
+                                  const float* lnb, float eps, float* h, float* xhat, float* rstd, int64_t B,
+                                  int64_t T, int64_t C, hipStream_t stream) {
+    OSP_CHECK_ARG(x && dw && dwb && lnw && lnb && h, "null operand");
+    OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
+    const int64_t runs = B * cdiv(T, FRAMES);
+    dim3 grid((unsigned)cdiv(runs, 4));
+    const int nch = (int)cdiv(C, 256);
+#define L(N) hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N>), grid, dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, xhat, rstd, (int)B, (int)T, (int)C)
+    if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
+#undef L
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm forward over the last dim.  Optional fused tail:  y = (LN(x)*w + b) * dropout * rowmask.
+// mean/rstd are saved (2 floats per row) so the backward recomputes xhat from x.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            const float* __restrict__ rowmask, float drop_p,
+                                                            uint64_t seed, uint32_t stream_id, int64_t rows, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invC = 1.0f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float4 v[NCH];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = k * 256 + lane * 4;
+            v[k] = ch < C ? *reinterpret_cast<const float4*>(x + row * C + ch) : f4zero();
+            s += f4sum(v[k]);
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (k * 256 + lane * 4 < C) {
+                v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+                q += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+        const float rm = rowmask ? rowmask[row] : 1.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = k * 256 + lane * 4;
+            if (ch < C) {
+                const float4 gw = *reinterpret_cast<const float4*>(w + ch), gb = *reinterpret_cast<const float4*>(b + ch);
+                float4 o = make_float4(fmaf(v[k].x * rstd, gw.x, gb.x), fmaf(v[k].y * rstd, gw.y, gb.y),
+                                       fmaf(v[k].z * rstd, gw.z, gb.z), fmaf(v[k].w * rstd, gw.w, gb.w));
+                if (drop_p > 0.f) {
+                    const uint64_t e = (uint64_t)row * C + ch;   // multiple of 4: one Philox call covers the float4
+                    const uint4 r = philox4(seed, e >> 2, stream_id);
+                    const float keep = 1.0f / (1.0f - drop_p);
+                    o.x *= u32_to_unit(r.x) < drop_p ? 0.f : keep;
+                    o.y *= u32_to_unit(r.y) < drop_p ? 0.f : keep;
+                    o.z *= u32_to_unit(r.z) < drop_p ? 0.f : keep;
+                    o.w *= u32_to_unit(r.w) < drop_p ? 0.f : keep;
+                }
+                o.x *= rm; o.y *= rm; o.z *= rm; o.w *= rm;
+                *reinterpret_cast<float4*>(y + row * C + ch) = o;
+            }
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
+extern "C" int osp_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean,
+                                 float* rstd, const float* rowmask, float drop_p, int64_t seed, int64_t stream_id,
+                                 int64_t rows, int64_t C, hipStream_t stream) {
+    OSP_CHECK_ARG(x && w && b && y, "null operand");
+    OSP_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
+    OSP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "dropout rate");
+    dim3 grid((unsigned)(cdiv(rows, 4) < 4096 ? cdiv(rows, 4) : 4096));
+    const int nch = (int)cdiv(C, 256);
+#define L(N) hipLaunchKernelGGL((layernorm_fwd_kernel<N>), grid, dim3(256), 0, stream, x, w, b, eps, y, mean, rstd, rowmask, drop_p, (uint64_t)seed, (uint32_t)stream_id, rows, (int)C)
+    if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
+#undef L
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  g = dy * dropout * rowmask;  xhat = xin (mean == null) or (xin - mean)*rstd;
+//   dx = rstd * (g*w - mean_C(g*w) - xhat * mean_C(g*w*xhat))  [* (relu_src > 0) if given]
+//   dlnw += sum_rows g * xhat ; dlnb += sum_rows g
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xin,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ w, const float* __restrict__ relu_src,
+                                                            const float* __restrict__ rowmask, float drop_p, uint64_t seed,
+                                                            uint32_t stream_id, float* __restrict__ dx,
+                                                            float* __restrict__ dlnw, float* __restrict__ dlnb,
+                                                            int64_t rows, int C) {
+    __shared__ float red[2][4][256 * NCH];   // [w|b][wave][channel-in-lane-order]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invC = 1.0f / (float)C;
+    float4 aw[NCH], ab[NCH], gw[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        aw[k] = f4zero(); ab[k] = f4zero();
+        const int ch = k * 256 + lane * 4;
+        gw[k] = ch < C ? *reinterpret_cast<const float4*>(w + ch) : f4zero();
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean ? mean[row] : 0.f, rs = rstd[row];
+        const float rm = rowmask ? rowmask[row] : 1.f;
+        float4 g[NCH], xh[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = k * 256 + lane * 4;
+            if (ch < C) {
+                float4 d = *reinterpret_cast<const float4*>(dy + row * C + ch);
+                float4 xv = *reinterpret_cast<const float4*>(xin + row * C + ch);
+                if (mean) { xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs; }
+                if (drop_p > 0.f) {
+                    const uint64_t e = (uint64_t)row * C + ch;
+                    const uint4 r = philox4(seed, e >> 2, stream_id);
+                    const float keep = 1.0f / (1.0f - drop_p);
+                    d.x *= u32_to_unit(r.x) < drop_p ? 0.f : keep;
+                    d.y *= u32_to_unit(r.y) < drop_p ? 0.f : keep;
+                    d.z *= u32_to_unit(r.z) < drop_p ? 0.f : keep;
+                    d.w *= u32_to_unit(r.w) < drop_p ? 0.f : keep;
+                }
+                d.x *= rm; d.y *= rm; d.z *= rm; d.w *= rm;
+                aw[k] = f4fma(d, xv, aw[k]);
+                ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
+                d.x *= gw[k].x; d.y *= gw[k].y; d.z *= gw[k].z; d.w *= gw[k].w;
+                g[k] = d; xh[k] = xv;
+                s1 += f4sum(d);
+                s2 += d.x * xv.x + d.y * xv.y + d.z * xv.z + d.w * xv.w;
+            } else { g[k] = f4zero(); xh[k] = f4zero(); }
+        }
+        const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = k * 256 + lane * 4;
+            if (ch < C) {
+                float4 o = make_float4(rs * (g[k].x - m1 - xh[k].x * m2), rs * (g[k].y - m1 - xh[k].y * m2),
+                                       rs * (g[k].z - m1 - xh[k].z * m2), rs * (g[k].w - m1 - xh[k].w * m2));
+                if (relu_src) {
+                    const float4 r = *reinterpret_cast<const float4*>(relu_src + row * C + ch);
+                    o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
+                    o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(dx + row * C + ch) = o;
+            }
+        }
+    }
+    if (!dlnw) return;
+    // block-level combine of the per-wave parameter-gradient partials, then one atomic per channel per block
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        *reinterpret_cast<float4*>(&red[0][wave][k * 256 + lane * 4]) = aw[k];
+        *reinterpret_cast<float4*>(&red[1][wave][k * 256 + lane * 4]) = ab[k];
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const float a = red[0][0][ch] + red[0][1][ch] + red[0][2][ch] + red[0][3][ch];
+        const float bsum = red[1][0][ch] + red[1][1][ch] + red[1][2][ch] + red[1][3][ch];
+        atomicAdd(dlnw + ch, a);
+        atomicAdd(dlnb + ch, bsum);
+    }
+}
+
+extern "C" int osp_layernorm_bwd(const float* dy, const float* xin, const float* mean, const float* rstd,
+                                 const float* w, const float* relu_src, const float* rowmask, float drop_p,
+                                 int64_t seed, int64_t stream_id, float* dx, float* dlnw, float* dlnb, int64_t rows,
+                                 int64_t C, hipStream_t stream) {
+    OSP_CHECK_ARG(dy && xin && rstd && w && dx, "null operand");
+    OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr), "dlnw/dlnb come together");
+    OSP_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
+    const int64_t blocks = cdiv(rows, 4 * FRAMES);   // FRAMES rows per wave => few atomics
+    dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024));
+    const int nch = (int)cdiv(C, 256);
+#define L(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), grid, dim3(256), 0, stream, dy, xin, mean, rstd, w, relu_src, rowmask, drop_p, (uint64_t)seed, (uint32_t)stream_id, dx, dlnw, dlnb, rows, (int)C)
+    if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
+#undef L
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Depthwise conv backward:  dx[t] = dres[t]*dres_rowmask[t] + sum_j w[j] * dc[t - j + 3];  ddw[j] += sum_t dc[t] * x[t + j - 3];
+// ddb += sum_t dc[t].  Same wave-per-run walk with two register windows (dc for dx, x for ddw).
+template <int NCH>
+__global__ __launch_bounds__(256) void dwconv7_bwd_kernel(const float* __restrict__ dc, const float* __restrict__ x,
+                                                          const float* __restrict__ dw, const float* __restrict__ dres,
+                                                          const float* __restrict__ dres_rowmask,
+                                                          float* __restrict__ dx, float* __restrict__ ddw,
+                                                          float* __restrict__ ddb, int B, int T, int C) {
+    __shared__ float red[4][256 * NCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int runs_per_utt = (T + FRAMES - 1) / FRAMES;
+    const int run = blockIdx.x * 4 + wave;
+    const bool live = run < B * runs_per_utt;
+    const int b = live ? run / runs_per_utt : 0, t0 = live ? (run - b * runs_per_utt) * FRAMES : 0;
+    const float* xb = x + (int64_t)b * T * C;
+    const float* db_ = dc + (int64_t)b * T * C;
+    bool act[NCH];
+    float4 w[NCH][7], gw[NCH][7], gb[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = k * 256 + lane * 4;
+        act[k] = live && ch < C;
+        gb[k] = f4zero();
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            gw[k][j] = f4zero();
+            w[k][j] = act[k] ? *reinterpret_cast<const float4*>(dw + (int64_t)j * C + ch) : f4zero();
+        }
+    }
+    auto ld = [&](const float* base, int k, int t) -> float4 {
+        if (!act[k] || t < 0 || t >= T) return f4zero();
+        return *reinterpret_cast<const float4*>(base + (int64_t)t * C + k * 256 + lane * 4);
+    };
+    float4 wx[NCH][7], wd[NCH][7];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { wx[k][j + 1] = ld(xb, k, t0 + j - 3); wd[k][j + 1] = ld(db_, k, t0 + j - 3); }
+    if (live)
+        for (int f = 0; f < FRAMES; ++f) {
+            const int t = t0 + f;
+            if (t >= T) break;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { wx[k][j] = wx[k][j + 1]; wd[k][j] = wd[k][j + 1]; }
+                wx[k][6] = ld(xb, k, t + 3);
+                wd[k][6] = ld(db_, k, t + 3);
+                if (!act[k]) continue;
+                const int64_t off = ((int64_t)b * T + t) * C + k * 256 + lane * 4;
+                float4 a = dres ? *reinterpret_cast<const float4*>(dres + off) : f4zero();
+                if (dres && dres_rowmask) {
+                    const float rm = dres_rowmask[(int64_t)b * T + t];
+                    a.x *= rm; a.y *= rm; a.z *= rm; a.w *= rm;
+                }
+                const float4 d0 = wd[k][3];   // dc[t]
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    a = f4fma(w[k][j], wd[k][6 - j], a);          // dc[t - j + 3]
+                    gw[k][j] = f4fma(d0, wx[k][j], gw[k][j]);     // x[t + j - 3]
+                }
+                gb[k].x += d0.x; gb[k].y += d0.y; gb[k].z += d0.z; gb[k].w += d0.w;
+                *reinterpret_cast<float4*>(dx + off) = a;
+            }
+        }
+    if (!ddw) return;
+    for (int j = 0; j < 8; ++j) {   // 7 taps + bias, one LDS pass each
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            *reinterpret_cast<float4*>(&red[wave][k * 256 + lane * 4]) = j < 7 ? gw[k][j] : gb[k];
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < C; ch += 256) {
+            const float s = red[0][ch] + red[1][ch] + red[2][ch] + red[3][ch];
+            atomicAdd(j < 7 ? ddw + (int64_t)j * C + ch : ddb + ch, s);
+        }
+    }
+}
+
+extern "C" int osp_dwconv7_bwd(const float* dc, const float* x, const float* dw, const float* dres,
+                               const float* dres_rowmask, float* dx, float* ddw, float* ddb, int64_t B, int64_t T, int64_t C, hipStream_t stream) {
+    OSP_CHECK_ARG(dc && x && dw && dx, "null operand");
+    OSP_CHECK_ARG((ddw == nullptr) == (ddb == nullptr), "ddw/ddb come together");
+    OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
+    const int64_t runs = B * cdiv(T, FRAMES);
+    dim3 grid((unsigned)cdiv(runs, 4));
+    const int nch = (int)cdiv(C, 256);
+#define L(N) hipLaunchKernelGGL((dwconv7_bwd_kernel<N>), grid, dim3(256), 0, stream, dc, x, dw, dres, dres_rowmask, dx, ddw, ddb, (int)B, (int)T, (int)C)
+    if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
+#undef L
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

@@ -1,0 +1,103 @@
+// Shared device/host helpers for libosp_hip (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define OSP_OK 0
+#define OSP_ERR_ARG -1
+#define OSP_ERR_HIP -2
+#define OSP_ERR_UNSUPPORTED -3
+
+extern "C" const char* osp_last_error();
+void osp_set_error(const char* fmt, ...);
+
+#define OSP_CHECK_ARG(cond, msg)                                      \
+    do {                                                              \
+        if (!(cond)) {                                                \
+            osp_set_error("%s: %s (%s)", __func__, msg, #cond);       \
+            return OSP_ERR_ARG;                                       \
+        }                                                             \
+    } while (0)
+
+#define OSP_LAUNCH_CHECK()                                            \
+    do {                                                              \
+        hipError_t e__ = hipGetLastError();                           \
+        if (e__ != hipSuccess) {                                      \
+            osp_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return OSP_ERR_HIP;                                       \
+        }                                                             \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block reduction through LDS scratch (>= 16 floats); result valid in all threads
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+// ---------------------------------------------------------------- activations (exact erf GELU == nn.GELU())
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------- counter-based RNG (dropout / drop-path)
+// Philox-4x32-10: (seed, stream) key, 64-bit counter -> 4 uniform u32.  Stateless, so a backward pass
+// regenerates the forward mask from (seed, stream, element index) instead of storing it.
+__device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr, uint32_t stream) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = stream, c3 = 0x9E3779B9u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// keep/scale factor for element idx: 0 with prob p, else 1/(1-p)
+__device__ __forceinline__ float dropout_factor(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
+    const uint4 r = philox4(seed, idx >> 2, stream);
+    const uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    return u32_to_unit(w) < p ? 0.0f : 1.0f / (1.0f - p);
+}

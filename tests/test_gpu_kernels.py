@@ -1,0 +1,174 @@
+"""HIP kernels vs the CPU oracle / torch-CPU fp32 restatement, through the C ABI.  Needs an MI355X.
+
+Tolerance for floating point: 1e-3 relative to the tensor scale as BASELINE.json states (observed
+~1e-6); integer paths exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nn_ops as ON                     # noqa: E402  (checker only)
+from oracle import schema as S                      # noqa: E402
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("nutt,T,cin,taps,n_out", [
+    (2, 50, 256, 1, 1024), (3, 37, 100, 3, 256), (2, 64, 384, 3, 384), (1, 200, 256, 5, 256),
+    (2, 33, 256, 7, 384), (2, 40, 1, 9, 256), (4, 128, 384, 1, 1), (2, 70, 1028, 1, 256), (8, 800, 256, 1, 1024)])
+def test_conv_gemm_forward(nutt, T, cin, taps, n_out):
+    from optispeech_amd import kernels as K
+    pad = (taps - 1) // 2
+    x = rnd(nutt, T, cin, seed=1)
+    w = rnd(n_out, cin, taps, seed=2, scale=1.0 / np.sqrt(cin * taps))
+    b = rnd(n_out, seed=3)
+    want = ON.conv1d_cl(x, w, b, pad)
+    wn = w.permute(0, 2, 1).contiguous().to(DEV)
+    got = K.conv_gemm(x.to(DEV).view(nutt * T, cin), wn, n_out, T=T, taps=taps, pad=pad, bias=b.to(DEV))
+    assert relerr(got.view(nutt, T, n_out), want) < 1e-5
+    got_r = K.conv_gemm(x.to(DEV).view(nutt * T, cin), wn, n_out, T=T, taps=taps, pad=pad, bias=b.to(DEV), epi=K.EPI_RELU)
+    assert relerr(got_r.view(nutt, T, n_out), F.relu(want)) < 1e-5
+
+
+def test_conv_gemm_epilogues_and_nn_mode():
+    from optispeech_amd import kernels as K
+    M, C, I = 300, 256, 1024
+    h, W1, b1 = rnd(M, C, seed=1), rnd(I, C, seed=2, scale=0.06), rnd(I, seed=3, scale=0.1)
+    u_want = F.linear(h, W1, b1)
+    u = torch.empty(M, I, device=DEV)
+    g = K.conv_gemm(h.to(DEV), W1.to(DEV), I, epi=K.EPI_GELU, bias=b1.to(DEV), aux_out=u)
+    assert relerr(u, u_want) < 1e-5 and relerr(g, F.gelu(u_want)) < 1e-5
+    W2, b2, gam = rnd(C, I, seed=4, scale=0.03), rnd(C, seed=5, scale=0.1), rnd(C, seed=6)
+    res, mask, rs = rnd(M, C, seed=7), (torch.arange(M) % 7 != 0).float(), torch.rand(M, generator=torch.Generator().manual_seed(8))
+    gw = F.gelu(u_want)
+    z_want = F.linear(gw, W2, b2)
+    y_want = (res + rs[:, None] * gam * z_want) * mask[:, None]
+    z = torch.empty(M, C, device=DEV)
+    y = K.conv_gemm(g, W2.to(DEV), C, epi=K.EPI_SCALE_RES_MASK, bias=b2.to(DEV), gamma=gam.to(DEV), res=res.to(DEV),
+                    rowmask=mask.to(DEV), rowscale=rs.to(DEV), aux_out=z)
+    assert relerr(z, z_want) < 1e-5 and relerr(y, y_want) < 1e-5
+    # NN mode (dgrad): dg = dy @ W2, fused gelu' and row scale
+    dy = rnd(M, C, seed=9)
+    du_want = rs[:, None] * (dy @ W2) * (torch.autograd.functional.jvp(F.gelu, u_want, torch.ones_like(u_want))[1])
+    du = K.conv_gemm(dy.to(DEV), W2.to(DEV), I, cin=C, w_strides=(1, 0, I), epi=K.EPI_GELU_BWD, rowscale=rs.to(DEV), aux_in=u)
+    assert relerr(du, du_want) < 1e-5
+
+
+@pytest.mark.parametrize("nutt,T,cin,taps,n_out", [(2, 50, 256, 1, 1024), (3, 37, 100, 3, 256), (2, 33, 256, 7, 384),
+                                                   (2, 40, 1, 9, 256), (4, 128, 384, 1, 1), (4, 800, 1024, 1, 256)])
+def test_conv_wgrad(nutt, T, cin, taps, n_out):
+    from optispeech_amd import kernels as K
+    pad = (taps - 1) // 2
+    x = rnd(nutt, T, cin, seed=1).requires_grad_(False)
+    w = rnd(n_out, cin, taps, seed=2).requires_grad_(True)
+    b = rnd(n_out, seed=3).requires_grad_(True)
+    dy = rnd(nutt, T, n_out, seed=4)
+    arow = torch.rand(nutt * T, generator=torch.Generator().manual_seed(5))
+    osc = rnd(n_out, seed=6)
+    y = ON.conv1d_cl(x, w, b, pad)
+    (y * dy * arow.view(nutt, T, 1) * osc).sum().backward()
+    dw = torch.zeros(n_out, taps, cin, device=DEV)
+    db = torch.zeros(n_out, device=DEV)
+    K.conv_wgrad(dy.to(DEV).view(nutt * T, n_out), x.to(DEV).view(nutt * T, cin), dw, db, T=T, taps=taps, pad=pad,
+                 arow=arow.to(DEV), oscale=osc.to(DEV))
+    assert relerr(dw.permute(0, 2, 1), w.grad) < 2e-5
+    assert relerr(db, b.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ ConvNeXt
+@pytest.mark.parametrize("B,T,C", [(2, 37, 256), (3, 64, 384), (1, 5, 64), (2, 130, 512)])
+def test_dwconv_ln_forward_backward(B, T, C):
+    from optispeech_amd import kernels as K
+    x = rnd(B, T, C, seed=1).requires_grad_(True)
+    dw, dwb = rnd(C, 1, 7, seed=2, scale=0.3).requires_grad_(True), rnd(C, seed=3, scale=0.1).requires_grad_(True)
+    lw, lb = (1 + 0.1 * rnd(C, seed=4)).requires_grad_(True), rnd(C, seed=5, scale=0.1).requires_grad_(True)
+    c = F.conv1d(x.transpose(1, 2), dw, dwb, padding=3, groups=C).transpose(1, 2)
+    h = F.layer_norm(c, (C,), lw, lb, 1e-6)
+    dh = rnd(B, T, C, seed=6)
+    h.backward(dh)
+    dwn = dw.detach()[:, 0, :].t().contiguous().to(DEV)
+    hg, xhat, rstd = K.dwconv7_ln_fwd(x.detach().to(DEV), dwn, dwb.detach().to(DEV), lw.detach().to(DEV), lb.detach().to(DEV), 1e-6, True)
+    assert relerr(hg, h) < 1e-5
+    glw, glb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dc = K.layernorm_bwd(dh.to(DEV).view(B * T, C), xhat.view(B * T, C), None, rstd.view(-1), lw.detach().to(DEV), glw, glb)
+    gdw, gdb = torch.zeros(7, C, device=DEV), torch.zeros(C, device=DEV)
+    dx = K.dwconv7_bwd(dc.view(B, T, C), x.detach().to(DEV), dwn, None, None, gdw, gdb)
+    assert relerr(dx, x.grad) < 2e-5
+    assert relerr(glw, lw.grad) < 2e-5 and relerr(glb, lb.grad) < 2e-5
+    assert relerr(gdw.t(), dw.grad[:, 0, :]) < 2e-5 and relerr(gdb, dwb.grad) < 2e-5
+
+
+def test_layernorm_dropout_mask_consistency():
+    from optispeech_amd import kernels as K
+    rows, C, p = 512, 384, 0.5
+    x, w, b = rnd(rows, C, seed=1).to(DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    y0, mean, rstd = K.layernorm_fwd(x, w, b, 1e-12)
+    want = F.layer_norm(x.cpu(), (C,), eps=1e-12)
+    assert relerr(y0, want) < 1e-5
+    y, mean, rstd = K.layernorm_fwd(x, w, b, 1e-12, drop_p=p, seed=99, stream_id=3)
+    keep = (y != 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01
+    assert relerr(y[keep], (y0 / (1 - p))[keep]) < 1e-6
+    # backward regenerates the identical mask: d/dx of sum(y) through dropout only where kept
+    dy = torch.ones_like(y)
+    gw, gb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    K.layernorm_bwd(dy, x, mean, rstd, w, gw, gb, drop_p=p, seed=99, stream_id=3)
+    assert relerr(gb, keep.float().sum(0) / (1 - p)) < 1e-5
+    y2, _, _ = K.layernorm_fwd(x, w, b, 1e-12, drop_p=p, seed=100, stream_id=3)
+    assert (y2 != 0).ne(keep).float().mean().item() > 0.3
+
+
+@pytest.mark.parametrize("C,I,L", [(256, 1024, 4), (384, 1152, 3)])
+def test_convnext_backbone_vs_oracle(C, I, L):
+    from optispeech_amd.model.modules import ConvNeXtBackbone
+    torch.manual_seed(0)
+    B, T = 3, 77
+    sch = {}
+    S._convnext(sch, "bb.", C, I, L)
+    P = S.make_weights(sch, 11)
+    for v in P.values():
+        v.requires_grad_(True)
+    lens = torch.tensor([77, 50, 9])
+    pad = torch.arange(T)[None, :] >= lens[:, None]
+    x = rnd(B, T, C, seed=3).requires_grad_(True)
+    y = ON.convnext_backbone(x, P, "bb.", pad)
+    dy = rnd(B, T, C, seed=4)
+    y.backward(dy)
+    m = ConvNeXtBackbone(C, I, L).to(DEV)
+    m.load_state_dict({k[3:]: v.detach() for k, v in P.items()})
+    sd = m.state_dict()
+    for k, v in P.items():                                   # schema round trip
+        assert torch.equal(sd[k[3:]].cpu(), v.detach()), k
+    xg = x.detach().to(DEV).requires_grad_(True)
+    yg = m(xg, pad.to(DEV))
+    assert relerr(yg, y) < 1e-4
+    yg.backward(dy.to(DEV))
+    assert relerr(xg.grad, x.grad) < 1e-4
+    got = {k: v for k, v in m.state_dict(keep_vars=True).items()}
+    named = dict(m.named_parameters())
+    ref_grads = {k[3:]: v.grad for k, v in P.items()}
+    from optispeech_amd.model.base import dw_to_ref
+    for name, p in named.items():
+        mod_name, leaf = name.rsplit(".", 1)
+        mod = m.get_submodule(mod_name)
+        key, _, to_ref = mod._ref(leaf)
+        g = to_ref(p.grad) if to_ref else p.grad
+        assert relerr(g, ref_grads[mod_name + "." + key]) < 2e-4, name
+    # eval-mode / no-grad path gives the same forward
+    with torch.no_grad():
+        assert relerr(m(xg, pad.to(DEV)), y) < 1e-4
