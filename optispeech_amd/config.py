@@ -1,0 +1,91 @@
+"""Configuration values of the reference's ConvNeXt model (configs/model/optispeech.yaml and the files it
+composes) as plain dataclasses, and builders that instantiate the modules through the
+same ``functools.partial`` contract Hydra uses upstream."""
+from dataclasses import dataclass, field
+from functools import partial
+from types import SimpleNamespace
+
+import torch
+
+
+@dataclass
+class FeatureExtractorArgs:             # configs/data/feature_extractor/22.05khz.yaml over default.yaml
+    sample_rate: int = 22050
+    n_feats: int = 100
+    n_fft: int = 1024
+    hop_length: int = 256
+    win_length: int = 1024
+    f_min: int = 80
+    f_max: int = 8000
+    center: bool = True
+
+
+@dataclass
+class ModelConfig:
+    dim: int = 256                                        # configs/model/optispeech.yaml:10
+    n_vocab: int = 250                                    # text_embedding/default.yaml
+    text_dropout: float = 0.1
+    max_source_positions: int = 2000
+    enc_layers: int = 4                                   # encoder/convnext.yaml
+    enc_inter: int = 1024
+    enc_drop_path: float = 0.2
+    dec_layers: int = 4                                   # decoder/convnext.yaml
+    dec_inter: int = 1024
+    dec_drop_path: float = 0.2
+    dur: tuple = (2, 384, 3, 0.1)                         # layers, channels, kernel, dropout
+    pitch: tuple = (5, 256, 5, 0.5)
+    energy: tuple = (2, 384, 3, 0.5)
+    embed_kernel: int = 9
+    pitch_embed_dropout: float = 0.2
+    energy_embed_dropout: float = 0.5
+    voc_dim: int = 384                                    # vocoder/wavenext.yaml
+    voc_inter: int = 1152
+    voc_layers: int = 8
+    voc_drop_path: float = 0.1
+    segment_size: int = 64                                # generator/default.yaml:12
+    lambda_align: float = 5.0
+    lambda_duration: float = 1.0
+    lambda_pitch: float = 1.0
+    lambda_energy: float = 1.0
+    lambda_mrd: float = 1.0                               # discriminator/vocos_disc.yaml
+    lambda_mel: float = 45.0
+    lambda_mr_stft: float = 2.5
+    fe: FeatureExtractorArgs = field(default_factory=FeatureExtractorArgs)
+
+    def no_dropout(self):
+        """Copy with every stochastic rate set to 0 (parity tests)."""
+        import copy
+        c = copy.deepcopy(self)
+        c.text_dropout = c.enc_drop_path = c.dec_drop_path = c.voc_drop_path = 0.0
+        c.pitch_embed_dropout = c.energy_embed_dropout = 0.0
+        c.dur, c.pitch, c.energy = c.dur[:3] + (0.0,), c.pitch[:3] + (0.0,), c.energy[:3] + (0.0,)
+        return c
+
+
+def make_generator(c: ModelConfig):
+    from .model.generator import OptiSpeechGenerator
+    from .model.modules import (ConvNeXtBackbone, DurationPredictor, EnergyPredictor, PitchPredictor, TextEmbedding)
+    from .model.vocoder import WaveNeXt
+
+    def pred(cls, spec, **kw):
+        return partial(cls, num_layers=spec[0], intermediate_dim=spec[1], kernel_size=spec[2], dropout=spec[3],
+                       conv_layer_class=torch.nn.Conv1d, **kw)
+
+    loss_coeffs = SimpleNamespace(lambda_align=c.lambda_align, lambda_duration=c.lambda_duration,
+                                  lambda_pitch=c.lambda_pitch, lambda_energy=c.lambda_energy)
+    return OptiSpeechGenerator(
+        dim=c.dim, segment_size=c.segment_size,
+        text_embedding=partial(TextEmbedding, n_vocab=c.n_vocab, dropout=c.text_dropout, padding_idx=0,
+                               max_source_positions=c.max_source_positions),
+        encoder=partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers,
+                        drop_path=c.enc_drop_path),
+        duration_predictor=pred(DurationPredictor, c.dur),
+        pitch_predictor=pred(PitchPredictor, c.pitch, embed_kernel_size=c.embed_kernel,
+                             embed_dropout=c.pitch_embed_dropout),
+        energy_predictor=pred(EnergyPredictor, c.energy, embed_kernel_size=c.embed_kernel,
+                              embed_dropout=c.energy_embed_dropout),
+        decoder=partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers,
+                        drop_path=c.dec_drop_path),
+        vocoder=partial(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers,
+                        drop_path=c.voc_drop_path),
+        loss_coeffs=loss_coeffs, feature_extractor=c.fe, num_speakers=1, num_languages=1, data_statistics=None)

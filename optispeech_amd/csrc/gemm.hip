@@ -307,6 +307,7 @@ struct WgradP {
     const float *arow, *oscale;
     float* dW; int64_t ldw; float* db;
     int chunk; int y_vec, x_vec;
+    int splits; int64_t sYb, sXb, sWb, sDb;   // batched: blockIdx.z = batch * splits + split
 };
 
 template <int BMo, int BNo>
@@ -324,7 +325,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(WgradP p) {
     const int ctiles = (p.Cin + BNo - 1) / BNo;
     const int j = blockIdx.y / ctiles, c0 = (blockIdx.y - j * ctiles) * BNo;
     const int n0 = blockIdx.x * BMo;
-    const int mbeg = blockIdx.z * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z - bz * p.splits;
+    const float* dYb = p.dY + (int64_t)bz * p.sYb;
+    const float* Xb = p.X + (int64_t)bz * p.sXb;
+    const float* arow = p.arow ? p.arow + (int64_t)bz * p.M : nullptr;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
     const int a_c4 = tid % A4, a_k0 = tid / A4, b_c4 = tid % B4, b_k0 = tid / B4;
 
     f32x16 acc[TM][TN];
@@ -344,8 +349,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(WgradP p) {
             const int m = mk + a_k0 + A_KSTEP * i, n = n0 + 4 * a_c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < mend) {
-                v = ld4_guard(p.dY + (int64_t)m * p.ldy + n, n, p.N, p.y_vec);
-                if (p.arow) { const float s = p.arow[m]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+                v = ld4_guard(dYb + (int64_t)m * p.ldy + n, n, p.N, p.y_vec);
+                if (arow) { const float s = arow[m]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
             }
             ra[i] = v;
         }
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(WgradP p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < mend) {
                 const int tt = (m % p.T) + j - p.pad;
-                if (tt >= 0 && tt < p.T) v = ld4_guard(p.X + ((int64_t)m + j - p.pad) * p.ldx + c, c, p.Cin, p.x_vec);
+                if (tt >= 0 && tt < p.T) v = ld4_guard(Xb + ((int64_t)m + j - p.pad) * p.ldx + c, c, p.Cin, p.x_vec);
             }
             rb[i] = v;
         }
@@ -401,32 +406,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(WgradP p) {
                 const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (n >= p.N) continue;
                 const float s = p.oscale ? p.oscale[n] : 1.f;
-                atomicAdd(p.dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c, s * acc[i][jj][r]);
+                atomicAdd(p.dW + (int64_t)bz * p.sWb + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c, s * acc[i][jj][r]);
             }
         }
-    if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, (p.oscale ? p.oscale[n0 + tid] : 1.f) * bsum);
+    if (do_bias && n0 + tid < p.N)
+        atomicAdd(p.db + (int64_t)bz * p.sDb + n0 + tid, (p.oscale ? p.oscale[n0 + tid] : 1.f) * bsum);
 }
 
 extern "C" int osp_conv_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T,
                                   int64_t N, int64_t Cin, int64_t taps, int64_t pad, const float* arow,
-                                  const float* oscale, float* dW, int64_t ldw, float* db, hipStream_t stream) {
+                                  const float* oscale, float* dW, int64_t ldw, float* db, int64_t batch, int64_t sYb,
+                                  int64_t sXb, int64_t sWb, int64_t sDb, hipStream_t stream) {
     OSP_CHECK_ARG(dY && X && dW, "null operand");
+    OSP_CHECK_ARG(batch > 0, "batch");
     OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && T > 0 && M % T == 0, "bad shape");
     WgradP p;
     p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.M = (int)M; p.T = (int)T; p.N = (int)N; p.Cin = (int)Cin;
     p.taps = (int)taps; p.pad = (int)pad; p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db;
-    p.y_vec = aligned16(dY) && (ldy % 4 == 0);
-    p.x_vec = aligned16(X) && (ldx % 4 == 0);
+    p.y_vec = aligned16(dY) && (ldy % 4 == 0) && (sYb % 4 == 0);
+    p.x_vec = aligned16(X) && (ldx % 4 == 0) && (sXb % 4 == 0);
+    p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb;
     const bool big = (N >= 128 && Cin >= 128);
     const int bmo = big ? 128 : 64;
-    const int64_t tiles = cdiv(N, bmo) * taps * cdiv(Cin, bmo);
+    const int64_t tiles = cdiv(N, bmo) * taps * cdiv(Cin, bmo) * batch;
     // split the frame dimension until ~2 blocks per CU are in flight (chunk multiple of BK)
     int64_t splits = cdiv(512, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), BK) * BK;
     if (chunk < 4 * BK) chunk = 4 * BK;
     splits = cdiv(M, chunk);
     p.chunk = (int)chunk;
-    dim3 grid((unsigned)cdiv(N, bmo), (unsigned)(taps * cdiv(Cin, bmo)), (unsigned)splits);
+    p.splits = (int)splits;
+    dim3 grid((unsigned)cdiv(N, bmo), (unsigned)(taps * cdiv(Cin, bmo)), (unsigned)(splits * batch));
     if (big) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 64>), grid, dim3(256), 0, stream, p);
     OSP_LAUNCH_CHECK();

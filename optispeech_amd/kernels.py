@@ -46,15 +46,17 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
     return out
 
 
-def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=None):
+def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=None, batch=1):
     """dw[n, j, c] += oscale[n] * sum_m arow[m] dy[m, n] x[m + j - pad, c];  db[n] += oscale[n] * sum_m arow[m] dy[m, n]."""
     _f32(dy, x, dw, db, arow, oscale)
     M, N = dy.shape[-2], dy.shape[-1]
     cin = x.shape[-1]
     T = M if T is None else T
-    assert dw.is_contiguous() and dw.numel() == N * taps * cin, (dw.shape, N, taps, cin)
+    assert dw.is_contiguous() and dw.numel() == batch * N * taps * cin, (dw.shape, N, taps, cin)
+    sy = dy.stride(0) if batch > 1 else 0
+    sx = x.stride(0) if batch > 1 else 0
     call("osp_conv_wgrad_f32", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
-         taps * cin, db)
+         taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
 
 
 def dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, eps, save):
@@ -99,3 +101,168 @@ def layernorm_bwd(dy, xin, mean, rstd, w, dlnw, dlnb, *, relu_src=None, rowmask=
     call("osp_layernorm_bwd", dy, xin, mean, rstd, w, relu_src, rowmask, float(drop_p), int(seed), int(stream_id),
          dx, dlnw, dlnb, rows, C)
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ alignment
+_LGAMMA = {}
+
+
+def lgamma_table(device, n):
+    """f64 table lg[i] = lgamma(i) on the device (cached; grown on demand)."""
+    key = str(device)
+    t = _LGAMMA.get(key)
+    if t is None or t.numel() < n:
+        n = max(n, 8192)
+        t = torch.empty((n,), device=device, dtype=torch.float64)
+        call("osp_lgamma_table", t, n)
+        _LGAMMA[key] = t
+    return t
+
+
+def _lens(*ts):
+    for t in ts:
+        assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+
+
+def betabinom_prior(x_len, y_len, Tm, Nm):
+    _lens(x_len, y_len)
+    B = x_len.numel()
+    lg = lgamma_table(x_len.device, Tm + Nm + 4)
+    out = torch.empty((B, Tm, Nm), device=x_len.device, dtype=torch.float32)
+    call("osp_betabinom_prior", lg, lg.numel(), x_len, y_len, out, B, Tm, Nm)
+    return out
+
+
+def pairwise_score(f, e, x_len):
+    _f32(f, e)
+    _lens(x_len)
+    B, Tm, C = f.shape
+    Nm = e.shape[1]
+    assert f.is_contiguous() and e.is_contiguous()
+    score = torch.empty((B, Tm, Nm), device=f.device, dtype=torch.float32)
+    call("osp_pairwise_score", f, e, x_len, score, B, Tm, Nm, C)
+    return score
+
+
+def logsoftmax_prior_fwd(score, prior):
+    B, Tm, Nm = score.shape
+    lp = torch.empty_like(score)
+    lse = torch.empty((B, Tm), device=score.device, dtype=torch.float32)
+    call("osp_logsoftmax_prior_fwd", score, prior, lp, lse, B * Tm, Nm)
+    return lp, lse
+
+
+def logsoftmax_prior_bwd(dlp, score, lse, x_len, y_len):
+    B, Tm, Nm = score.shape
+    w = torch.empty_like(score)
+    wrow = torch.empty((B, Tm), device=score.device, dtype=torch.float32)
+    call("osp_logsoftmax_prior_bwd", dlp.contiguous(), score, lse, x_len, y_len, w, wrow, B, Tm, Nm)
+    return w, wrow
+
+
+def mas(lp, x_len, y_len):
+    """-> path int32 (B,Tm) [valid t < y_len], durations f32 (B,Nm), bin_item f32 (B,) = -mean_t lp[t, path[t]]."""
+    _f32(lp)
+    _lens(x_len, y_len)
+    B, Tm, Nm = lp.shape
+    assert lp.is_contiguous()
+    path = torch.zeros((B, Tm), device=lp.device, dtype=torch.int32)
+    dur = torch.empty((B, Nm), device=lp.device, dtype=torch.float32)
+    bin_item = torch.zeros((B,), device=lp.device, dtype=torch.float32)
+    from ._lib import lib
+    import ctypes
+    f = lib().cdll.osp_mas_workspace_bytes
+    f.restype = ctypes.c_int64
+    nbytes = f(ctypes.c_int64(B), ctypes.c_int64(Tm), ctypes.c_int64(Nm))
+    ws = torch.empty((max(nbytes, 8) // 8,), device=lp.device, dtype=torch.int64) if nbytes else None
+    call("osp_mas", lp, x_len, y_len, path, dur, bin_item, ws, B, Tm, Nm)
+    return path, dur, bin_item
+
+
+def bin_loss_bwd(path, y_len, gscale, dlp):
+    B, Tm, Nm = dlp.shape
+    call("osp_bin_loss_bwd", path, y_len, gscale, dlp, B, Tm, Nm)
+
+
+def duration_stats(ds, xs0=None, xs1=None, x_len=None, y_len=None, want_centre=False):
+    """token-level averages of xs0/xs1 by duration, and/or gaussian-upsampling centres cumsum(d) - d/2."""
+    _f32(ds, xs0, xs1)
+    B, Nm = ds.shape
+    Tm = xs0.shape[1] if xs0 is not None else 0
+    a0 = torch.empty((B, Nm), device=ds.device, dtype=torch.float32) if xs0 is not None else None
+    a1 = torch.empty((B, Nm), device=ds.device, dtype=torch.float32) if xs1 is not None else None
+    ce = torch.empty((B, Nm), device=ds.device, dtype=torch.float32) if want_centre else None
+    call("osp_duration_stats", ds.contiguous(), xs0, xs1, x_len, y_len, a0, a1, ce, B, Tm, Nm)
+    return a0, a1, ce
+
+
+def gaussian_weights(centre, x_len, y_len, Tm, delta=0.1):
+    B, Nm = centre.shape
+    P = torch.empty((B, Tm, Nm), device=centre.device, dtype=torch.float32)
+    call("osp_gaussian_weights", centre, x_len, y_len, float(delta), P, B, Tm, Nm)
+    return P
+
+
+def gather_rows(src, start, S, mult=1):
+    """out[b, s, :] = src[b, start[b]*mult + s, :]; src (B,T,C)."""
+    _f32(src)
+    _lens(start)
+    B, T, C = src.shape
+    assert src.is_contiguous()
+    out = torch.empty((B, S, C), device=src.device, dtype=torch.float32)
+    call("osp_gather_rows", src, start, mult, out, B, T, S, C)
+    return out
+
+
+def expand_by_duration(x, dur, Tout):
+    _f32(x)
+    _lens(dur)
+    B, Nm, C = x.shape
+    out = torch.empty((B, Tout, C), device=x.device, dtype=torch.float32)
+    call("osp_expand_by_duration", x.contiguous(), dur, out, B, Nm, Tout, C)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def variance_losses(d_hat, p_hat, e_hat, ds, ps, es, x_len, clip_val=1e-8):
+    _f32(d_hat, p_hat, e_hat, ds, ps, es)
+    _lens(x_len)
+    B, T = d_hat.shape
+    out = torch.empty((3,), device=d_hat.device, dtype=torch.float32)
+    gd, gp, ge = torch.empty_like(d_hat), torch.empty_like(d_hat), torch.empty_like(d_hat)
+    call("osp_variance_losses", d_hat.contiguous(), p_hat.contiguous(), e_hat.contiguous(), ds.contiguous(),
+         ps.contiguous(), es.contiguous(), x_len, float(clip_val), out, gd, gp, ge, B, T)
+    return out, gd, gp, ge
+
+
+def forwardsum_ctc(lp, x_len, y_len, want_grad=True, blank_logprob=-1.0):
+    """-> loss_item (B,) [ctc_b / N_b], grad (B,Tm,Nm) of sum_b loss_item/B w.r.t. lp (or None)."""
+    _f32(lp)
+    _lens(x_len, y_len)
+    B, Tm, Nm = lp.shape
+    from ._lib import lib
+    import ctypes
+    f = lib().cdll.osp_forwardsum_ctc_workspace_floats
+    f.restype = ctypes.c_int64
+    n = f(ctypes.c_int64(B), ctypes.c_int64(Tm), ctypes.c_int64(Nm))
+    ws = torch.empty((n,), device=lp.device, dtype=torch.float32)
+    loss_item = torch.empty((B,), device=lp.device, dtype=torch.float32)
+    grad = torch.empty_like(lp) if want_grad else None
+    call("osp_forwardsum_ctc", lp, x_len, y_len, float(blank_logprob), ws, loss_item, grad, B, Tm, Nm)
+    return loss_item, grad
+
+
+# ------------------------------------------------------------------------------------------------ text embedding
+def text_embed_fwd(tok, E, pos, scale, drop_p=0.0, seed=0, stream_id=0):
+    B, T = tok.shape
+    C = E.shape[1]
+    assert tok.dtype == torch.int64 and tok.is_contiguous() and pos.shape[0] >= T and pos.shape[1] == C
+    out = torch.empty((B, T, C), device=E.device, dtype=torch.float32)
+    call("osp_text_embed_fwd", tok, E, pos, scale, float(C) ** 0.5, float(drop_p), int(seed), int(stream_id), out, B, T, C)
+    return out
+
+
+def text_embed_bwd(dy, tok, pos, dE, dscale, padding_idx=0, drop_p=0.0, seed=0, stream_id=0):
+    B, T, C = dy.shape
+    call("osp_text_embed_bwd", dy.contiguous(), tok, pos, float(C) ** 0.5, float(drop_p), int(seed), int(stream_id),
+         int(padding_idx), dE, dscale, B, T, C)

@@ -1,0 +1,161 @@
+"""Host-side mirror of optispeech/model/generator/__init__.py (OptiSpeechGenerator).
+
+Same constructor (partials for the sub-modules), same ``forward`` / ``synthesise`` signatures and output
+dicts.  Differences that are invisible at the interface: activations stay channels-last, and the
+alignment search / duration averaging / segment slicing run on the device, so a training step has no
+host round trip (the reference has >= 2B+4).
+"""
+from time import perf_counter
+
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .. import ops
+from .alignments import (AlignmentModule, GaussianUpsampling, average_by_duration, expand_by_duration,
+                         viterbi_decode)
+
+
+def sequence_mask(length, max_length=None):
+    """utils/model.py:12-16."""
+    if max_length is None:
+        max_length = length.max()
+    x = torch.arange(max_length, dtype=length.dtype, device=length.device)
+    return x.unsqueeze(0) < length.unsqueeze(1)
+
+
+class OptiSpeechGenerator(nn.Module):
+    def __init__(self, dim: int, segment_size, text_embedding, encoder, duration_predictor, pitch_predictor,
+                 energy_predictor, decoder, vocoder, loss_coeffs, feature_extractor, num_speakers, num_languages,
+                 data_statistics, **kwargs):
+        super().__init__()
+        self.segment_size = segment_size
+        self.loss_coeffs = loss_coeffs
+        self.n_feats = feature_extractor.n_feats
+        self.n_fft = feature_extractor.n_fft
+        self.hop_length = feature_extractor.hop_length
+        self.sample_rate = feature_extractor.sample_rate
+        self.data_statistics = data_statistics
+        self.num_speakers = num_speakers
+        self.num_languages = num_languages
+
+        self.text_embedding = text_embedding(dim=dim)
+        self.encoder = encoder(dim=dim)
+        self.duration_predictor = duration_predictor(dim=dim)
+        self.alignment_module = AlignmentModule(adim=dim, odim=self.n_feats)
+        self.pitch_predictor = pitch_predictor(dim=dim)
+        self.energy_predictor = energy_predictor(dim=dim)
+        self.feature_upsampler = GaussianUpsampling()
+        self.decoder = decoder(dim=dim)
+        self.vocoder = vocoder(input_channels=dim, sample_rate=self.sample_rate, n_fft=self.n_fft,
+                               hop_length=self.hop_length)
+        if self.num_speakers > 1:
+            self.sid_embed = torch.nn.Embedding(self.num_speakers, dim)
+        if self.num_languages > 1:
+            self.lid_embed = torch.nn.Embedding(self.num_languages, dim)
+        #: test hook: fixed uniform draws in [0,1) for the segment starts (None = torch.rand)
+        self.segment_rand01 = None
+
+    # ------------------------------------------------------------------------------------------ training forward
+    def forward(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids):
+        """generator/__init__.py:72-192.  ``mel`` arrives in the reference layout (B, n_feats, T_mel)."""
+        B = x.shape[0]
+        Tt, Tm = x.shape[1], mel.shape[2]
+        x_lengths = x_lengths.contiguous()
+        mel_lengths = mel_lengths.contiguous()
+        input_padding_mask = ~sequence_mask(x_lengths, Tt)                  # :96-102
+        target_padding_mask = ~sequence_mask(mel_lengths, Tm)               # :99-103
+
+        h, _ = self.text_embedding(x)                                       # :106
+        h = self.encoder(h, input_padding_mask)                             # :109
+        if sids is not None:
+            h = h + self.sid_embed(sids.view(-1)).unsqueeze(1)              # :112-114
+        if lids is not None:
+            h = h + self.lid_embed(lids.view(-1)).unsqueeze(1)              # :115-117
+
+        feats = mel.transpose(1, 2).contiguous()                            # :122
+        log_p_attn = self.alignment_module(text=h, feats=feats, text_lengths=x_lengths, feats_lengths=mel_lengths,
+                                           x_masks=input_padding_mask)      # :120-126
+        durations, path, bin_item = viterbi_decode(log_p_attn, x_lengths, mel_lengths)      # :127
+        duration_hat = self.duration_predictor(h.detach(), input_padding_mask)              # :128
+        p_avg, e_avg = average_by_duration(durations, pitches, energies, x_lengths, mel_lengths)   # :131-132
+        h, pitch_hat = self.pitch_predictor(h, input_padding_mask, p_avg)                   # :135
+        h, energy_hat = self.energy_predictor(h, input_padding_mask, e_avg)                 # :136
+        y = self.feature_upsampler(h, durations, x_lengths, mel_lengths, Tm)                # :139-141
+        y = self.decoder(y, target_padding_mask)                                            # :144
+
+        segment_size = min(self.segment_size, y.shape[1])                                   # :147
+        num_frames = (mel_lengths - 4).to(torch.float32)                                    # :148
+        max_start = (num_frames - segment_size).clamp_(min=0)                               # utils/segments.py:29-31
+        r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=y.device)
+        start_idx = (r.to(y.device) * max_start).to(torch.long)                             # utils/segments.py:32-34
+        segment = K.gather_rows(y.detach(), start_idx, segment_size)                        # :149-153, detach :161
+        wav_hat = self.vocoder(segment, f0=None)                                            # :161 (f0 unused by WaveNeXt)
+
+        c = self.loss_coeffs
+        duration_loss, pitch_loss, energy_loss = ops.VarianceLossFn.apply(
+            duration_hat, pitch_hat, energy_hat, durations, p_avg, e_avg, x_lengths)        # :165-173
+        forwardsum_loss, bin_loss = ops.AlignLossFn.apply(log_p_attn, x_lengths, mel_lengths, path, bin_item)  # :174
+        align_loss = forwardsum_loss + bin_loss                                             # :175
+        loss = (align_loss * c.lambda_align + duration_loss * c.lambda_duration + pitch_loss * c.lambda_pitch
+                + energy_loss * c.lambda_energy)                                            # :176-181
+        # NB: the reference moves the sub-losses to the CPU here (4 device syncs); we keep them on the device and
+        # let the caller fetch all scalars with one copy.
+        return {"wav_hat": wav_hat, "start_idx": start_idx, "segment_size": segment_size, "loss": loss,
+                "align_loss": align_loss.detach(), "duration_loss": duration_loss.detach(),
+                "pitch_loss": pitch_loss.detach(), "energy_loss": energy_loss.detach(),
+                "_aux": {"log_p_attn": log_p_attn, "durations": durations, "path": path, "p_avg": p_avg,
+                         "e_avg": e_avg, "duration_hat": duration_hat, "pitch_hat": pitch_hat,
+                         "energy_hat": energy_hat, "decoder_out": y, "segment": segment,
+                         "bin_loss": bin_loss.detach(), "forwardsum_loss": forwardsum_loss.detach()}}
+
+    # ------------------------------------------------------------------------------------------ inference
+    @torch.inference_mode()
+    def synthesise(self, x, x_lengths, sids=None, lids=None, d_factor=1.0, p_factor=1.0, e_factor=1.0,
+                   durations_override=None):
+        """generator/__init__.py:194-301.  ``durations_override`` is a benchmarking hook (random-init weights
+        predict degenerate durations)."""
+        dev = x.device
+        torch.cuda.synchronize(dev)
+        am_t0 = perf_counter()
+        x_lengths = x_lengths.to(dev).contiguous()
+        Tt = x.shape[1]
+        input_padding_mask = ~sequence_mask(x_lengths, Tt)
+        h, _ = self.text_embedding(x)                                       # :229
+        h = self.encoder(h, input_padding_mask)                             # :232
+        if (self.num_speakers > 1) and sids is None:
+            sids = torch.zeros(x.shape[0], dtype=torch.long, device=dev)
+        if (self.num_languages > 1) and lids is None:
+            lids = torch.zeros(x.shape[0], dtype=torch.long, device=dev)
+        if sids is not None:
+            h = h + self.sid_embed(sids.view(-1)).unsqueeze(1)
+        if lids is not None:
+            h = h + self.lid_embed(lids.view(-1)).unsqueeze(1)
+        durations = self.duration_predictor.infer(h, input_padding_mask, factor=d_factor)   # :249
+        if durations_override is not None:
+            durations = durations_override.to(dev).masked_fill(input_padding_mask, 0)
+        h, pitch = self.pitch_predictor.infer(h, input_padding_mask, p_factor)              # :252
+        h, energy = self.energy_predictor.infer(h, input_padding_mask, e_factor)            # :254
+        y_lengths = durations.sum(dim=1)                                                    # :258
+        y_max_length = int(y_lengths.max())                                                 # data-dependent shape: 1 sync
+        if int(durations.sum()) == 0:                                                       # alignments.py:152-157
+            durations = torch.ones_like(durations)
+            y_lengths = durations.sum(dim=1)
+            y_max_length = int(y_lengths.max())
+        target_padding_mask = ~sequence_mask(y_lengths, y_max_length)
+        y = self.feature_upsampler(h, durations, x_lengths, y_lengths.contiguous(), y_max_length)   # :263-265
+        y = self.decoder(y, target_padding_mask)                                            # :268
+        torch.cuda.synchronize(dev)
+        am_infer = (perf_counter() - am_t0) * 1000
+        v_t0 = perf_counter()
+        f0_cond, _ = expand_by_duration(pitch.unsqueeze(-1), durations)                     # :273-276 (unused by WaveNeXt)
+        wav = self.vocoder(y, f0=f0_cond, padding_mask=target_padding_mask)                 # :277-281
+        wav_lengths = y_lengths * self.hop_length                                           # :282
+        torch.cuda.synchronize(dev)
+        v_infer = (perf_counter() - v_t0) * 1000
+        wav_t = wav.shape[-1] / (self.sample_rate * 1e-3)                                   # :285
+        am_rtf, v_rtf = am_infer / wav_t, v_infer / wav_t
+        return {"wav": wav.detach().cpu(), "wav_lengths": wav_lengths.detach().cpu(),
+                "durations": durations.detach().cpu(), "pitch": pitch.detach().cpu(),
+                "energy": energy.detach().cpu(), "am_rtf": am_rtf, "v_rtf": v_rtf, "rtf": am_rtf + v_rtf,
+                "latency": am_infer + v_infer}

@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, rng
 from .base import RefSchemaModule, conv_to_native, conv_to_ref, dw_to_native, dw_to_ref
 
 
@@ -88,3 +88,165 @@ class ConvNeXtBackbone(nn.Module):
         for blk in self.convnext:
             x = blk(x, rm)
         return self.final_layer_norm(x)
+
+
+# =================================================================================================== text embedding
+def _sinusoid_table(T, dim, theta):
+    """ScaledSinusoidalEmbedding buffers (modules/layers.py:54-70) as a (T, dim) constant table, built on the
+    host exactly as the reference does (inv_freq = theta ** -(arange(half)/half); cat(sin, cos))."""
+    half = dim // 2
+    inv_freq = theta ** -(torch.arange(half).float() / half)
+    ang = torch.arange(T).float()[:, None] * inv_freq[None, :]
+    return torch.cat((ang.sin(), ang.cos()), dim=-1).contiguous()
+
+
+class _ScaledSinusoidal(RefSchemaModule):
+    def __init__(self, dim, theta):
+        super().__init__()
+        assert dim % 2 == 0
+        self.dim, self.theta = dim, theta
+        self.scale = nn.Parameter(torch.ones(1) * dim ** -0.5)
+        self.register_buffer("table", _sinusoid_table(256, dim, theta), persistent=False)
+
+    def table_for(self, T, device):
+        if self.table.shape[0] < T or self.table.device != device:
+            self.table = _sinusoid_table(max(T, 2 * self.table.shape[0]), self.dim, self.theta).to(device)
+        return self.table
+
+
+class _EmbedTokens(RefSchemaModule):
+    def __init__(self, n_vocab, dim, padding_idx):
+        super().__init__()
+        self.padding_idx = padding_idx
+        self.weight = nn.Parameter(torch.empty(n_vocab, dim))
+        nn.init.normal_(self.weight)                        # nn.Embedding default init
+        with torch.no_grad():
+            self.weight[padding_idx].zero_()
+
+
+class TextEmbedding(nn.Module):
+    """TextEmbedding (modules/core.py:11-31). forward(src_tokens (B,T) int64) -> (x (B,T,dim), None)."""
+
+    def __init__(self, dim: int, n_vocab: int, dropout: float = 0.0, padding_idx: int = 0,
+                 max_source_positions: int = 2000):
+        super().__init__()
+        assert padding_idx == 0
+        self.dim, self.dropout = dim, float(dropout)
+        self.embed_tokens = _EmbedTokens(n_vocab, dim, padding_idx)
+        self.embed_positions = _ScaledSinusoidal(dim, theta=max_source_positions)
+        self._stream = rng.new_stream()
+
+    def forward(self, src_tokens):
+        p = self.dropout if self.training else 0.0
+        pos = self.embed_positions.table_for(src_tokens.shape[1], src_tokens.device)
+        x = ops.TextEmbedFn.apply(src_tokens.contiguous(), self.embed_tokens.weight, self.embed_positions.scale, pos, p,
+                                  rng.seed(), self._stream)
+        return x, None
+
+
+# =================================================================================================== variance predictors
+class _ConvLayer(RefSchemaModule):
+    """`conv.{i}` Sequential of the reference: .0 = Conv1d, .2 = LayerNorm(dim=1) (core.py:62-76)."""
+    _ref_layout = {"conv_weight": ("0.weight", conv_to_native, conv_to_ref), "conv_bias": ("0.bias", None, None),
+                   "ln_weight": ("2.weight", None, None), "ln_bias": ("2.bias", None, None)}
+
+    def __init__(self, cin, cout, k, dropout):
+        super().__init__()
+        self.k, self.dropout = k, float(dropout)
+        conv = nn.Conv1d(cin, cout, k)                      # reference default init (kaiming-uniform)
+        self.conv_weight = nn.Parameter(conv_to_native(conv.weight.detach()))
+        self.conv_bias = nn.Parameter(conv.bias.detach().clone())
+        self.ln_weight = nn.Parameter(torch.ones(cout))
+        self.ln_bias = nn.Parameter(torch.zeros(cout))
+        self._stream = rng.new_stream()
+
+    def forward(self, x):
+        p = self.dropout if self.training else 0.0
+        return ops.PredictorLayerFn.apply(x, self.conv_weight, self.conv_bias, self.ln_weight, self.ln_bias, self.k, p,
+                                          rng.seed(), self._stream)
+
+
+class _Linear(RefSchemaModule):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        lin = nn.Linear(cin, cout, bias)
+        self.weight = nn.Parameter(lin.weight.detach().clone())
+        self.bias = nn.Parameter(lin.bias.detach().clone()) if bias else None
+
+
+class VariancePredictor(nn.Module):
+    """VariancePredictor (modules/core.py:34-97). forward(x (B,T,dim), padding_mask (B,T) True=pad) -> (B,T)."""
+
+    def __init__(self, dim: int, num_layers: int, intermediate_dim: int, kernel_size: int, dropout: float = 0.1,
+                 conv_layer_class: type = torch.nn.Conv1d):
+        super().__init__()
+        if conv_layer_class is not torch.nn.Conv1d:
+            raise ValueError("only torch.nn.Conv1d predictors are on the ConvNeXt hot path")
+        self.dim, self.conv_layer_class = dim, conv_layer_class
+        self.conv = nn.ModuleList([_ConvLayer(dim if i == 0 else intermediate_dim, intermediate_dim, kernel_size, dropout)
+                                   for i in range(num_layers)])
+        self.linear = _Linear(intermediate_dim, 1)
+
+    def forward(self, x, padding_mask):
+        for layer in self.conv:
+            x = layer(x)
+        y = ops.conv_linear(x, self.linear.weight, self.linear.bias, 1, rowmask=row_mask(padding_mask))
+        return y.squeeze(-1)
+
+
+class DurationPredictor(VariancePredictor):
+    """DurationPredictor (modules/core.py:100-133)."""
+
+    def __init__(self, *args, clip_val=1e-8, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.clip_val = clip_val
+
+    @torch.inference_mode()
+    def infer(self, x, mask, factor=1.0):
+        log_d = self(x, mask)
+        d = torch.exp(log_d) - self.clip_val
+        d = torch.ceil(d * factor)
+        d = torch.clamp(d.long(), min=0)
+        return d.masked_fill(mask, 0)
+
+
+class _EmbedConv(RefSchemaModule):
+    """`embed` Sequential of the reference: .0 = Conv1d(1, dim, k) (+ Dropout) (core.py:141-149)."""
+    _ref_layout = {"weight": ("0.weight", conv_to_native, conv_to_ref), "bias": ("0.bias", None, None)}
+
+    def __init__(self, dim, k):
+        super().__init__()
+        conv = nn.Conv1d(1, dim, k)
+        self.weight = nn.Parameter(conv_to_native(conv.weight.detach()))
+        self.bias = nn.Parameter(conv.bias.detach().clone())
+
+
+class PitchPredictor(nn.Module):
+    """PitchPredictor (modules/core.py:136-176)."""
+
+    def __init__(self, *args, embed_kernel_size=9, embed_dropout=0.1, **kwargs):
+        super().__init__()
+        self.predictor = VariancePredictor(*args, **kwargs)
+        self.dim = kwargs["dim"]
+        self.conv_layer_class = kwargs.get("conv_layer_class", torch.nn.Conv1d)
+        self.embed = _EmbedConv(self.dim, embed_kernel_size)
+        self.embed_dropout = float(embed_dropout)
+        self._stream = rng.new_stream()
+
+    def _add(self, x, values, padding_mask):
+        p = self.embed_dropout if self.training else 0.0
+        return ops.VarianceEmbedFn.apply(x, values, self.embed.weight, self.embed.bias, row_mask(padding_mask), p,
+                                         rng.seed(), self._stream)
+
+    def forward(self, x, padding_mask, target):
+        preds = self.predictor(x, padding_mask)
+        return self._add(x, target, padding_mask), preds
+
+    @torch.inference_mode()
+    def infer(self, x, padding_mask, factor=1.0):
+        preds = self.predictor(x, padding_mask) * factor
+        return self._add(x, preds, padding_mask), preds
+
+
+class EnergyPredictor(PitchPredictor):
+    pass

@@ -108,3 +108,253 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, w, b, eps, rowmask=None, drop_p=0.0, seed=0, stream_id=0):
     return LayerNormFn.apply(x, w, b, eps, rowmask, drop_p, seed, stream_id)
+
+
+# ------------------------------------------------------------------------------------------------ dense conv / linear
+class ConvLinearFn(torch.autograd.Function):
+    """y = act(conv1d_k(x) + b) on channels-last frames (nn.Conv1d / nn.Linear call sites of the path).
+
+    x (B,T,Cin); w: the *parameter itself* holding Cout*taps*Cin floats in native (Cout, taps, Cin) order (any
+    view shape -- it must be the leaf so that its gradient arena slot is found); act in {None, "relu"};
+    rowmask (B*T,) optional output mask.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, b, cout, taps, pad, act, rowmask):
+        B, T, Cin = x.shape
+        assert w.numel() == cout * taps * Cin and w.is_contiguous(), (tuple(w.shape), cout, taps, Cin)
+        x = x.contiguous()
+        epi = K.EPI_RELU if act == "relu" else (K.EPI_MASK if rowmask is not None else K.EPI_NONE)
+        assert not (act == "relu" and rowmask is not None)
+        y = K.conv_gemm(x.view(B * T, Cin), w, cout, T=T, taps=taps, pad=pad, bias=b, epi=epi, rowmask=rowmask)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, y if act == "relu" else None, rowmask)
+            ctx.params = (w, b)
+            ctx.cfg = (cout, taps, pad, act)
+        return y.view(B, T, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, rowmask = ctx.saved_tensors
+        w, b = ctx.params
+        Cout, taps, pad, act = ctx.cfg
+        B, T, Cin = x.shape
+        g = dy.contiguous().view(B * T, Cout)
+        if act == "relu":
+            g = g * (y > 0)
+        # dgrad: dx[m,c] = sum_{j,n} g[m - j + pad, n] w[n, j, c]  == conv with flipped taps over the (n) axis
+        dx = None
+        if ctx.needs_input_grad[0]:
+            base = w.detach().view(Cout, taps, Cin)[:, taps - 1:, :]          # pointer to the last tap
+            dx = K.conv_gemm(g, base, Cin, T=T, taps=taps, pad=taps - 1 - pad, cin=Cout,
+                             w_strides=(1, -Cin, taps * Cin), a_rowscale=rowmask).view(B, T, Cin)
+        if _want(w):
+            K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad,
+                         arow=rowmask)
+        return (dx,) + (None,) * 7
+
+
+def conv_linear(x, w, b, cout, taps=1, pad=0, act=None, rowmask=None):
+    return ConvLinearFn.apply(x, w, b, cout, taps, pad, act, rowmask)
+
+
+class PredictorLayerFn(torch.autograd.Function):
+    """One VariancePredictor layer: Conv1d(k) -> ReLU -> LayerNorm(C, eps 1e-12) -> Dropout (core.py:62-76)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lnw, lnb, taps, drop_p, seed, stream_id):
+        B, T, Cin = x.shape
+        Cout = w.shape[0]
+        pad = (taps - 1) // 2
+        x = x.contiguous()
+        r = K.conv_gemm(x.view(B * T, Cin), w, Cout, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_RELU)
+        save = any(ctx.needs_input_grad)
+        y, mean, rstd = K.layernorm_fwd(r, lnw, lnb, 1e-12, save=save, drop_p=drop_p, seed=seed, stream_id=stream_id)
+        if save:
+            ctx.save_for_backward(x, r, mean, rstd)
+            ctx.params = (w, b, lnw, lnb)
+            ctx.cfg = (taps, pad, drop_p, seed, stream_id)
+        return y.view(B, T, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r, mean, rstd = ctx.saved_tensors
+        w, b, lnw, lnb = ctx.params
+        taps, pad, drop_p, seed, stream_id = ctx.cfg
+        B, T, Cin = x.shape
+        Cout = w.shape[0]
+        wl = _want(lnw)
+        g = K.layernorm_bwd(dy.contiguous().view(B * T, Cout), r, mean, rstd, lnw, gsink(lnw) if wl else None,
+                            gsink(lnb) if wl else None, relu_src=r, drop_p=drop_p, seed=seed, stream_id=stream_id)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            base = w.detach()[:, taps - 1:, :]
+            dx = K.conv_gemm(g, base, Cin, T=T, taps=taps, pad=taps - 1 - pad, cin=Cout,
+                             w_strides=(1, -Cin, taps * Cin)).view(B, T, Cin)
+        if _want(w):
+            K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad)
+        return (dx,) + (None,) * 8
+
+
+class VarianceEmbedFn(torch.autograd.Function):
+    """x_out = (x + dropout(Conv1d(1 -> C, k)(values))) * keep_mask   (core.py:161-165 / :170-175)."""
+
+    @staticmethod
+    def forward(ctx, x, values, w, b, rowmask, drop_p, seed, stream_id):
+        B, T, C = x.shape
+        taps = w.shape[1]
+        pad = (taps - 1) // 2
+        x = x.contiguous()
+        v = values.contiguous().view(B * T, 1)
+        if drop_p > 0.0:
+            emb = K.conv_gemm(v, w, C, T=T, taps=taps, pad=pad, bias=b)
+            dm = dropout_mask((B * T, C), drop_p, seed, stream_id, x.device)
+            y = (x.view(B * T, C) + emb * dm) * rowmask[:, None]
+        else:
+            dm = None
+            y = K.conv_gemm(v, w, C, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_SCALE_RES_MASK, res=x.view(B * T, C),
+                            rowmask=rowmask)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(v, rowmask, dm)
+            ctx.params = (w, b)
+            ctx.cfg = (B, T, C, taps, pad)
+        return y.view(B, T, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, rowmask, dm = ctx.saved_tensors
+        w, b = ctx.params
+        B, T, C, taps, pad = ctx.cfg
+        g = dy.contiguous().view(B * T, C) * rowmask[:, None]
+        dx = g.view(B, T, C) if ctx.needs_input_grad[0] else None
+        ge = g if dm is None else g * dm
+        dval = None
+        if ctx.needs_input_grad[1]:
+            base = w.detach()[:, taps - 1:, :]
+            dval = K.conv_gemm(ge, base, 1, T=T, taps=taps, pad=taps - 1 - pad, cin=C,
+                               w_strides=(1, -1, taps)).view(B, T)
+        if _want(w):
+            K.conv_wgrad(ge, v, gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad)
+        return dx, dval, None, None, None, None, None, None
+
+
+def dropout_mask(shape, p, seed, stream_id, device):
+    """Materialised keep/scale mask from the same Philox stream the fused kernels use (cold paths only)."""
+    ones = torch.ones(shape, device=device, dtype=torch.float32)
+    w = torch.ones(shape[-1], device=device)
+    b = torch.zeros(shape[-1], device=device)
+    # LN of a constant row is 0*w+b; use b=1 trick: y = (0*1 + 1) * dropout
+    y, _, _ = K.layernorm_fwd(ones, w, b + 1.0, 1.0, save=False, drop_p=p, seed=seed, stream_id=stream_id)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ text embedding
+class TextEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, E, scale, pos, drop_p, seed, stream_id):
+        out = K.text_embed_fwd(tok, E, pos, scale, drop_p, seed, stream_id)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(tok, pos)
+            ctx.params = (E, scale)
+            ctx.cfg = (drop_p, seed, stream_id)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, pos = ctx.saved_tensors
+        E, scale = ctx.params
+        drop_p, seed, stream_id = ctx.cfg
+        K.text_embed_bwd(dy, tok, pos, gsink(E) if _want(E) else None, gsink(scale) if _want(scale) else None,
+                         0, drop_p, seed, stream_id)
+        return (None,) * 7
+
+
+# ------------------------------------------------------------------------------------------------ alignment
+class AlignLogProbFn(torch.autograd.Function):
+    """log_p_attn = log_softmax_n(-||f_t - e_n||_2 masked) + prior   (alignments.py:66-81)."""
+
+    @staticmethod
+    def forward(ctx, f, e, prior, x_len, y_len):
+        f, e = f.contiguous(), e.contiguous()
+        score = K.pairwise_score(f, e, x_len)
+        lp, lse = K.logsoftmax_prior_fwd(score, prior)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(f, e, score, lse, x_len, y_len)
+        return lp
+
+    @staticmethod
+    def backward(ctx, dlp):
+        f, e, score, lse, x_len, y_len = ctx.saved_tensors
+        B, T, C = f.shape
+        N = e.shape[1]
+        w, wrow = K.logsoftmax_prior_bwd(dlp, score, lse, x_len, y_len)
+        # df = rowsum(w) * f - w @ e       (batched, NN mode, fused in the epilogue)
+        df = torch.empty_like(f)
+        K.conv_gemm(w, e, C, cin=N, w_strides=(1, 0, C), out=df, epi=K.EPI_AXMY, rowscale=wrow.view(-1), aux_in=f,
+                    batch=B, batch_strides=(T * N, N * C, T * C, T * C))
+        # de = colsum(w) * e - w^T @ f     (batched wgrad form; its bias-gradient output is colsum(w))
+        wtf = torch.zeros((B, N, C), device=f.device, dtype=torch.float32)
+        wcol = torch.zeros((B, N), device=f.device, dtype=torch.float32)
+        K.conv_wgrad(w, f, wtf, wcol, batch=B)
+        de = torch.addcmul(-wtf, wcol.unsqueeze(-1), e)
+        return df, de, None, None, None
+
+
+class AlignLossFn(torch.autograd.Function):
+    """(forwardsum_loss, bin_loss) from log_p_attn: ForwardSumLoss (loss.py:150-194) and the binarisation term of
+    viterbi_decode (alignments.py:236-238); `path`/`bin_item` come from the MAS kernel."""
+
+    @staticmethod
+    def forward(ctx, lp, x_len, y_len, path, bin_item):
+        B = lp.shape[0]
+        need = ctx.needs_input_grad[0]
+        loss_item, grad = K.forwardsum_ctc(lp.contiguous(), x_len, y_len, want_grad=need)
+        if need:
+            ctx.save_for_backward(grad, path, y_len)
+        return loss_item.sum() / B, bin_item.sum() / B
+
+    @staticmethod
+    def backward(ctx, g_fs, g_bin):
+        grad, path, y_len = ctx.saved_tensors
+        dlp = grad * g_fs
+        K.bin_loss_bwd(path, y_len, g_bin.reshape(1).contiguous().float(), dlp)
+        return dlp, None, None, None, None
+
+
+class VarianceLossFn(torch.autograd.Function):
+    """(duration, pitch, energy) losses of FastSpeech2Loss (loss.py:83-140)."""
+
+    @staticmethod
+    def forward(ctx, d_hat, p_hat, e_hat, ds, ps, es, x_len):
+        out, gd, gp, ge = K.variance_losses(d_hat, p_hat, e_hat, ds, ps, es, x_len)
+        ctx.save_for_backward(gd, gp, ge)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        gd, gp, ge = ctx.saved_tensors
+        return gd * g0, gp * g1, ge * g2, None, None, None, None
+
+
+class GaussianUpsampleFn(torch.autograd.Function):
+    """hs' = softmax_n(-delta (t - c_n)^2) @ hs  (alignments.py:136-174); durations carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, hs, ds, x_len, y_len, Tm, delta):
+        B, N, C = hs.shape
+        _, _, centre = K.duration_stats(ds, want_centre=True)
+        P = K.gaussian_weights(centre, x_len, y_len, Tm, delta)
+        hs = hs.contiguous()
+        y = K.conv_gemm(P, hs, C, cin=N, w_strides=(1, 0, C), batch=B, batch_strides=(Tm * N, N * C, Tm * C, 0))
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(P)
+            ctx.shape = (B, N, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (P,) = ctx.saved_tensors
+        B, N, C = ctx.shape
+        dhs = torch.zeros((B, N, C), device=dy.device, dtype=torch.float32)
+        K.conv_wgrad(P, dy.contiguous(), dhs, None, batch=B)
+        return dhs, None, None, None, None, None
