@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: full OptiSpeech ConvNeXt GAN training step on synthetic LJSpeech-shaped batches.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = BaseLightningModule.training_step in the post-pre-training regime: generator forward, adversarial
+losses through MPD/MRD, G backward, clip + AdamW(G), discriminator forward/backward, clip + AdamW(D); train mode
+(dropout / drop-path active), fp32.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
+line; `value` is the whole-job aggregate (mel-frames/s over all ranks, weak scaling: 32 utterances per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, T_TEXT, T_MEL = 32, 128, 800
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="utterances in the bounded CPU-baseline sample")
+    ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of one C-ABI entry point on the launch stream (torch's current stream), filtered by a
+    predicate on the call arguments, so `roofline.achieved` comes from launches inside the timed region."""
+
+    def __init__(self, name, pred):
+        self.name, self.pred, self.events, self.enabled = name, pred, [], False
+
+    def install(self):
+        from optispeech_amd import _lib
+        lib = _lib.lib()
+        orig = lib.call
+        timer = self
+
+        def call(name, *args):
+            if timer.enabled and name == timer.name and timer.pred(args):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(name, *args)
+                e1.record()
+                timer.events.append((e0, e1))
+            else:
+                orig(name, *args)
+        lib.call = call
+
+    def mean_ms(self):
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+def cpu_baseline(nb):
+    """Oracle (CPU port of the reference step) on a bounded sample: `nb` utterances of the same shape, one
+    untimed + one timed full GAN step incl. torch.optim.AdamW updates.  Returns (frames/s, threads, note)."""
+    from oracle import generator as OG
+    from oracle import losses as OL
+    from oracle import schema as S
+    from optispeech_amd.config import ModelConfig, synthetic_batch
+    threads = torch.get_num_threads()
+    P = S.make_weights(S.generator_schema(S.Cfg()), 1)
+    P.update(S.make_weights(S.discriminator_schema(), 2))
+    for v in P.values():
+        v.requires_grad_(True)
+    fb = OL.mel_filterbank(22050, 1024, 100, 80, 8000)
+    gp = [v for k, v in P.items() if k.startswith("generator.")]
+    dp_ = [v for k, v in P.items() if k.startswith("discriminator.")]
+    og = torch.optim.AdamW(gp, lr=2e-4, betas=(0.8, 0.99), weight_decay=1e-2)
+    od = torch.optim.AdamW(dp_, lr=2e-4, betas=(0.8, 0.99), weight_decay=1e-2)
+    batch = synthetic_batch(nb, T_TEXT, T_MEL, ModelConfig(), seed=3)
+    rand01 = torch.rand(nb)
+
+    def step():
+        res = OG.training_step(P, batch, rand01=rand01, fb=fb, train_discriminator=True, with_mel=True)
+        for k, g in res["grads_g"].items():
+            P[k].grad = g
+        torch.nn.utils.clip_grad_norm_([p for p in gp if p.grad is not None], 10.0)
+        og.step()
+        for k, g in res["grads_d"].items():
+            P[k].grad = g
+        torch.nn.utils.clip_grad_norm_(dp_, 10.0)
+        od.step()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    return nb * T_MEL / dt, threads, f"{nb} utterances x (T_text={T_TEXT}, T_mel={T_MEL}), 1 warm + 1 timed GAN step, {dt:.1f}s"
+
+
+def main():
+    a = parse()
+    from optispeech_amd import dp, rng
+    world, rank, local = dp.init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+
+    torch.manual_seed(1234)                                   # configs/train.yaml:53; same init on every rank
+    rng.manual_seed(1234, rank)
+    cfg = ModelConfig()
+    model = make_optispeech(cfg, batch_size=B, pretraining_steps=0).to(dev).train()
+    batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
+    model.optimizers()
+
+    # dominant hand-written kernel: the decoder's pointwise GEMMs (M = B*T_mel frames, 256 <-> 1024 channels)
+    M = B * T_MEL
+    timer = KernelTimer("osp_conv_gemm_f32", lambda args: args[2] == M and args[4] * args[12] == 256 * 1024 and args[5] == 1)
+    timer.install()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        model.training_step(batch, i)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        model.training_step(batch, a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    logs = model.fetch_logs()
+    ms_per_step = dt / a.steps * 1e3
+    value = world * B * T_MEL / (dt / a.steps)
+
+    if rank == 0:
+        kms = timer.mean_ms()
+        flops = 2.0 * M * 256 * 1024                           # algorithmic flops of one launch
+        roof = {"bound": "mfma", "kernel": "conv_gemm_f32 (decoder pwconv1/pwconv2, M=25600, 256<->1024)",
+                "achieved": (flops / (kms * 1e-3) / 1e12) if kms else None, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "traffic": None, "launches_timed": len(timer.events)}
+        roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        cpu = None
+        if not a.no_cpu_baseline:
+            v, threads, note = cpu_baseline(a.cpu_batch)
+            cpu = {"value": v, "unit": "mel-frames/s", "cores": threads, "kind": "port", "sample": note}
+        out = {"metric": "mel-frames/sec/GPU (train step) + RTF (synthesize), ConvNeXt@22.05kHz, 1/2/4/8 MI355X",
+               "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: ConvNeXt backbone, synthetic LJSpeech-shaped batch=32 per GPU "
+                                      "(T_text=128, T_mel=800, 22.05 kHz), full GAN training step "
+                                      "(G phase + D phase + 2x AdamW), train mode",
+                          "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}",
+                          "lengths": "ragged" if a.ragged else "fixed"},
+               "per_gpu": value / world, "roofline": roof, "cpu_baseline": cpu,
+               "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")}}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

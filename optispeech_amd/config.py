@@ -89,3 +89,65 @@ def make_generator(c: ModelConfig):
         vocoder=partial(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers,
                         drop_path=c.voc_drop_path),
         loss_coeffs=loss_coeffs, feature_extractor=c.fe, num_speakers=1, num_languages=1, data_statistics=None)
+
+
+def make_optispeech(c: ModelConfig = None, batch_size=32, pretraining_steps=1000, optimizer=None, scheduler=None):
+    """Instantiate the full ``OptiSpeech`` module (generator + VocosDiscriminator) the way configs/model/optispeech.yaml
+    composes it."""
+    from .model.discriminator import VocosDiscriminator
+    from .model.generator import OptiSpeechGenerator
+    from .model.modules import (ConvNeXtBackbone, DurationPredictor, EnergyPredictor, PitchPredictor, TextEmbedding)
+    from .model.optispeech import OptiSpeech, default_args
+    from .model.vocoder import WaveNeXt
+    c = c or ModelConfig()
+
+    def pred(cls, spec, **kw):
+        return partial(cls, num_layers=spec[0], intermediate_dim=spec[1], kernel_size=spec[2], dropout=spec[3],
+                       conv_layer_class=torch.nn.Conv1d, **kw)
+
+    gen = partial(
+        OptiSpeechGenerator, segment_size=c.segment_size,
+        text_embedding=partial(TextEmbedding, n_vocab=c.n_vocab, dropout=c.text_dropout, padding_idx=0,
+                               max_source_positions=c.max_source_positions),
+        encoder=partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers,
+                        drop_path=c.enc_drop_path),
+        duration_predictor=pred(DurationPredictor, c.dur),
+        pitch_predictor=pred(PitchPredictor, c.pitch, embed_kernel_size=c.embed_kernel,
+                             embed_dropout=c.pitch_embed_dropout),
+        energy_predictor=pred(EnergyPredictor, c.energy, embed_kernel_size=c.embed_kernel,
+                              embed_dropout=c.energy_embed_dropout),
+        decoder=partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers,
+                        drop_path=c.dec_drop_path),
+        loss_coeffs=SimpleNamespace(lambda_align=c.lambda_align, lambda_duration=c.lambda_duration,
+                                    lambda_pitch=c.lambda_pitch, lambda_energy=c.lambda_energy))
+    voc = partial(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers,
+                  drop_path=c.voc_drop_path)
+    disc = partial(VocosDiscriminator, loss_coeffs=SimpleNamespace(lambda_mrd=c.lambda_mrd, lambda_mel=c.lambda_mel,
+                                                                   lambda_mr_stft=c.lambda_mr_stft))
+    train_args, data_args, inference_args = default_args(batch_size, c.fe)
+    train_args.pretraining_steps = pretraining_steps
+    return OptiSpeech(dim=c.dim, generator=gen, vocoder=voc, discriminator=disc, train_args=train_args,
+                      data_args=data_args, inference_args=inference_args, optimizer=optimizer, scheduler=scheduler)
+
+
+def synthetic_batch(B=32, T_text=128, T_mel=800, c: ModelConfig = None, seed=1234, ragged=False, device="cpu"):
+    """BASELINE.md section 3 synthetic LJSpeech-shaped batch (batch dict schema of TextWavBatchCollate)."""
+    c = c or ModelConfig()
+    g = torch.Generator().manual_seed(seed)
+    if ragged:
+        x_len = torch.randint(int(T_text * 0.75), T_text + 1, (B,), generator=g)
+        m_len = torch.randint(int(T_mel * 0.75), T_mel + 1, (B,), generator=g)
+        x_len[0], m_len[0] = T_text, T_mel
+    else:
+        x_len = torch.full((B,), T_text, dtype=torch.int64)
+        m_len = torch.full((B,), T_mel, dtype=torch.int64)
+    x = torch.randint(1, 159, (B, T_text), generator=g)
+    x = x * (torch.arange(T_text)[None] < x_len[:, None])
+    mvalid = (torch.arange(T_mel)[None] < m_len[:, None])
+    mel = torch.randn(B, c.fe.n_feats, T_mel, generator=g) * mvalid[:, None, :]
+    pit = torch.randn(B, T_mel, generator=g) * mvalid
+    ene = torch.randn(B, T_mel, generator=g) * mvalid
+    wav = (torch.rand(B, T_mel * c.fe.hop_length, generator=g) * 2 - 1).clamp_(-1, 1)
+    batch = dict(x=x, x_lengths=x_len, mel=mel, mel_lengths=m_len, pitches=pit, energies=ene, wav=wav, sids=None,
+                 lids=None, wav_lengths=m_len * c.fe.hop_length, x_texts=[""] * B, filepaths=[""] * B)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}

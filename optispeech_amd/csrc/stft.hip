@@ -1,0 +1,183 @@
+// STFT magnitude forward / backward with the FFT in LDS (reference rows A15, A15b):
+//   disc/loss.py:123-142   stft(): |torch.stft(center=True, reflect, hann zero-padded to n_fft)| with clamp 1e-7
+//   _discriminators.py:196-216  DiscriminatorR.spectrogram: rectangular window, plain abs
+//   disc/loss.py:94-118    torchaudio MelSpectrogram's inner spectrogram (power=1)
+//
+// One workgroup of N/4 threads per frame.  The frame is formed directly from the waveform (reflect padding and
+// the window are applied on load -- the padded / framed signal is never materialised in HBM), transformed by a
+// Stockham autosort FFT (radix-4 stages, one radix-2 stage when log2 N is odd) ping-ponging between two LDS
+// buffers, and only the N/2+1 magnitudes are stored.  Algorithmic HBM bytes per frame: hop*4 read (each sample is
+// used by n_fft/hop frames but fetched from L2 after the first touch) + (N/2+1)*4 written.
+// Backward recomputes the spectrum (cheaper than saving 2x the magnitudes), forms G = dmag * X/|X| on the half
+// spectrum, evaluates Re(sum_k G_k e^{+i 2 pi k n / N}) as Re(FFT(conj G)) with the same routine, applies the window
+// and overlap-adds into dx with the reflect index map (f32 atomics).
+#include "osp_common.h"
+
+__global__ void fft_twiddles_kernel(float2* tw, int N) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < N) {
+        double s, c;
+        sincos(-2.0 * 3.14159265358979323846 * (double)m / (double)N, &s, &c);
+        tw[m] = make_float2((float)c, (float)s);
+    }
+}
+// tw[m] = exp(-2 pi i m / N), m in [0, N)
+extern "C" int osp_fft_twiddles(float* tw, int64_t N, hipStream_t stream) {
+    OSP_CHECK_ARG(tw && N >= 8 && (N & (N - 1)) == 0, "N must be a power of two >= 8");
+    hipLaunchKernelGGL(fft_twiddles_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, stream, (float2*)tw, (int)N);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// In-LDS Stockham FFT of N complex points held in buf0 (natural order); returns the buffer holding the
+// result (natural order).  blockDim.x == N/4.  Forward transform (e^{-i...}).
+__device__ __forceinline__ float2* lds_fft(float2* buf0, float2* buf1, const float2* __restrict__ tw, int N) {
+    const int j = threadIdx.x, Q = N >> 2;
+    float2 *in = buf0, *out = buf1;
+    int Ns = 1;
+    for (; Ns * 4 <= N; Ns *= 4) {
+        __syncthreads();
+        const int k = j & (Ns - 1);
+        const int tstep = N / (Ns * 4);                       // twiddle index of angle -2 pi k / (4 Ns)
+        float2 v0 = in[j], v1 = in[j + Q], v2 = in[j + 2 * Q], v3 = in[j + 3 * Q];
+        if (Ns > 1) {
+            v1 = cmul(v1, tw[k * tstep]);
+            v2 = cmul(v2, tw[2 * k * tstep]);
+            v3 = cmul(v3, tw[3 * k * tstep]);
+        }
+        const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), d = csub(v1, v3);
+        const float2 a3 = make_float2(d.y, -d.x);              // -i * (v1 - v3)
+        const int base = ((j - k) << 2) + k;                   // (j / Ns) * 4 Ns + k
+        out[base] = cadd(a0, a2);
+        out[base + Ns] = cadd(a1, a3);
+        out[base + 2 * Ns] = csub(a0, a2);
+        out[base + 3 * Ns] = csub(a1, a3);
+        float2* t = in; in = out; out = t;
+    }
+    if (Ns < N) {                                              // one radix-2 stage: N/2 butterflies, 2 per thread
+        __syncthreads();
+        const int H = N >> 1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int jj = j + r * Q, k = jj & (Ns - 1);
+            const float2 a = in[jj], b = cmul(in[jj + H], tw[k * (N / (Ns * 2))]);
+            const int base = ((jj - k) << 1) + k;
+            out[base] = cadd(a, b);
+            out[base + Ns] = csub(a, b);
+        }
+        float2* t = in; in = out; out = t;
+    }
+    __syncthreads();
+    return in;
+}
+
+__device__ __forceinline__ int reflect_index(int p, int T) {   // index into x of padded position p - N/2 (reflect, no edge repeat)
+    if (p < 0) p = -p;
+    if (p >= T) p = 2 * (T - 1) - p;
+    return p;
+}
+
+__global__ void stft_mag_fwd_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                    const float2* __restrict__ tw, float clamp_min, float* __restrict__ mag, int T,
+                                    int N, int hop, int frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2 *b0 = lds, *b1 = lds + N;
+    const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x, Q = N >> 2;
+    const float* xb = x + (int64_t)b * T;
+    const int start = f * hop - (N >> 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = j + r * Q;
+        float v = xb[reflect_index(start + n, T)];
+        if (window) v *= window[n];
+        b0[n] = make_float2(v, 0.f);
+    }
+    const float2* X = lds_fft(b0, b1, tw, N);
+    const int bins = (N >> 1) + 1;
+    float* out = mag + ((int64_t)b * frames + f) * bins;
+    for (int k = j; k < bins; k += Q) {
+        const float2 c = X[k];
+        const float p = c.x * c.x + c.y * c.y;
+        out[k] = sqrtf(clamp_min >= 0.f ? fmaxf(p, clamp_min) : p);
+    }
+}
+
+__global__ void stft_mag_bwd_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                    const float2* __restrict__ tw, float clamp_min, const float* __restrict__ dmag,
+                                    float* __restrict__ dx, int T, int N, int hop, int frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2 *b0 = lds, *b1 = lds + N;
+    const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x, Q = N >> 2;
+    const float* xb = x + (int64_t)b * T;
+    const int start = f * hop - (N >> 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = j + r * Q;
+        float v = xb[reflect_index(start + n, T)];
+        if (window) v *= window[n];
+        b0[n] = make_float2(v, 0.f);
+    }
+    float2* X = lds_fft(b0, b1, tw, N);
+    float2* other = (X == b0) ? b1 : b0;
+    const int bins = (N >> 1) + 1;
+    const float* g = dmag + ((int64_t)b * frames + f) * bins;
+    // conj(G) on the half spectrum, zero above Nyquist
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = j + r * Q;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < bins) {
+            const float2 c = X[k];
+            const float p = c.x * c.x + c.y * c.y;
+            const bool live = clamp_min >= 0.f ? (p >= clamp_min) : (p > 0.f);
+            if (live) {
+                const float s = g[k] * rsqrtf(p);
+                v = make_float2(s * c.x, -s * c.y);
+            }
+        }
+        other[k] = v;
+    }
+    const float2* Y = lds_fft(other, X, tw, N);
+    float* dxb = dx + (int64_t)b * T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = j + r * Q;
+        float v = Y[n].x;
+        if (window) v *= window[n];
+        if (v != 0.f) atomicAdd(dxb + reflect_index(start + n, T), v);
+    }
+}
+
+static int stft_check(const void* x, const void* tw, int64_t B, int64_t T, int64_t N, int64_t hop) {
+    if (!x || !tw || B <= 0 || hop <= 0) return 0;
+    if (N < 16 || N > 4096 || (N & (N - 1))) return 0;
+    if (T <= N / 2) return 0;                                  // reflect padding needs T > n_fft/2 (as torch.stft)
+    return 1;
+}
+
+// mag: (B, frames, N/2+1), frames = 1 + T / hop (center=True).  window: N floats (already centred / zero padded)
+// or null for the rectangular window; clamp_min < 0 selects plain |X|.
+extern "C" int osp_stft_mag_fwd(const float* x, const float* window, const float* tw, float clamp_min, float* mag,
+                                int64_t B, int64_t T, int64_t N, int64_t hop, hipStream_t stream) {
+    OSP_CHECK_ARG(stft_check(x, tw, B, T, N, hop) && mag, "bad STFT arguments");
+    const int frames = (int)(1 + T / hop);
+    hipLaunchKernelGGL(stft_mag_fwd_kernel, dim3((unsigned)frames, (unsigned)B), dim3((unsigned)(N / 4)), (size_t)N * 16, stream,
+                       x, window, (const float2*)tw, clamp_min, mag, (int)T, (int)N, (int)hop, frames);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// dx (B,T) must be zero-initialised by the caller (or hold a gradient to accumulate into).
+extern "C" int osp_stft_mag_bwd(const float* x, const float* window, const float* tw, float clamp_min, const float* dmag,
+                                float* dx, int64_t B, int64_t T, int64_t N, int64_t hop, hipStream_t stream) {
+    OSP_CHECK_ARG(stft_check(x, tw, B, T, N, hop) && dmag && dx, "bad STFT arguments");
+    const int frames = (int)(1 + T / hop);
+    hipLaunchKernelGGL(stft_mag_bwd_kernel, dim3((unsigned)frames, (unsigned)B), dim3((unsigned)(N / 4)), (size_t)N * 16, stream,
+                       x, window, (const float2*)tw, clamp_min, dmag, dx, (int)T, (int)N, (int)hop, frames);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

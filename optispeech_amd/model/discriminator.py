@@ -1,0 +1,198 @@
+"""Host-side mirror of optispeech/model/vocoder/wavenext/disc/{__init__,_discriminators,loss}.py.
+
+VocosDiscriminator = MPD (5 periods) + MRD (3 resolutions) + hinge / feature-matching / mel / MR-STFT losses.
+Status (DESIGN.md, section "what runs where"): the STFT magnitudes and the spectral losses are HIP kernels
+(optispeech_amd/csrc/stft.hip); the Conv2d stacks of MPD/MRD are v1 = PyTorch-ROCm conv2d (MIOpen), listed as
+SURVEY.md section 8f row 1 ("next": hand-written implicit-GEMM).  Parameter names follow the reference's weight_norm
+schema (`weight_g` / `weight_v`).
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import spectral
+
+
+class BaseVocoderDiscriminator(nn.Module):
+    """optispeech/model/discriminator/__init__.py:11-23."""
+
+    def forward_disc(self, wav, wav_hat):
+        raise NotImplementedError
+
+    def forward_gen(self, wav, wav_hat):
+        raise NotImplementedError
+
+    def forward_val(self, wav, wav_hat):
+        raise NotImplementedError
+
+
+class _WNConv2d(nn.Module):
+    """weight_norm(Conv2d): w = g * v / ||v||  (norm over all dims but 0), keys bias / weight_g / weight_v."""
+
+    def __init__(self, cin, cout, kernel, stride=(1, 1), padding=(0, 0)):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, kernel, stride, padding=padding)
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(conv.bias.detach().clone())
+        v = conv.weight.detach().clone()
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+        self.weight_v = nn.Parameter(v)
+
+    def forward(self, x):
+        v = self.weight_v
+        w = v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+        return F.conv2d(x, w, self.bias, self.stride, self.padding)
+
+
+class DiscriminatorP(nn.Module):
+    """_discriminators.py:41-97."""
+
+    def __init__(self, period: int, kernel_size: int = 5, stride: int = 3, lrelu_slope: float = 0.1):
+        super().__init__()
+        self.period, self.lrelu_slope = period, lrelu_slope
+        p = (kernel_size // 2, 0)
+        ch = [1, 32, 128, 512, 1024]
+        self.convs = nn.ModuleList([_WNConv2d(ch[i], ch[i + 1], (kernel_size, 1), (stride, 1), p) for i in range(4)]
+                                   + [_WNConv2d(1024, 1024, (kernel_size, 1), (1, 1), p)])
+        self.conv_post = _WNConv2d(1024, 1, (3, 1), (1, 1), (1, 0))
+
+    def forward(self, x):
+        x = x.unsqueeze(1)
+        b, c, t = x.shape
+        if t % self.period != 0:
+            n_pad = self.period - (t % self.period)
+            x = F.pad(x, (0, n_pad), "reflect")
+            t = t + n_pad
+        x = x.view(b, c, t // self.period, self.period)
+        fmap = []
+        for i, conv in enumerate(self.convs):
+            x = F.leaky_relu(conv(x), self.lrelu_slope)
+            if i > 0:
+                fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class DiscriminatorR(nn.Module):
+    """_discriminators.py:139-216; the rectangular-window magnitude spectrogram comes from the HIP STFT."""
+
+    def __init__(self, resolution, channels: int = 64, lrelu_slope: float = 0.1):
+        super().__init__()
+        self.resolution, self.lrelu_slope = resolution, lrelu_slope
+        spec = [((7, 5), (2, 2), (3, 2)), ((5, 3), (2, 1), (2, 1)), ((5, 3), (2, 2), (2, 1)), ((3, 3), (2, 1), (1, 1)),
+                ((3, 3), (2, 2), (1, 1))]
+        self.convs = nn.ModuleList([_WNConv2d(1 if i == 0 else channels, channels, k, s, p)
+                                    for i, (k, s, p) in enumerate(spec)])
+        self.conv_post = _WNConv2d(channels, 1, (3, 3), (1, 1), (1, 1))
+
+    def spectrogram(self, x):
+        n_fft, hop, win = self.resolution
+        return spectral.stft_magnitude(x, n_fft, hop, None, None).transpose(1, 2)      # (B, freq, frames)
+
+    def forward(self, x):
+        fmap = []
+        x = self.spectrogram(x).unsqueeze(1)
+        for conv in self.convs:
+            x = F.leaky_relu(conv(x), self.lrelu_slope)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class _Multi(nn.Module):
+    def forward(self, y, y_hat):
+        rs, gs, frs, fgs = [], [], [], []
+        B = y.shape[0]
+        both = torch.cat([y, y_hat], 0)                      # real and generated share every launch
+        for d in self.discriminators:
+            o, fm = d(both)
+            rs.append(o[:B]); gs.append(o[B:])
+            frs.append([f[:B] for f in fm]); fgs.append([f[B:] for f in fm])
+        return rs, gs, frs, fgs
+
+
+class MultiPeriodDiscriminator(_Multi):
+    """_discriminators.py:10-38."""
+
+    def __init__(self, periods=(2, 3, 5, 7, 11)):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorP(period=p) for p in periods])
+
+
+class MultiResolutionDiscriminator(_Multi):
+    """_discriminators.py:100-136."""
+
+    def __init__(self, resolutions=((1024, 256, 1024), (2048, 512, 2048), (512, 128, 512))):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorR(resolution=r) for r in resolutions])
+
+
+def _hinge_g(outs):                                            # GeneratorLoss, disc/loss.py:16-32
+    return sum(torch.mean(torch.clamp(1 - o, min=0)) for o in outs) / len(outs)
+
+
+def _hinge_d(real, fake):                                      # DiscriminatorLoss, disc/loss.py:40-65
+    return sum(torch.mean(torch.clamp(1 - r, min=0)) + torch.mean(torch.clamp(1 + g, min=0))
+               for r, g in zip(real, fake)) / len(real)
+
+
+def _feature_matching(fr, fg):                                 # FeatureMatchingLoss, disc/loss.py:71-85
+    tot = 0
+    for dr, dg in zip(fr, fg):
+        for a, b in zip(dr, dg):
+            tot = tot + torch.mean(torch.abs(a - b))
+    return tot / len(fr)
+
+
+class VocosDiscriminator(BaseVocoderDiscriminator):
+    """disc/__init__.py:16-111.  Losses are returned as device scalars; log dicts hold device tensors (the
+    reference calls .item() on each of them = one device sync apiece, base_lightning_module.py:132-148)."""
+
+    def __init__(self, feature_extractor, loss_coeffs=None):
+        super().__init__()
+        self.feature_extractor = feature_extractor
+        self.loss_coeffs = loss_coeffs or SimpleNamespace(lambda_mrd=1.0, lambda_mel=45.0, lambda_mr_stft=2.5)
+        self.lambda_mel = self.loss_coeffs.lambda_mel
+        self.lambda_mr_stft = self.loss_coeffs.lambda_mr_stft
+        self.multiperioddisc = MultiPeriodDiscriminator()
+        self.multiresddisc = MultiResolutionDiscriminator()
+        fe = feature_extractor
+        self.melspec_loss = spectral.MelSpecReconstructionLoss(fe.sample_rate, fe.n_fft, fe.hop_length, fe.win_length,
+                                                               fe.n_feats, fe.f_min, fe.f_max)
+        self.mr_stft_loss = spectral.MultiResolutionSTFTLoss()
+
+    def forward_disc(self, wav, wav_hat):
+        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat)
+        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat)
+        loss_mp, loss_mrd = _hinge_d(r_mp, g_mp), _hinge_d(r_mr, g_mr)
+        loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd
+        return loss, dict(loss_mp=loss_mp.detach(), loss_mrd=loss_mrd.detach())
+
+    def forward_gen(self, wav, wav_hat):
+        _, g_mp, fr_mp, fg_mp = self.multiperioddisc(y=wav, y_hat=wav_hat)
+        _, g_mr, fr_mr, fg_mr = self.multiresddisc(y=wav, y_hat=wav_hat)
+        loss_gen_mp, loss_gen_mrd = _hinge_g(g_mp), _hinge_g(g_mr)
+        loss_fm_mp, loss_fm_mrd = _feature_matching(fr_mp, fg_mp), _feature_matching(fr_mr, fg_mr)
+        mel_loss = self._get_mel_loss(wav, wav_hat)
+        mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
+        lam = self.loss_coeffs.lambda_mrd
+        loss = loss_gen_mp + loss_gen_mrd * lam + loss_fm_mp + loss_fm_mrd * lam + mel_loss + mr_stft_loss
+        logs = dict(loss_gen_mp=loss_gen_mp, loss_gen_mrd=loss_gen_mrd, loss_fm_mp=loss_fm_mp, loss_fm_mrd=loss_fm_mrd,
+                    mel_loss=mel_loss, mr_stft_loss=mr_stft_loss)
+        return loss, {k: v.detach() for k, v in logs.items()}
+
+    def forward_val(self, wav, wav_hat):
+        mel_loss = self._get_mel_loss(wav, wav_hat)
+        mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
+        return mel_loss + mr_stft_loss, dict(mel_loss=mel_loss.detach(), mr_stft_loss=mr_stft_loss.detach())
+
+    def _get_mel_loss(self, wav, wav_hat):
+        return self.melspec_loss(wav_hat, wav) * self.lambda_mel
+
+    def _get_mr_stft_loss(self, wav, wav_hat):
+        sc, mag = self.mr_stft_loss(wav_hat, wav)
+        return (sc + mag) * self.lambda_mr_stft

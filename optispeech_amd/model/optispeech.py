@@ -1,0 +1,309 @@
+"""Host-side mirror of optispeech/model/optispeech.py + base_lightning_module.py: the ``OptiSpeech`` module with
+``training_step`` (manual two-optimiser GAN step), ``configure_optimizers``, ``synthesise``/``synthesize``,
+``prepare_input`` and ``load_from_checkpoint`` -- no Lightning / Hydra dependency on the GPU box.
+
+Trainer integration: Lightning calls ``training_step(batch, batch_idx)`` with manual optimisation; here the
+module owns its optimisers (``configure_optimizers()`` is called lazily), the step counter Lightning would keep
+(``global_step`` = number of optimiser steps taken, both optimisers counted -- which is what
+``self.global_step >= pretraining_steps`` compares against upstream) and the data-parallel gradient reducer.
+"""
+import io
+import pickle
+from functools import partial
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .. import rng
+from ..dp import GradReducer
+from ..optim import CosineWarmupSchedule, FusedAdamW
+from ..values import InferenceInputs, InferenceOutputs
+
+
+class IdsTextProcessor:
+    """Minimal stand-in for optispeech.text.TextProcessor (espeak/piper_phonemize are host string processing and out
+    of scope): accepts pre-tokenised phoneme ids."""
+    languages = ["en-us"]
+    is_multi_language = False
+    num_languages = 1
+
+    def __call__(self, text, lang=None, split_sentences=True):
+        if isinstance(text, str):
+            sents = [[int(t) for t in s.split()] for s in text.split("|") if s.strip()]
+        else:
+            sents = [list(s) for s in (text if text and isinstance(text[0], (list, tuple, np.ndarray)) else [text])]
+        if split_sentences:
+            return sents, [" ".join(map(str, s)) for s in sents]
+        flat = [t for s in sents for t in s]
+        return flat, " ".join(map(str, flat))
+
+
+def default_args(batch_size=32, feature_extractor=None):
+    from ..config import FeatureExtractorArgs
+    train_args = SimpleNamespace(cache_generator_outputs=True, gradient_clip_val=10, gradient_accumulate_batches=None,
+                                 pretraining_steps=1000, evaluate_periodicity=False, evaluate_utmos=False,
+                                 evaluate_pesq=False)
+    data_args = SimpleNamespace(name="synthetic", num_speakers=1, text_processor=IdsTextProcessor(),
+                                feature_extractor=feature_extractor or FeatureExtractorArgs(), batch_size=batch_size,
+                                data_statistics=None)
+    inference_args = SimpleNamespace(d_factor=1.1, p_factor=1.6, e_factor=1.2)
+    return train_args, data_args, inference_args
+
+
+class OptiSpeech(nn.Module):
+    def __init__(self, dim, generator, vocoder, discriminator, train_args, data_args, inference_args, optimizer=None,
+                 scheduler=None):
+        super().__init__()
+        if (train_args.gradient_accumulate_batches is not None) and (train_args.gradient_accumulate_batches <= 0):
+            raise ValueError("gradient_accumulate_batches should be a positive number")          # optispeech.py:29-30
+        if data_args.num_speakers < 1:
+            raise ValueError("num_speakers should be a positive integer >= 1")                  # optispeech.py:32-33
+        self.train_args, self.data_args, self.inference_args = train_args, data_args, inference_args
+        self.text_processor = data_args.text_processor
+        self.num_speakers = data_args.num_speakers
+        self.sample_rate = data_args.feature_extractor.sample_rate
+        self.hop_length = data_args.feature_extractor.hop_length
+        self.automatic_optimization = False
+        self.hparams = SimpleNamespace(optimizer=optimizer, scheduler=scheduler)
+        self.generator = generator(dim=dim, vocoder=vocoder, feature_extractor=data_args.feature_extractor,
+                                   data_statistics=data_args.data_statistics, num_speakers=data_args.num_speakers,
+                                   num_languages=self.text_processor.num_languages)
+        self.discriminator = discriminator(feature_extractor=data_args.feature_extractor)
+        self.global_step = 0
+        self.max_steps = 2_000_000
+        self._opts = None
+        self._reducers = None
+        self.last_logs = {}
+
+    # ------------------------------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def configure_optimizers(self):
+        """base_lightning_module.py:47-71: two optimisers from the same partial, cosine-with-warm-up per step."""
+        opt_f = self.hparams.optimizer or partial(FusedAdamW, lr=2e-4, betas=(0.8, 0.99), weight_decay=1e-2)
+        opt_gen = opt_f([{"params": list(self.generator.parameters())}])
+        opt_disc = opt_f([{"params": list(self.discriminator.parameters())}])
+        max_steps = self.max_steps // 2
+        sch_f = self.hparams.scheduler or partial(CosineWarmupSchedule, num_warmup_steps=1000)
+        if isinstance(sch_f, partial) and "num_training_steps" in sch_f.keywords:
+            sch_f.keywords["num_training_steps"] = max_steps
+            sg, sd = sch_f(opt_gen, last_epoch=-1), sch_f(opt_disc, last_epoch=-1)
+        else:
+            sg = sch_f(opt_gen, num_training_steps=max_steps, last_epoch=-1)
+            sd = sch_f(opt_disc, num_training_steps=max_steps, last_epoch=-1)
+        return ([opt_gen, opt_disc], [{"scheduler": sg, "interval": "step"}, {"scheduler": sd, "interval": "step"}])
+
+    def optimizers(self):
+        if self._opts is None:
+            opts, scheds = self.configure_optimizers()
+            self._opts = (opts, [s["scheduler"] for s in scheds])
+            self._reducers = (GradReducer(), GradReducer())
+        return self._opts[0]
+
+    def lr_schedulers(self):
+        self.optimizers()
+        return self._opts[1]
+
+    # ------------------------------------------------------------------------------------------ training
+    def _process_batch(self, batch):
+        """base_lightning_module.py:24-45; the ground-truth segment gather happens on the device."""
+        dev = self.device
+        t = lambda v: v.to(dev, non_blocking=True) if v is not None else None      # noqa: E731
+        gen_outputs = self.generator(x=t(batch["x"]), x_lengths=t(batch["x_lengths"]), mel=t(batch["mel"]),
+                                     mel_lengths=t(batch["mel_lengths"]), pitches=t(batch["pitches"]),
+                                     energies=t(batch["energies"]), sids=t(batch.get("sids")), lids=t(batch.get("lids")))
+        wav = batch["wav"]
+        if isinstance(wav, np.ndarray):
+            wav = torch.from_numpy(wav)
+        wav = wav.to(dev, dtype=torch.float32, non_blocking=True)
+        B, Tw = wav.shape
+        hop, seg = self.hop_length, gen_outputs["segment_size"]
+        if Tw % hop:
+            wav = torch.nn.functional.pad(wav, (0, hop - Tw % hop))
+        rows = wav.contiguous().view(B, -1, hop)
+        gen_outputs["wav"] = K.gather_rows(rows, gen_outputs["start_idx"], seg).view(B, seg * hop)
+        return gen_outputs
+
+    def training_step(self, batch, batch_idx=0, **kwargs):
+        """base_lightning_module.py:78-126."""
+        ta = self.train_args
+        accum = ta.gradient_accumulate_batches
+        scale = float(accum) if accum is not None else 1.0
+        apply = ((batch_idx + 1) % accum == 0) if accum is not None else True
+        train_discriminator = self.global_step >= ta.pretraining_steps
+        opt_g, opt_d = self.optimizers()
+        sched_g, sched_d = self.lr_schedulers()
+        red_g, red_d = self._reducers
+        rng.advance()
+        logs = {}
+        # ---- generator phase (discriminator weights frozen = toggle_optimizer)
+        for p in self.discriminator.parameters():
+            p.requires_grad_(False)
+        loss_g, (wav, wav_hat) = self.training_step_g(batch, train_discriminator, logs)
+        if apply:
+            opt_g.zero_grad()
+        (loss_g / scale).backward()
+        red_g.start(opt_g.arena.grad)
+        for p in self.discriminator.parameters():
+            p.requires_grad_(True)
+        # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce)
+        if train_discriminator:
+            loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs)
+            if apply:
+                opt_d.zero_grad()
+            (loss_d / scale).backward()
+            red_d.start(opt_d.arena.grad)
+        red_g.wait()
+        if apply:
+            opt_g.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_g.world)
+            sched_g.step()
+            self.global_step += 1
+        if train_discriminator:
+            red_d.wait()
+            if apply:
+                opt_d.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_d.world)
+                sched_d.step()
+                self.global_step += 1
+        self.last_logs = logs
+
+    def training_step_g(self, batch, train_discriminator, logs):
+        """base_lightning_module.py:128-161 (log values stay on the device; see fetch_logs)."""
+        gen_outputs = self._process_batch(batch)
+        gen_am_loss = gen_outputs["loss"]
+        logs.update({"total_loss/train_am_loss": gen_am_loss.detach(),
+                     "gen_subloss/train_alighn_loss": gen_outputs["align_loss"],
+                     "gen_subloss/train_duration_loss": gen_outputs["duration_loss"],
+                     "gen_subloss/train_pitch_loss": gen_outputs["pitch_loss"],
+                     "gen_subloss/train_energy_loss": gen_outputs["energy_loss"]})
+        wav, wav_hat = gen_outputs["wav"], gen_outputs["wav_hat"]
+        if train_discriminator:
+            gen_adv_loss, log_dict = self.discriminator.forward_gen(wav, wav_hat)
+            logs["total_loss/train_gen_adv_loss"] = gen_adv_loss.detach()
+            logs.update({f"gen_adv_loss/train_{k}": v for k, v in log_dict.items()})
+            loss = gen_am_loss + gen_adv_loss
+        else:
+            loss = gen_am_loss
+        logs["total_loss/generator"] = loss.detach()
+        self._last_gen_outputs = gen_outputs
+        return loss, (wav.detach(), wav_hat)
+
+    def training_step_d(self, batch, wav_outputs, logs):
+        """base_lightning_module.py:163-186; D sees wav_hat.detach()."""
+        wav, wav_hat = wav_outputs
+        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat)
+        logs["total_loss/discriminator"] = loss.detach()
+        logs.update({f"discriminator/{k}": v for k, v in log_dict.items()})
+        return loss
+
+    def fetch_logs(self):
+        """All logged scalars with ONE device->host copy (and one packed all-reduce under data parallelism)."""
+        if not self.last_logs:
+            return {}
+        keys = list(self.last_logs)
+        packed = torch.stack([self.last_logs[k].float().reshape(()) for k in keys])
+        if self._reducers is not None:
+            self._reducers[0].mean_scalars(packed)
+        vals = packed.cpu().tolist()
+        return dict(zip(keys, vals))
+
+    # ------------------------------------------------------------------------------------------ inference
+    @torch.inference_mode()
+    def synthesise(self, inputs: InferenceInputs, durations_override=None) -> InferenceOutputs:
+        """optispeech.py:58-81."""
+        inputs = inputs.as_torch().to(self.device)
+        out = self.generator.synthesise(x=inputs.x, x_lengths=inputs.x_lengths.to("cpu"), sids=inputs.sids,
+                                        lids=inputs.lids, d_factor=inputs.d_factor, p_factor=inputs.p_factor,
+                                        e_factor=inputs.e_factor, durations_override=durations_override)
+        return InferenceOutputs(wav=out["wav"], wav_lengths=out["wav_lengths"], durations=out["durations"],
+                                pitch=out["pitch"], energy=out["energy"], latency=out["latency"], rtf=out["rtf"],
+                                am_rtf=out["am_rtf"], v_rtf=out["v_rtf"])
+
+    synthesize = synthesise            # README spelling (README.md:90)
+
+    def prepare_input(self, text, *, language=None, speaker=None, d_factor=None, p_factor=None, e_factor=None,
+                      split_sentences=True) -> InferenceInputs:
+        """optispeech.py:83-154."""
+        languages = self.text_processor.languages
+        if language is None:
+            language = languages[0]
+        if self.num_speakers > 1:
+            if speaker is None:
+                sid = 0
+            elif type(speaker) is str:
+                try:
+                    sid = self.speakers.index(speaker)
+                except (IndexError, ValueError, AttributeError):
+                    raise ValueError(f"A speaker with the given name `{speaker}` was not found in speaker list")
+            else:
+                sid = int(speaker)
+        else:
+            sid = None
+        if self.text_processor.is_multi_language:
+            try:
+                lid = languages.index(language)
+            except (IndexError, ValueError):
+                raise ValueError(f"A language with the given name `{language}` was not found in language list")
+        else:
+            lid = None
+        input_ids, clean_text = self.text_processor(text, lang=language, split_sentences=split_sentences)
+        if split_sentences:
+            lengths = [len(p) for p in input_ids]
+        else:
+            lengths, input_ids = [len(input_ids)], [input_ids]
+        sids = [sid] * len(input_ids) if sid is not None else None
+        lids = [lid] * len(input_ids) if lid is not None else None
+        ia = self.inference_args
+        inputs = InferenceInputs.from_ids_and_lengths(ids=input_ids, lengths=lengths, clean_text=clean_text, sids=sids,
+                                                      lids=lids, d_factor=d_factor or ia.d_factor,
+                                                      p_factor=p_factor or ia.p_factor, e_factor=e_factor or ia.e_factor)
+        return inputs.as_torch().to(self.device)
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, config=None, strict=False, **kwargs):
+        """Read a reference (Lightning) ``.ckpt``: only ``state_dict`` is used; the pickled Hydra partials /
+        OmegaConf nodes of ``hyper_parameters`` are skipped by a tolerant unpickler, and
+        the architecture comes from ``config`` (default: the BASELINE ConvNeXt configuration)."""
+        from ..config import ModelConfig, make_optispeech
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", pickle_module=_TolerantPickle,
+                          weights_only=False)
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        model = make_optispeech(config or ModelConfig())
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        bad = [k for k in missing if "melspec_loss" not in k and "window" not in k]
+        if strict and (bad or unexpected):
+            raise RuntimeError(f"checkpoint mismatch: missing {bad[:5]}, unexpected {list(unexpected)[:5]}")
+        model.ckpt_loaded_epoch = ckpt.get("epoch") if isinstance(ckpt, dict) else None    # on_load_checkpoint :305-306
+        return model
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+    def __setstate__(self, state):
+        pass
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            return _Dummy
+
+
+class _TolerantPickle:
+    """pickle-module shim for torch.load: unknown classes (lightning / omegaconf / hydra / optispeech.*) -> inert."""
+    __name__ = "tolerant_pickle"
+    Unpickler = _TolerantUnpickler
+    load = staticmethod(lambda f, **kw: _TolerantUnpickler(f, **kw).load())
+    loads = staticmethod(lambda b, **kw: _TolerantUnpickler(io.BytesIO(b), **kw).load())
