@@ -1,0 +1,42 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/osp.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "osp.h")).read()
+    return sorted(set(re.findall(r"\b(osp_\w+)\s*\(", txt)))
+
+
+def test_header_is_valid_c():
+    subprocess.check_call(["gcc", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "osp.h")])
+
+
+def test_library_exports_every_declared_symbol():
+    from optispeech_amd.build import build
+    lib = ctypes.CDLL(build(verbose=False))
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/osp.h but not exported"
+    lib.osp_abi_version.restype = ctypes.c_int
+    assert lib.osp_abi_version() >= 1
+
+
+def test_header_matches_sources():
+    """include/osp.h is generated; regenerate and compare so it cannot drift from the kernels."""
+    before = open(os.path.join(ROOT, "include", "osp.h")).read()
+    subprocess.check_call(["python", os.path.join(ROOT, "tools", "gen_header.py")], stdout=subprocess.DEVNULL)
+    assert open(os.path.join(ROOT, "include", "osp.h")).read() == before
+
+
+def test_product_never_imports_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "optispeech_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
