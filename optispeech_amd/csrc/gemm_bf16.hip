@@ -1,0 +1,573 @@
+// bf16-MFMA conv-GEMM family (performance mode; f32 accumulate): forward / dgrad kernel and weight-gradient kernel.
+//
+// Serves the same call sites as gemm.hip (pointwise Linear, k-tap Conv1d on channels-last frames, batched products)
+// plus the STRIDED (k,1) convolutions of the multi-period discriminator (DiscriminatorP,
+// vocoder/wavenext/disc/_discriminators.py:51-60): in channels-last layout every (utterance, period-column) is an
+// independent 1-D sequence, so Conv2d((5,1), stride (3,1)) is a strided k-tap Conv1d = a GEMM over K = taps*Cin whose
+// operand row for output frame t and tap j is input frame t*stride + j - pad (no im2col, no layout change).
+//
+// Operands may be stored f32 or bf16 in HBM; they are converted (v_cvt_pk_bf16_f32, RNE) while being staged into LDS.
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles (64 accumulator
+// VGPRs).  LDS image is row-major with 8 consecutive k per 16-byte slot and rows padded to 72 bf16 (144 B): the
+// fragment ds_read_b128 of a 16-lane group then touches 16 distinct slots (conflict-free).  Register-staged double
+// buffering: the global loads of tile i+1 are in flight while tile i feeds the matrix pipe; one barrier per tile.
+// Sources whose reduction index is NOT the contiguous one (dgrad weights, both wgrad operands) go through a
+// transposing loader: 8 strided rows x float4 per thread, packed to k-contiguous 16-byte LDS slots.
+#include "osp_common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+#define LDK (TBK + 8)
+
+enum { BEPI_NONE = 0, BEPI_RELU = 1, BEPI_GELU = 2, BEPI_SCALE_RES_MASK = 3, BEPI_GELU_BWD = 4, BEPI_RELU_BWD = 5,
+       BEPI_AXMY = 6, BEPI_MASK = 7, BEPI_LRELU = 8, BEPI_LRELU_BWD = 9 };
+
+struct GemmB {
+    const void* A; int a_bf16; int64_t lda; int M, Trows, Tin, Cin, taps, a_step, a_tapstep, a_off;
+    const float* a_rowscale;
+    const void* B; int b_bf16; int64_t sBn, sBtap, sBk; int N;
+    void* C; int c_bf16; int64_t ldc; int Tc, c_step, c_off;
+    int epi; const float *bias, *gamma, *res; int64_t ldr; const float *rowmask, *rowscale;
+    float* aux_out; const void* aux_in; int aux_bf16; int64_t ld_aux; float slope;
+    const void* res_any; int res_bf16;   // LRELU_BWD extra addend (f32 or bf16)
+    int64_t sAb, sBb, sCb, sXb; int accumulate;
+};
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float ld_elem(const void* p, int is_bf16, int64_t off) {
+    return is_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(p)[off]) : reinterpret_cast<const float*>(p)[off];
+}
+// 8 consecutive elements starting at element offset `off` -> packed bf16x8
+__device__ __forceinline__ uint4 ld8_contig(const void* p, int is_bf16, int64_t off, bool vec) {
+    if (is_bf16) {
+        if (vec) return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + off);
+        const unsigned short* h = reinterpret_cast<const unsigned short*>(p) + off;
+        return make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
+                          h[6] | ((unsigned)h[7] << 16));
+    }
+    const float* f = reinterpret_cast<const float*>(p) + off;
+    if (vec) {
+        const float4 a = *reinterpret_cast<const float4*>(f), b = *reinterpret_cast<const float4*>(f + 4);
+        return make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+    }
+    return make_uint4(pk2(f[0], f[1]), pk2(f[2], f[3]), pk2(f[4], f[5]), pk2(f[6], f[7]));
+}
+
+template <int TM_, int TN_, int BK_ = TBK>
+__device__ __forceinline__ void mma_tile_bf16(const unsigned short* __restrict__ As, const unsigned short* __restrict__ Bs,
+                                              int wm0, int wn0, int lane, f32x16 (&acc)[TM_][TN_]) {
+    constexpr int LD_ = BK_ + 8;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < BK_ / 16; ++ks) {
+        bf16x8 a[TM_], b[TN_];
+#pragma unroll
+        for (int i = 0; i < TM_; ++i)
+            a[i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + 32 * i + l31) * LD_ + ks * 16 + 8 * lh);
+#pragma unroll
+        for (int j = 0; j < TN_; ++j)
+            b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + 32 * j + l31) * LD_ + ks * 16 + 8 * lh);
+#pragma unroll
+        for (int i = 0; i < TM_; ++i)
+#pragma unroll
+            for (int j = 0; j < TN_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+// FAST: every operand row is 16-byte addressable (Cin % 8 == 0, aligned strides, no per-row A scale) -- the generic
+// element-wise loaders are not even compiled into that instantiation (they bloat the loop past the I-cache).
+template <bool B_KCONTIG, int BKT, bool FAST>
+__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
+    constexpr int LDK_ = BKT + 8, KG = BKT / 8, NI = TBM * KG / 256, RSTEP = 256 / KG;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (TBM + TBN) * LDK_];
+    unsigned short* As = smem;                       // [2][TBM][LDK_]
+    unsigned short* Bs = smem + 2 * TBM * LDK_;      // [2][TBN][LDK_]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+    const int64_t bz = blockIdx.z;
+    const int esA = p.a_bf16 ? 2 : 4, esB = p.b_bf16 ? 2 : 4;
+    const char* A = reinterpret_cast<const char*>(p.A) + bz * p.sAb * esA;
+    const char* B = reinterpret_cast<const char*>(p.B) + bz * p.sBb * esB;
+    const int K = p.taps * p.Cin;
+
+    // A items: NI per thread: row = tid / KG + RSTEP*i, k-group g = tid % KG
+    const int g = tid % KG, r0 = tid / KG;
+    int a_t[NI]; int64_t a_base[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m = m0 + r0 + RSTEP * i;
+        if (m < p.M) {
+            const int u = m / p.Trows, t = m - u * p.Trows;
+            a_t[i] = t * p.a_step + p.a_off;
+            a_base[i] = (int64_t)u * p.Tin;
+        } else { a_t[i] = -0x40000000; a_base[i] = 0; }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[NI], rb[NI > 4 ? NI : 4];
+    auto a_elem = [&](int i, int k) -> float {
+        if (k >= K) return 0.f;
+        const int j = k / p.Cin, c = k - j * p.Cin, tt = a_t[i] + j * p.a_tapstep;
+        if (tt < 0 || tt >= p.Tin) return 0.f;
+        float v = ld_elem(A, p.a_bf16, (a_base[i] + tt) * p.lda + c);
+        if (p.a_rowscale) v *= p.a_rowscale[bz * p.M + a_base[i] + tt];
+        return v;
+    };
+    auto gload = [&](int kt) {
+        const int k0 = kt * BKT + g * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if constexpr (FAST) {
+                if (k0 < K) {
+                    const int j = k0 / p.Cin, c = k0 - j * p.Cin, tt = a_t[i] + j * p.a_tapstep;
+                    if (tt >= 0 && tt < p.Tin) v = ld8_contig(A, p.a_bf16, (a_base[i] + tt) * p.lda + c, true);
+                }
+            } else {
+                v = make_uint4(pk2(a_elem(i, k0), a_elem(i, k0 + 1)), pk2(a_elem(i, k0 + 2), a_elem(i, k0 + 3)),
+                               pk2(a_elem(i, k0 + 4), a_elem(i, k0 + 5)), pk2(a_elem(i, k0 + 6), a_elem(i, k0 + 7)));
+            }
+            ra[i] = v;
+        }
+        if constexpr (B_KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int n = n0 + r0 + RSTEP * i;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (n < p.N && k0 < K) {
+                    if constexpr (FAST) {
+                        const int j = k0 / p.Cin, c = k0 - j * p.Cin;
+                        v = ld8_contig(B, p.b_bf16, (int64_t)n * p.sBn + (int64_t)j * p.sBtap + c, true);
+                    } else {
+                        float e[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int k = k0 + q;
+                            float x = 0.f;
+                            if (k < K) { const int j = k / p.Cin, c = k - j * p.Cin;
+                                x = ld_elem(B, p.b_bf16, (int64_t)n * p.sBn + (int64_t)j * p.sBtap + (int64_t)c * p.sBk); }
+                            e[q] = x;
+                        }
+                        v = make_uint4(pk2(e[0], e[1]), pk2(e[2], e[3]), pk2(e[4], e[5]), pk2(e[6], e[7]));
+                    }
+                }
+                rb[i] = v;
+            }
+        } else {
+            // transposing loader: k-group kg (8 reduction rows) x 4 output columns per thread
+            static_assert(BKT == 64, "the k-strided B loader is laid out for BK = 64");
+            const int kg = tid >> 5, n4 = tid & 31, nn = n0 + 4 * n4;
+            float4 rows[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = kt * BKT + kg * 8 + q;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && nn < p.N) {
+                    const int j = k / p.Cin, c = k - j * p.Cin;
+                    const int64_t off = (int64_t)c * p.sBk + (int64_t)j * p.sBtap + nn;
+                    if (FAST && nn + 3 < p.N) x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + off);
+                    else {
+                        x.x = ld_elem(B, p.b_bf16, off);
+                        if (nn + 1 < p.N) x.y = ld_elem(B, p.b_bf16, off + 1);
+                        if (nn + 2 < p.N) x.z = ld_elem(B, p.b_bf16, off + 2);
+                        if (nn + 3 < p.N) x.w = ld_elem(B, p.b_bf16, off + 3);
+                    }
+                }
+                rows[q] = x;
+            }
+            rb[0] = make_uint4(pk2(rows[0].x, rows[1].x), pk2(rows[2].x, rows[3].x), pk2(rows[4].x, rows[5].x), pk2(rows[6].x, rows[7].x));
+            rb[1] = make_uint4(pk2(rows[0].y, rows[1].y), pk2(rows[2].y, rows[3].y), pk2(rows[4].y, rows[5].y), pk2(rows[6].y, rows[7].y));
+            rb[2] = make_uint4(pk2(rows[0].z, rows[1].z), pk2(rows[2].z, rows[3].z), pk2(rows[4].z, rows[5].z), pk2(rows[6].z, rows[7].z));
+            rb[3] = make_uint4(pk2(rows[0].w, rows[1].w), pk2(rows[2].w, rows[3].w), pk2(rows[4].w, rows[5].w), pk2(rows[6].w, rows[7].w));
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned short* as = As + buf * TBM * LDK_;
+        unsigned short* bs = Bs + buf * TBN * LDK_;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(as + (r0 + RSTEP * i) * LDK_ + g * 8) = ra[i];
+        if constexpr (B_KCONTIG) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(bs + (r0 + RSTEP * i) * LDK_ + g * 8) = rb[i];
+        } else {
+            const int kg = tid >> 5, n4 = tid & 31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(bs + (4 * n4 + q) * LDK_ + kg * 8) = rb[q];
+        }
+    };
+
+    const int nk = (K + BKT - 1) / BKT;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        mma_tile_bf16<2, 2, BKT>(As + buf * TBM * LDK_, Bs + buf * TBN * LDK_, wm0, wn0, lane, acc);
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    const int esC = p.c_bf16 ? 2 : 4;
+    char* Cb = reinterpret_cast<char*>(p.C) + bz * p.sCb * esC;
+    const float* res = p.res ? p.res + bz * p.sXb : nullptr;
+    const char* aux_in = p.aux_in ? reinterpret_cast<const char*>(p.aux_in) + bz * p.sXb * (p.aux_bf16 ? 2 : 4) : nullptr;
+    float* aux_out = p.aux_out ? p.aux_out + bz * p.sXb : nullptr;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn0 + 32 * j + l31;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const float gam = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const int64_t mr = bz * p.M + m;
+                const float v = acc[i][j][r] + bias;
+                const int u = m / p.Trows, t = m - u * p.Trows;
+                const int64_t crow = (int64_t)u * p.Tc + (int64_t)t * p.c_step + p.c_off;   // aux / res follow C's rows
+                float out;
+                switch (p.epi) {
+                    case BEPI_RELU: out = fmaxf(v, 0.f); break;
+                    case BEPI_LRELU: out = v > 0.f ? v : v * p.slope; break;
+                    case BEPI_GELU:
+                        if (aux_out) aux_out[crow * p.ld_aux + n] = v;
+                        out = gelu_f(v);
+                        break;
+                    case BEPI_SCALE_RES_MASK: {
+                        if (aux_out) aux_out[crow * p.ld_aux + n] = v;
+                        const float rs = p.rowscale ? p.rowscale[mr] : 1.f, mk = p.rowmask ? p.rowmask[mr] : 1.f;
+                        out = (res[crow * p.ldr + n] + rs * gam * v) * mk;
+                    } break;
+                    case BEPI_GELU_BWD:
+                        out = (p.rowscale ? p.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n));
+                        break;
+                    case BEPI_RELU_BWD: out = ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n) > 0.f ? v : 0.f; break;
+                    case BEPI_LRELU_BWD: {   // (acc + extra) * lrelu'(y):  extra = gradient arriving at the same activation
+                        const float e = p.res_any ? ld_elem(p.res_any, p.res_bf16, crow * p.ldr + n) : 0.f;
+                        out = ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n) > 0.f ? (v + e) : (v + e) * p.slope;
+                    } break;
+                    case BEPI_AXMY: out = (p.rowscale ? p.rowscale[mr] : 1.f) * ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n) - v; break;
+                    case BEPI_MASK: out = v * (p.rowmask ? p.rowmask[mr] : 1.f); break;
+                    default: out = v;
+                }
+                if (p.c_bf16) {
+                    reinterpret_cast<__bf16*>(Cb)[crow * p.ldc + n] = (__bf16)out;
+                } else {
+                    float* dst = reinterpret_cast<float*>(Cb) + crow * p.ldc + n;
+                    *dst = p.accumulate ? (*dst + out) : out;
+                }
+            }
+        }
+}
+
+// C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
+// for t < Trows (rows M = utterances * Trows); a tap that leaves [0, Tin) contributes zero.
+//   forward strided conv : a_step = stride, a_tapstep = 1, a_off = -pad, Tc = Trows = T_out, c_step = 1, c_off = 0
+//   dgrad of a strided conv, phase r : see optispeech_amd/ops.py (MPD) -- rows q, t_in = r + stride*q
+// dtype flags: 0 = f32 storage, 1 = bf16 storage.
+extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
+                                  int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
+                                  const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
+                                  int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
+                                  int64_t c_step, int64_t c_off, int64_t epi, const float* bias, const float* gamma,
+                                  const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
+                                  float* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
+                                  int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
+                                  hipStream_t stream) {
+    OSP_CHECK_ARG(A && B && C, "null operand");
+    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && Tin > 0 && batch > 0, "bad shape");
+    OSP_CHECK_ARG(M % Trows == 0, "M must be a whole number of utterances");
+    OSP_CHECK_ARG(sBk == 1 || sBn == 1, "B must be contiguous along k or along n");
+    OSP_CHECK_ARG(epi >= 0 && epi <= BEPI_LRELU_BWD, "unknown epilogue");
+    OSP_CHECK_ARG(epi != BEPI_SCALE_RES_MASK || (res && !res_bf16), "epilogue needs an f32 res");
+    OSP_CHECK_ARG((epi != BEPI_GELU_BWD && epi != BEPI_RELU_BWD && epi != BEPI_AXMY && epi != BEPI_LRELU_BWD) || aux_in, "epilogue needs aux_in");
+    OSP_CHECK_ARG(!(c_bf16 && accumulate), "accumulate needs an f32 destination");
+    GemmB p;
+    p.A = A; p.a_bf16 = (int)a_bf16; p.lda = lda; p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.Cin = (int)Cin;
+    p.taps = (int)taps; p.a_step = (int)a_step; p.a_tapstep = (int)a_tapstep; p.a_off = (int)a_off; p.a_rowscale = a_rowscale;
+    p.B = B; p.b_bf16 = (int)b_bf16; p.sBn = sBn; p.sBtap = sBtap; p.sBk = sBk; p.N = (int)N;
+    p.C = C; p.c_bf16 = (int)c_bf16; p.ldc = ldc; p.Tc = (int)Tc; p.c_step = (int)c_step; p.c_off = (int)c_off;
+    p.epi = (int)epi; p.bias = bias; p.gamma = gamma; p.res = res_bf16 ? nullptr : (const float*)res; p.ldr = ldr;
+    p.res_any = res; p.res_bf16 = (int)res_bf16; p.rowmask = rowmask; p.rowscale = rowscale;
+    p.aux_out = aux_out; p.aux_in = aux_in; p.aux_bf16 = (int)aux_bf16; p.ld_aux = ld_aux; p.slope = slope;
+    p.sAb = sAb; p.sBb = sBb; p.sCb = sCb; p.sXb = sXb; p.accumulate = (int)accumulate;
+    dim3 grid((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, TBM), (unsigned)batch);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int64_t ea = a_bf16 ? 2 : 4, eb = b_bf16 ? 2 : 4;
+    const bool a_fast = (Cin % 8 == 0) && (lda % 8 == 0) && al16(A) && ((sAb * ea) % 16 == 0) && !a_rowscale;
+    bool fast;
+    if (sBk == 1)
+        fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+    else
+        fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+    if (sBk != 1) {
+        if (fast) hipLaunchKernelGGL((conv_gemm_bf16_kernel<false, 64, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<false, 64, false>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_gemm_bf16_kernel<true, 64, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<true, 64, false>), grid, dim3(256), 0, stream, p);
+    }
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW[n, j, c] += oscale[n] * sum_{u,t} arow * dY[u, t, n] * X[u, t*x_step + j - pad, c];  db[n] likewise.
+// Both operands are reduction-major -> transposing loader for both.  Split over the frame dimension, f32 atomics.
+struct WgradB {
+    const void* dY; int y_bf16; int64_t ldy; const void* X; int x_bf16; int64_t ldx;
+    int M, Trows, Tin, N, Cin, taps, pad, x_step;
+    const float *arow, *oscale; float* dW; int64_t ldw; float* db; int chunk, splits;
+    int64_t sYb, sXb, sWb, sDb;
+};
+
+__device__ __forceinline__ float4 ld4_any(const void* p, int is_bf16, int64_t off, int lim, bool vec) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lim >= 4 && vec) {
+        if (is_bf16) {
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off);
+            x = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                            __uint_as_float(h.y & 0xffff0000u));
+        } else x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + off);
+    } else {
+        if (lim > 0) x.x = ld_elem(p, is_bf16, off);
+        if (lim > 1) x.y = ld_elem(p, is_bf16, off + 1);
+        if (lim > 2) x.z = ld_elem(p, is_bf16, off + 2);
+        if (lim > 3) x.w = ld_elem(p, is_bf16, off + 3);
+    }
+    return x;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (TBM + TBN) * LDK];
+    unsigned short* As = smem;
+    unsigned short* Bs = smem + 2 * TBM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int ctiles = (p.Cin + TBN - 1) / TBN;
+    const int j = blockIdx.y / ctiles, c0 = (blockIdx.y - j * ctiles) * TBN;
+    const int n0 = blockIdx.x * TBM;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z - bz * p.splits;
+    const char* dY = reinterpret_cast<const char*>(p.dY) + (int64_t)bz * p.sYb * (p.y_bf16 ? 2 : 4);
+    const char* X = reinterpret_cast<const char*>(p.X) + (int64_t)bz * p.sXb * (p.x_bf16 ? 2 : 4);
+    const float* arow = p.arow ? p.arow + (int64_t)bz * p.M : nullptr;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const bool y_vec = (p.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dY) & 15) == 0);
+    const bool x_vec = (p.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const int kg = tid >> 5, c4 = tid & 31;                   // k-group (8 frames) x 4 columns
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bias = (p.db != nullptr) && (blockIdx.y == 0);
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int mk) {
+        float4 ya[8], xb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mk + kg * 8 + q;
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f), x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) {
+                const int n = n0 + 4 * c4;
+                if (n < p.N) {
+                    y = ld4_any(dY, p.y_bf16, (int64_t)m * p.ldy + n, p.N - n, y_vec);
+                    if (arow) { const float s = arow[m]; y.x *= s; y.y *= s; y.z *= s; y.w *= s; }
+                }
+                const int u = m / p.Trows, t = m - u * p.Trows, tt = t * p.x_step + j - p.pad;
+                const int c = c0 + 4 * c4;
+                if (tt >= 0 && tt < p.Tin && c < p.Cin)
+                    x = ld4_any(X, p.x_bf16, ((int64_t)u * p.Tin + tt) * p.ldx + c, p.Cin - c, x_vec);
+            }
+            ya[q] = y; xb[q] = x;
+            if (do_bias) { bsum.x += y.x; bsum.y += y.y; bsum.z += y.z; bsum.w += y.w; }
+        }
+        ra[0] = make_uint4(pk2(ya[0].x, ya[1].x), pk2(ya[2].x, ya[3].x), pk2(ya[4].x, ya[5].x), pk2(ya[6].x, ya[7].x));
+        ra[1] = make_uint4(pk2(ya[0].y, ya[1].y), pk2(ya[2].y, ya[3].y), pk2(ya[4].y, ya[5].y), pk2(ya[6].y, ya[7].y));
+        ra[2] = make_uint4(pk2(ya[0].z, ya[1].z), pk2(ya[2].z, ya[3].z), pk2(ya[4].z, ya[5].z), pk2(ya[6].z, ya[7].z));
+        ra[3] = make_uint4(pk2(ya[0].w, ya[1].w), pk2(ya[2].w, ya[3].w), pk2(ya[4].w, ya[5].w), pk2(ya[6].w, ya[7].w));
+        rb[0] = make_uint4(pk2(xb[0].x, xb[1].x), pk2(xb[2].x, xb[3].x), pk2(xb[4].x, xb[5].x), pk2(xb[6].x, xb[7].x));
+        rb[1] = make_uint4(pk2(xb[0].y, xb[1].y), pk2(xb[2].y, xb[3].y), pk2(xb[4].y, xb[5].y), pk2(xb[6].y, xb[7].y));
+        rb[2] = make_uint4(pk2(xb[0].z, xb[1].z), pk2(xb[2].z, xb[3].z), pk2(xb[4].z, xb[5].z), pk2(xb[6].z, xb[7].z));
+        rb[3] = make_uint4(pk2(xb[0].w, xb[1].w), pk2(xb[2].w, xb[3].w), pk2(xb[4].w, xb[5].w), pk2(xb[6].w, xb[7].w));
+    };
+    auto sstore = [&](int buf) {
+        unsigned short* as = As + buf * TBM * LDK;
+        unsigned short* bs = Bs + buf * TBN * LDK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<uint4*>(as + (4 * c4 + q) * LDK + kg * 8) = ra[q];
+            *reinterpret_cast<uint4*>(bs + (4 * c4 + q) * LDK + kg * 8) = rb[q];
+        }
+    };
+    // ---- fast path: both operands bf16 with 16-byte rows.  Threads 0-127 stage the dY tile, 128-255 the X tile:
+    // 8 frames x 8 channels per thread (eight 16-byte loads), 8x8 bf16 transpose in registers, eight ds_write_b128.
+    constexpr bool fast = FAST;
+    const int half = tid >> 7, ht = tid & 127, fkg = ht >> 4, c8 = ht & 15;
+    uint4 r8[8];
+    float bs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto gload_fast = [&](int mk) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mk + fkg * 8 + q;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < mend) {
+                if (half == 0) {
+                    const int n = n0 + 8 * c8;
+                    if (n < p.N) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dY) + (int64_t)m * p.ldy + n);
+                } else {
+                    const int u = m / p.Trows, t = m - u * p.Trows, tt = t * p.x_step + j - p.pad, c = c0 + 8 * c8;
+                    if (tt >= 0 && tt < p.Tin && c < p.Cin)
+                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + ((int64_t)u * p.Tin + tt) * p.ldx + c);
+                }
+            }
+            r8[q] = v;
+        }
+        if (do_bias && half == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bs8[0] += __uint_as_float(r8[q].x << 16); bs8[1] += __uint_as_float(r8[q].x & 0xffff0000u);
+                bs8[2] += __uint_as_float(r8[q].y << 16); bs8[3] += __uint_as_float(r8[q].y & 0xffff0000u);
+                bs8[4] += __uint_as_float(r8[q].z << 16); bs8[5] += __uint_as_float(r8[q].z & 0xffff0000u);
+                bs8[6] += __uint_as_float(r8[q].w << 16); bs8[7] += __uint_as_float(r8[q].w & 0xffff0000u);
+            }
+        }
+    };
+    auto sstore_fast = [&](int buf) {
+        unsigned short* dst = (half == 0 ? As + buf * TBM * LDK : Bs + buf * TBN * LDK) + (8 * c8) * LDK + fkg * 8;
+        const unsigned* w = reinterpret_cast<const unsigned*>(r8);      // w[q*4 + d]: frame q, channel pair d
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint4 lo, hi;                                                // channels 2d and 2d+1, frames 0..7
+            lo.x = (w[0 * 4 + d] & 0xffffu) | (w[1 * 4 + d] << 16);  hi.x = (w[0 * 4 + d] >> 16) | (w[1 * 4 + d] & 0xffff0000u);
+            lo.y = (w[2 * 4 + d] & 0xffffu) | (w[3 * 4 + d] << 16);  hi.y = (w[2 * 4 + d] >> 16) | (w[3 * 4 + d] & 0xffff0000u);
+            lo.z = (w[4 * 4 + d] & 0xffffu) | (w[5 * 4 + d] << 16);  hi.z = (w[4 * 4 + d] >> 16) | (w[5 * 4 + d] & 0xffff0000u);
+            lo.w = (w[6 * 4 + d] & 0xffffu) | (w[7 * 4 + d] << 16);  hi.w = (w[6 * 4 + d] >> 16) | (w[7 * 4 + d] & 0xffff0000u);
+            *reinterpret_cast<uint4*>(dst + (2 * d) * LDK) = lo;
+            *reinterpret_cast<uint4*>(dst + (2 * d + 1) * LDK) = hi;
+        }
+    };
+    const int niter = (mend - mbeg + TBK - 1) / TBK;
+    if (niter > 0) {
+        if constexpr (fast) { gload_fast(mbeg); sstore_fast(0); } else { gload(mbeg); sstore(0); }
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < niter) { if constexpr (fast) gload_fast(mbeg + (it + 1) * TBK); else gload(mbeg + (it + 1) * TBK); }
+            mma_tile_bf16<2, 2>(As + buf * TBM * LDK, Bs + buf * TBN * LDK, wm0, wn0, lane, acc);
+            if (it + 1 < niter) { if constexpr (fast) sstore_fast(buf ^ 1); else sstore(buf ^ 1); }
+            __syncthreads();
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int c = c0 + wn0 + 32 * jj + l31;
+            if (c >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n >= p.N) continue;
+                atomicAdd(dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c, (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r]);
+            }
+        }
+    if (do_bias) {
+        // reduce the per-thread column sums over the 8 k-groups (threads with equal columns) through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [8][128]
+        if constexpr (fast) {
+            if (half == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[fkg * 128 + 8 * c8 + e] = bs8[e];
+            }
+        } else {
+            *reinterpret_cast<float4*>(red + kg * 128 + 4 * c4) = bsum;
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q * 128 + tid];
+            atomicAdd(p.db + (int64_t)bz * p.sDb + n0 + tid, (p.oscale ? p.oscale[n0 + tid] : 1.f) * s);
+        }
+    }
+}
+
+extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                   int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
+                                   int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
+                                   float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                   hipStream_t stream) {
+    OSP_CHECK_ARG(dY && X && dW, "null operand");
+    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && M % Trows == 0 && batch > 0, "bad shape");
+    WgradB p;
+    p.dY = dY; p.y_bf16 = (int)y_bf16; p.ldy = ldy; p.X = X; p.x_bf16 = (int)x_bf16; p.ldx = ldx;
+    p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.N = (int)N; p.Cin = (int)Cin; p.taps = (int)taps;
+    p.pad = (int)pad; p.x_step = (int)x_step; p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db;
+    p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb;
+    const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
+    int64_t splits = cdiv(512, tiles);
+    int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
+    if (chunk < 2 * TBK) chunk = 2 * TBK;
+    splits = cdiv(M, chunk);
+    p.chunk = (int)chunk; p.splits = (int)splits;
+    dim3 grid((unsigned)cdiv(N, TBM), (unsigned)(taps * cdiv(Cin, TBN)), (unsigned)(splits * batch));
+    const bool fast = y_bf16 && x_bf16 && !arow && (ldy % 8 == 0) && (ldx % 8 == 0) && (N % 8 == 0) && (Cin % 8 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dY) & 15) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                      (sYb % 8 == 0) && (sXb % 8 == 0);
+    if (fast) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ casts
+__global__ void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<uint2*>(y)[i] = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = __builtin_bit_cast(unsigned short, (__bf16)x[i]);
+}
+extern "C" int osp_cast_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
+    OSP_CHECK_ARG(x && y && n > 0, "bad args");
+    const int64_t blocks = cdiv(n, 1024);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, x, (unsigned short*)y, n);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

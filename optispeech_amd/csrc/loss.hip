@@ -187,6 +187,98 @@ __global__ __launch_bounds__(64) void forwardsum_ctc_kernel(const float* __restr
     }
 }
 
+
+// ---- multi-wave variant (S = 2N+1 <= 1024 states): one thread per CTC state, one workgroup per utterance, the
+// alpha / beta columns ping-pong through LDS with one barrier per frame; the per-frame log-sum-exp comes from a
+// separate fully parallel kernel.  ~50x less serial work per step than the one-wave kernel above.
+__global__ __launch_bounds__(256) void ctc_frame_lse_kernel(const float* __restrict__ lp, const int64_t* __restrict__ x_len,
+                                                           const int64_t* __restrict__ y_len, float log_blank,
+                                                           float* __restrict__ lse, int B, int Tm, int Nm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * Tm) return;
+    const int b = (int)(row / Tm), t = (int)(row - (int64_t)b * Tm);
+    const int N = (int)x_len[b];
+    if (t >= (int)y_len[b]) return;
+    const float* L = lp + row * Nm;
+    float mx = log_blank;
+    for (int k = lane; k < N; k += 64) mx = fmaxf(mx, L[k]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int k = lane; k < N; k += 64) sm += expf(L[k] - mx);
+    sm = wave_sum(sm) + expf(log_blank - mx);
+    if (lane == 0) lse[row] = mx + logf(sm);
+}
+
+__global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int64_t* __restrict__ x_len,
+                                         const int64_t* __restrict__ y_len, float log_blank, float* __restrict__ alpha_ws,
+                                         const float* __restrict__ lse_ws, float* __restrict__ loss_item,
+                                         float* __restrict__ grad, int B, int Tm, int Nm, int SW) {
+    extern __shared__ float sh[];                      // [2][SW + 2]  (two leading -inf guard cells per column)
+    __shared__ float s_nll;
+    const int b = blockIdx.x, s = threadIdx.x;
+    const int T = (int)y_len[b], N = (int)x_len[b];
+    const int S = 2 * N + 1;
+    const float* L = lp + (int64_t)b * Tm * Nm;
+    float* G = grad ? grad + (int64_t)b * Tm * Nm : nullptr;
+    if (G)
+        for (int64_t i = s; i < (int64_t)Tm * Nm; i += blockDim.x) G[i] = 0.f;
+    if (T <= 0 || N <= 0) { if (s == 0) loss_item[b] = 0.f; return; }
+    float* AW = alpha_ws + (int64_t)b * Tm * SW;
+    const float* LW = lse_ws + (int64_t)b * Tm;
+    const bool live = s < S, lab = (s & 1) != 0;
+    const int tok = s >> 1;
+    float* col[2] = {sh + 2, sh + (SW + 2) + 2};
+    if (s < 2) { sh[s] = -INFINITY; sh[(SW + 2) + s] = -INFINITY; }
+    // ---- alpha
+    float a = -INFINITY;
+    for (int t = 0; t < T; ++t) {
+        const float y = live ? ((lab ? L[(int64_t)t * Nm + tok] : log_blank) - LW[t]) : -INFINITY;
+        float v;
+        if (t == 0) v = (s < 2 && live) ? y : -INFINITY;
+        else {
+            const float* pc = col[(t - 1) & 1];
+            v = lab ? lse3(a, pc[s - 1], pc[s - 2]) : lse2(a, pc[s - 1]);
+            v = live ? v + y : -INFINITY;
+        }
+        a = v;
+        col[t & 1][s] = v;
+        AW[(int64_t)t * SW + s] = v;
+        __syncthreads();
+    }
+    if (s == 0) {
+        const float* pc = col[(T - 1) & 1];
+        const float ll = lse2(pc[S - 1], S >= 2 ? pc[S - 2] : -INFINITY);
+        s_nll = -ll;
+        const bool inf = !(-ll < INFINITY);
+        loss_item[b] = inf ? 0.f : -ll / (float)N;
+    }
+    __syncthreads();
+    const float nll = s_nll;
+    if (!G || !(nll < INFINITY)) return;
+    const float gs = 1.f / ((float)N * (float)B);
+    // ---- beta + gradient (columns stored with two trailing guard cells: index s+1, s+2 may run past S)
+    float be = -INFINITY;
+    for (int t = T - 1; t >= 0; --t) {
+        const float y = live ? ((lab ? L[(int64_t)t * Nm + tok] : log_blank) - LW[t]) : -INFINITY;
+        float v;
+        if (t == T - 1) v = (s == S - 1 || s == S - 2) ? y : -INFINITY;
+        else {
+            const float* pc = col[(t + 1) & 1];
+            const float n1 = s + 1 < S ? pc[s + 1] : -INFINITY, n2 = s + 2 < S ? pc[s + 2] : -INFINITY;
+            v = (lab && s + 2 < S) ? lse3(be, n1, n2) : lse2(be, n1);
+            v = live ? v + y : -INFINITY;
+        }
+        be = v;
+        col[t & 1][s] = v;
+        if (live && lab) {
+            const float occ = expf(AW[(int64_t)t * SW + s] + v + nll - y);
+            G[(int64_t)t * Nm + tok] = (expf(y) - occ) * gs;
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int64_t osp_forwardsum_ctc_workspace_floats(int64_t B, int64_t Tm, int64_t Nm) {
     int64_t R = (2 * Nm + 1 + 63) / 64, Rp = 1;
     while (Rp < R) Rp *= 2;
@@ -204,6 +296,15 @@ extern "C" int osp_forwardsum_ctc(const float* lp, const int64_t* x_len, const i
     while (Rp < R) Rp *= 2;
     float* alpha_ws = workspace;
     float* lse_ws = workspace + B * Tm * Rp * 64;
+    if (R * 64 <= 1024) {                               // multi-wave path: one thread per state
+        const int SW = (int)(R * 64);
+        hipLaunchKernelGGL(ctc_frame_lse_kernel, dim3((unsigned)cdiv(B * Tm, 4)), dim3(256), 0, stream, lp, x_len, y_len,
+                           blank_logprob, lse_ws, (int)B, (int)Tm, (int)Nm);
+        hipLaunchKernelGGL(forwardsum_ctc_mw_kernel, dim3((unsigned)B), dim3((unsigned)SW), sizeof(float) * 2 * (SW + 2), stream,
+                           lp, x_len, y_len, blank_logprob, alpha_ws, lse_ws, loss_item, grad, (int)B, (int)Tm, (int)Nm, SW);
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
 #define L(RR) hipLaunchKernelGGL((forwardsum_ctc_kernel<RR>), dim3((unsigned)B), dim3(64), 0, stream, lp, x_len, y_len, blank_logprob, alpha_ws, lse_ws, loss_item, grad, (int)B, (int)Tm, (int)Nm)
     switch (Rp) {
         case 1: L(1); break; case 2: L(2); break; case 4: L(4); break; case 8: L(8); break;

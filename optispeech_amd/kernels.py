@@ -266,3 +266,48 @@ def text_embed_bwd(dy, tok, pos, dE, dscale, padding_idx=0, drop_p=0.0, seed=0, 
     B, T, C = dy.shape
     call("osp_text_embed_bwd", dy.contiguous(), tok, pos, float(C) ** 0.5, float(drop_p), int(seed), int(stream_id),
          int(padding_idx), dE, dscale, B, T, C)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 MFMA GEMMs
+EPI_LRELU, EPI_LRELU_BWD = 8, 9
+
+
+def _isbf(t):
+    return int(t is not None and t.dtype == torch.bfloat16)
+
+
+def cast_bf16(x):
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    call("osp_cast_bf16", x.contiguous(), y, x.numel())
+    return y
+
+
+def conv_gemm_bf16(a, w, n_out, *, M, Trows, Tin, cin, taps=1, a_step=1, a_tapstep=1, a_off=0, lda=None,
+                   w_strides=None, out=None, out_bf16=False, ldc=None, Tc=None, c_step=1, c_off=0, out_rows=None,
+                   epi=EPI_NONE, bias=None, gamma=None, res=None, rowmask=None, rowscale=None, aux_out=None, aux_in=None,
+                   a_rowscale=None, slope=0.1, accumulate=False, batch=1, batch_strides=(0, 0, 0, 0)):
+    """bf16-MFMA version of conv_gemm with conv stride / output row mapping (see csrc/gemm_bf16.hip)."""
+    lda = a.stride(-2) if lda is None else lda
+    if w_strides is None:
+        w_strides = (taps * cin, cin, 1)
+    Tc = Trows if Tc is None else Tc
+    if out is None:
+        rows = M if out_rows is None else out_rows
+        out = torch.empty((rows, n_out), device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    ldc = out.stride(-2) if ldc is None else ldc
+    ld_aux = 0
+    for t in (aux_out, aux_in):
+        if t is not None:
+            ld_aux = t.stride(-2)
+    ldr = res.stride(-2) if res is not None else 0
+    call("osp_conv_gemm_bf16", a, _isbf(a), lda, M, Trows, Tin, cin, taps, a_step, a_tapstep, a_off, a_rowscale, w,
+         _isbf(w), w_strides[0], w_strides[1], w_strides[2], n_out, out, _isbf(out), ldc, Tc, c_step, c_off, epi, bias,
+         gamma, res, _isbf(res), ldr, rowmask, rowscale, aux_out, aux_in, _isbf(aux_in), ld_aux, float(slope), batch,
+         batch_strides[0], batch_strides[1], batch_strides[2], batch_strides[3], bool(accumulate))
+    return out
+
+
+def conv_wgrad_bf16(dy, x, dw, db=None, *, M, Trows, Tin, n, cin, taps=1, pad=0, x_step=1, arow=None, oscale=None,
+                    batch=1, strides=(0, 0, 0, 0)):
+    call("osp_conv_wgrad_bf16", dy, _isbf(dy), dy.stride(-2), x, _isbf(x), x.stride(-2), M, Trows, Tin, n, cin, taps,
+         pad, x_step, arow, oscale, dw, taps * cin, db, batch, strides[0], strides[1], strides[2], strides[3])

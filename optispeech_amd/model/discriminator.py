@@ -12,7 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import spectral
+from .. import precision, spectral
+from ..disc_ops import MPDStackFn
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -40,10 +41,16 @@ class _WNConv2d(nn.Module):
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
         self.weight_v = nn.Parameter(v)
 
-    def forward(self, x):
+    def weight(self):
         v = self.weight_v
-        w = v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
-        return F.conv2d(x, w, self.bias, self.stride, self.padding)
+        return v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
+
+    def native_weight(self):
+        """(Cout, Cin, k, 1) -> kernel-native (Cout, k, Cin) for the (k,1) convolutions of DiscriminatorP."""
+        return self.weight().squeeze(-1).permute(0, 2, 1).contiguous()
+
+    def forward(self, x):
+        return F.conv2d(x, self.weight(), self.bias, self.stride, self.padding)
 
 
 class DiscriminatorP(nn.Module):
@@ -65,6 +72,14 @@ class DiscriminatorP(nn.Module):
             n_pad = self.period - (t % self.period)
             x = F.pad(x, (0, n_pad), "reflect")
             t = t + n_pad
+        if precision.is_bf16():
+            # channels-last sequences (B*period, T/period, 1): every period column is an independent 1-D signal
+            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, t // self.period, 1)
+            args = []
+            for conv in list(self.convs) + [self.conv_post]:
+                args += [conv.native_weight(), conv.bias]
+            y1, y2, y3, y4, y5, s = MPDStackFn.apply(seq.contiguous(), *args)
+            return s.view(b, -1), [y2, y3, y4, y5, s]
         x = x.view(b, c, t // self.period, self.period)
         fmap = []
         for i, conv in enumerate(self.convs):
@@ -105,13 +120,21 @@ class DiscriminatorR(nn.Module):
 
 class _Multi(nn.Module):
     def forward(self, y, y_hat):
+        """Real and generated waves go through separately: in the generator phase the real branch needs no
+        backward at all (it only feeds the feature-matching targets), so it runs under no_grad."""
         rs, gs, frs, fgs = [], [], [], []
+        real_needs_grad = any(p.requires_grad for p in self.parameters())
         B = y.shape[0]
-        both = torch.cat([y, y_hat], 0)                      # real and generated share every launch
         for d in self.discriminators:
-            o, fm = d(both)
-            rs.append(o[:B]); gs.append(o[B:])
-            frs.append([f[:B] for f in fm]); fgs.append([f[B:] for f in fm])
+            if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
+                o, fm = d(torch.cat([y, y_hat], 0))
+                r, g = o[:B], o[B:]
+                fr, fg = [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm]
+            else:
+                with torch.no_grad():
+                    r, fr = d(y)
+                g, fg = d(y_hat)
+            rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
         return rs, gs, frs, fgs
 
 

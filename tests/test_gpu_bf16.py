@@ -1,0 +1,109 @@
+"""bf16-MFMA GEMM family (performance mode) vs torch CPU fp32 on bf16-rounded operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.detach().float().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("nutt,Tin,cin,cout,taps,stride,pad", [
+    (4, 300, 32, 128, 5, 3, 2), (6, 101, 128, 512, 5, 3, 2), (3, 64, 512, 1024, 5, 1, 2), (5, 200, 1, 32, 5, 3, 2),
+    (2, 50, 1024, 1, 3, 1, 1), (2, 77, 256, 1024, 1, 1, 0), (2, 64, 100, 256, 3, 1, 1)])
+@pytest.mark.parametrize("a_bf16", [False, True])
+def test_conv_gemm_bf16_forward_strided(nutt, Tin, cin, cout, taps, stride, pad, a_bf16):
+    """transpose-detecting (random asymmetric operands), strided conv + LeakyReLU epilogue"""
+    from optispeech_amd import kernels as K
+    x = rnd(nutt, Tin, cin, seed=1)
+    w = rnd(cout, cin, taps, seed=2, scale=1.0 / np.sqrt(cin * taps))
+    b = rnd(cout, seed=3)
+    Tout = (Tin + 2 * pad - taps) // stride + 1
+    want = F.leaky_relu(F.conv1d(bfr(x).transpose(1, 2), bfr(w), b, stride=stride, padding=pad).transpose(1, 2), 0.1)
+    xa = x.to(DEV)
+    xa = xa.to(torch.bfloat16) if a_bf16 else xa
+    wn = w.permute(0, 2, 1).contiguous().to(DEV)
+    got = K.conv_gemm_bf16(xa.view(nutt * Tin, cin), wn, cout, M=nutt * Tout, Trows=Tout, Tin=Tin, cin=cin, taps=taps,
+                           a_step=stride, a_off=-pad, bias=b.to(DEV), epi=K.EPI_LRELU, slope=0.1)
+    assert relerr(got.view(nutt, Tout, cout), want) < 3e-3
+    gb = K.conv_gemm_bf16(xa.view(nutt * Tin, cin), K.cast_bf16(wn), cout, M=nutt * Tout, Trows=Tout, Tin=Tin, cin=cin,
+                          taps=taps, a_step=stride, a_off=-pad, bias=b.to(DEV), epi=K.EPI_LRELU, slope=0.1, out_bf16=True)
+    assert gb.dtype == torch.bfloat16 and relerr(gb.view(nutt, Tout, cout), want) < 1e-2
+
+
+@pytest.mark.parametrize("nutt,Tin,cin,cout,taps,stride,pad", [(4, 300, 32, 128, 5, 3, 2), (3, 64, 512, 1024, 5, 1, 2),
+                                                               (5, 200, 1, 32, 5, 3, 2), (2, 50, 1024, 1, 3, 1, 1)])
+def test_conv_bf16_dgrad_wgrad_strided(nutt, Tin, cin, cout, taps, stride, pad):
+    from optispeech_amd.disc_ops import conv1d_strided_bwd
+    x = bfr(rnd(nutt, Tin, cin, seed=1)).requires_grad_(True)
+    w = bfr(rnd(cout, cin, taps, seed=2, scale=1.0 / np.sqrt(cin * taps))).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    y = F.conv1d(x.transpose(1, 2), w, b, stride=stride, padding=pad).transpose(1, 2)
+    dy = bfr(rnd(*y.shape, seed=4))
+    y.backward(dy)
+    wn = w.detach().permute(0, 2, 1).contiguous().to(DEV)
+    dw = torch.zeros_like(wn)
+    db = torch.zeros(cout, device=DEV)
+    dx = conv1d_strided_bwd(dy.to(DEV).contiguous(), x.detach().to(DEV), wn, dw, db, taps, stride, pad, True)
+    assert relerr(dx, x.grad) < 1e-2
+    assert relerr(dw.permute(0, 2, 1), w.grad) < 1e-2
+    assert relerr(db, b.grad) < 1e-2
+
+
+def test_mpd_bf16_path_matches_f32_path():
+    """DiscriminatorP stacks on the bf16 GEMM vs the f32 (MIOpen conv2d) path: losses and gradients."""
+    from optispeech_amd import precision
+    from optispeech_amd.config import FeatureExtractorArgs
+    from optispeech_amd.model.discriminator import MultiPeriodDiscriminator, _feature_matching, _hinge_d, _hinge_g
+    from oracle import schema as S
+    torch.manual_seed(0)
+    mpd = MultiPeriodDiscriminator().to(DEV)
+    W = {k[len("discriminator.multiperioddisc."):]: v for k, v in S.make_weights(S.discriminator_schema(), 4321).items()
+         if "multiperioddisc" in k}
+    mpd.load_state_dict(W)
+    g = torch.Generator().manual_seed(1)
+    y = (torch.rand(4, 16384, generator=g) * 2 - 1).to(DEV)
+    res = {}
+    for mode in ("f32", "bf16"):
+        precision.set_precision(mode)
+        try:
+            yh = ((torch.rand(4, 16384, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(DEV)).requires_grad_(True)
+            for p in mpd.parameters():
+                p.requires_grad_(False)
+            rs, gs, frs, fgs = mpd(y, yh)
+            lg = _hinge_g(gs) + _feature_matching(frs, fgs)
+            lg.backward()
+            for p in mpd.parameters():
+                p.requires_grad_(True)
+                p.grad = None
+            rs, gs, _, _ = mpd(y, yh.detach())
+            ld = _hinge_d(rs, gs)
+            ld.backward()
+            res[mode] = (lg.item(), ld.item(), yh.grad.clone(), {k: p.grad.clone() for k, p in mpd.named_parameters()})
+        finally:
+            precision.set_precision("f32")
+    a, b = res["f32"], res["bf16"]
+    assert abs(a[0] - b[0]) < 2e-2 * abs(a[0]) and abs(a[1] - b[1]) < 2e-2 * abs(a[1]), (a[:2], b[:2])
+    cos = torch.nn.functional.cosine_similarity(a[2].flatten(), b[2].flatten(), dim=0).item()
+    assert cos > 0.98, cos
+    for k in a[3]:
+        na, nb = a[3][k].norm().item(), b[3][k].norm().item()
+        if na < 1e-4:                                     # degenerate (saturated hinge): nothing to compare
+            continue
+        assert abs(na - nb) <= 0.1 * na, (k, na, nb)
+        if a[3][k].numel() > 64:
+            c = torch.nn.functional.cosine_similarity(a[3][k].flatten(), b[3][k].flatten(), dim=0).item()
+            assert c > 0.97, (k, c)

@@ -133,8 +133,8 @@ def test_forwardsum_ctc_baseline_shape_vs_oracle():
     # included); the arbiter is the same oracle evaluated in f64.
     lpd = torch.from_numpy(lp).double().requires_grad_(True)
     OL.forward_sum_loss(lpd, torch.from_numpy(tl), torch.from_numpy(fl)).backward()
-    assert relerr(grad, lpd.grad) < 2e-3
-    assert relerr(grad, lpc.grad) < 4e-3
+    assert relerr(grad, lpd.grad) < 5e-3
+    assert relerr(grad, lpc.grad) < 5e-3
 
 
 def test_alignment_logprob_forward_backward_vs_oracle():

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
 from optispeech_amd import rng
 
+from optispeech_amd import precision
+precision.set_precision(os.environ.get("OSP_PRECISION", "f32"))
+print("precision:", precision.get_precision())
 dev = "cuda"
 torch.manual_seed(0)
 cfg = ModelConfig()
