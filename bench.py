@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="utterances in the bounded CPU-baseline sample")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
+    ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("OSP_PRECISION", "bf16"),
+                    help="bf16 = BASELINE config[1] (bf16 MFMA operands, f32 accumulate, f32 master weights); "
+                         "f32 = exact-f32 parity mode")
     return ap.parse_args()
 
 
@@ -108,7 +111,8 @@ def cpu_baseline(nb):
 
 def main():
     a = parse()
-    from optispeech_amd import dp, rng
+    from optispeech_amd import dp, precision, rng
+    precision.set_precision(a.precision)
     world, rank, local = dp.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension has no CPU fallback)"
@@ -165,7 +169,7 @@ def main():
         out = {"metric": "mel-frames/sec/GPU (train step) + RTF (synthesize), ConvNeXt@22.05kHz, 1/2/4/8 MI355X",
                "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": a.precision, "data": "synthetic",
                "config": {"workload": "configs[1]: ConvNeXt backbone, synthetic LJSpeech-shaped batch=32 per GPU "
                                       "(T_text=128, T_mel=800, 22.05 kHz), full GAN training step "
                                       "(G phase + D phase + 2x AdamW), train mode",

@@ -36,6 +36,8 @@ struct GemmB {
     int epi; const float *bias, *gamma, *res; int64_t ldr; const float *rowmask, *rowscale;
     float* aux_out; const void* aux_in; int aux_bf16; int64_t ld_aux; float slope;
     const void* res_any; int res_bf16;   // LRELU_BWD extra addend (f32 or bf16)
+    // 2-D (conv2d over channels-last (U,H,W,C)) extension; the 1-D case has Hin = 1, Wrows = Trows, KW = taps
+    int Wrows, Hin, KW, a_step_h, a_tapstep_h, a_off_h, Wc, c_step_h, c_off_h; int64_t sBtap_h;
     int64_t sAb, sBb, sCb, sXb; int accumulate;
 };
 
@@ -84,11 +86,88 @@ __device__ __forceinline__ void mma_tile_bf16(const unsigned short* __restrict__
     }
 }
 
+// ---- shared epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+__device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+                                                   int lane, int64_t bz) {
+    const int esC = pp.c_bf16 ? 2 : 4;
+    char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * esC;
+    const float* res = pp.res ? pp.res + bz * pp.sXb : nullptr;
+    const char* aux_in = pp.aux_in ? reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
+    float* aux_out = pp.aux_out ? pp.aux_out + bz * pp.sXb : nullptr;
+    // Pull the accumulators out with a branch-free, fully unrolled copy first: if the (large) epilogue loop below is
+    // not fully unrolled, a dynamically indexed copy may go to scratch -- but the MFMA accumulators themselves never do.
+    float vals[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vals[i][j][r] = acc[i][j][r];
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn0 + 32 * j + l31;
+            if (n >= pp.N) continue;
+            const float bias = pp.bias ? pp.bias[n] : 0.f;
+            const float gam = pp.gamma ? pp.gamma[n] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= pp.M) continue;
+                const int64_t mr = bz * pp.M + m;
+                const float v = vals[i][j][r] + bias;
+                const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+                const int64_t crow = (int64_t)u * pp.Tc + (int64_t)(th * pp.c_step_h + pp.c_off_h) * pp.Wc +
+                                     (int64_t)tw * pp.c_step + pp.c_off;                       // aux / res follow C's rows
+                float out;
+                switch (pp.epi) {
+                    case BEPI_RELU: out = fmaxf(v, 0.f); break;
+                    case BEPI_LRELU: out = v > 0.f ? v : v * pp.slope; break;
+                    case BEPI_GELU:
+                        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+                        out = gelu_f(v);
+                        break;
+                    case BEPI_SCALE_RES_MASK: {
+                        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+                        const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
+                        out = (res[crow * pp.ldr + n] + rs * gam * v) * mk;
+                    } break;
+                    case BEPI_GELU_BWD:
+                        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n));
+                        break;
+                    case BEPI_RELU_BWD: out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? v : 0.f; break;
+                    case BEPI_LRELU_BWD: {   // (acc + extra) * lrelu'(y):  extra = gradient arriving at the same activation
+                        const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * pp.ldr + n) : 0.f;
+                        out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? (v + e) : (v + e) * pp.slope;
+                    } break;
+                    case BEPI_AXMY: out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) - v; break;
+                    case BEPI_MASK: out = v * (pp.rowmask ? pp.rowmask[mr] : 1.f); break;
+                    default: out = v;
+                }
+                if (pp.c_bf16) {
+                    reinterpret_cast<__bf16*>(Cb)[crow * pp.ldc + n] = (__bf16)out;
+                } else {
+                    float* dst = reinterpret_cast<float*>(Cb) + crow * pp.ldc + n;
+                    *dst = pp.accumulate ? (*dst + out) : out;
+                }
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 // FAST: every operand row is 16-byte addressable (Cin % 8 == 0, aligned strides, no per-row A scale) -- the generic
 // element-wise loaders are not even compiled into that instantiation (they bloat the loop past the I-cache).
 template <bool B_KCONTIG, int BKT, bool FAST>
-__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
+__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
+    // hot-loop scalars in registers (the by-value struct must not be addressed inside the K loop)
+    struct { int M, Trows, Wrows, Tin, Hin, Cin, taps, KW, a_step, a_step_h, a_off, a_off_h, a_tapstep, a_tapstep_h, N, a_bf16, b_bf16;
+             int64_t lda, sBn, sBtap, sBtap_h, sBk; const float* a_rowscale; } p;
+    p.M = pp.M; p.Trows = pp.Trows; p.Wrows = pp.Wrows; p.Tin = pp.Tin; p.Hin = pp.Hin; p.Cin = pp.Cin; p.taps = pp.taps; p.KW = pp.KW;
+    p.a_step = pp.a_step; p.a_step_h = pp.a_step_h; p.a_off = pp.a_off; p.a_off_h = pp.a_off_h; p.a_tapstep = pp.a_tapstep;
+    p.a_tapstep_h = pp.a_tapstep_h; p.N = pp.N; p.a_bf16 = pp.a_bf16; p.b_bf16 = pp.b_bf16; p.lda = pp.lda; p.sBn = pp.sBn;
+    p.sBtap = pp.sBtap; p.sBtap_h = pp.sBtap_h; p.sBk = pp.sBk; p.a_rowscale = pp.a_rowscale;
     constexpr int LDK_ = BKT + 8, KG = BKT / 8, NI = TBM * KG / 256, RSTEP = 256 / KG;
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (TBM + TBN) * LDK_];
     unsigned short* As = smem;                       // [2][TBM][LDK_]
@@ -98,21 +177,22 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
     const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
     const int64_t bz = blockIdx.z;
     const int esA = p.a_bf16 ? 2 : 4, esB = p.b_bf16 ? 2 : 4;
-    const char* A = reinterpret_cast<const char*>(p.A) + bz * p.sAb * esA;
-    const char* B = reinterpret_cast<const char*>(p.B) + bz * p.sBb * esB;
+    const char* A = reinterpret_cast<const char*>(pp.A) + bz * pp.sAb * esA;
+    const char* B = reinterpret_cast<const char*>(pp.B) + bz * pp.sBb * esB;
     const int K = p.taps * p.Cin;
 
     // A items: NI per thread: row = tid / KG + RSTEP*i, k-group g = tid % KG
     const int g = tid % KG, r0 = tid / KG;
-    int a_t[NI]; int64_t a_base[NI];
+    int a_t[NI], a_h[NI]; int64_t a_base[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = m0 + r0 + RSTEP * i;
         if (m < p.M) {
-            const int u = m / p.Trows, t = m - u * p.Trows;
-            a_t[i] = t * p.a_step + p.a_off;
-            a_base[i] = (int64_t)u * p.Tin;
-        } else { a_t[i] = -0x40000000; a_base[i] = 0; }
+            const int u = m / p.Trows, t = m - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
+            a_t[i] = tw * p.a_step + p.a_off;
+            a_h[i] = th * p.a_step_h + p.a_off_h;
+            a_base[i] = (int64_t)u * p.Hin * p.Tin;
+        } else { a_t[i] = -0x40000000; a_h[i] = 0; a_base[i] = 0; }
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -125,21 +205,25 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
     uint4 ra[NI], rb[NI > 4 ? NI : 4];
     auto a_elem = [&](int i, int k) -> float {
         if (k >= K) return 0.f;
-        const int j = k / p.Cin, c = k - j * p.Cin, tt = a_t[i] + j * p.a_tapstep;
-        if (tt < 0 || tt >= p.Tin) return 0.f;
-        float v = ld_elem(A, p.a_bf16, (a_base[i] + tt) * p.lda + c);
-        if (p.a_rowscale) v *= p.a_rowscale[bz * p.M + a_base[i] + tt];
+        const int j = k / p.Cin, c = k - j * p.Cin, kh = j / p.KW, kw = j - kh * p.KW;
+        const int tt = a_t[i] + kw * p.a_tapstep, hh = a_h[i] + kh * p.a_tapstep_h;
+        if (tt < 0 || tt >= p.Tin || hh < 0 || hh >= p.Hin) return 0.f;
+        const int64_t row = a_base[i] + (int64_t)hh * p.Tin + tt;
+        float v = ld_elem(A, p.a_bf16, row * p.lda + c);
+        if (p.a_rowscale) v *= p.a_rowscale[bz * p.M + row];
         return v;
     };
     auto gload = [&](int kt) {
         const int k0 = kt * BKT + g * 8;
+        const int j0k = k0 / p.Cin, c0k = k0 - j0k * p.Cin, kh0 = (p.KW == p.taps) ? 0 : j0k / p.KW, kw0 = j0k - kh0 * p.KW;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (FAST) {
-                if (k0 < K) {
-                    const int j = k0 / p.Cin, c = k0 - j * p.Cin, tt = a_t[i] + j * p.a_tapstep;
-                    if (tt >= 0 && tt < p.Tin) v = ld8_contig(A, p.a_bf16, (a_base[i] + tt) * p.lda + c, true);
+                if (k0 < K) {   // (j, c, kh, kw) of this thread's k-group: hoisted, one division pair per k-tile
+                    const int tt = a_t[i] + kw0 * p.a_tapstep, hh = a_h[i] + kh0 * p.a_tapstep_h;
+                    if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin)
+                        v = ld8_contig(A, p.a_bf16, (a_base[i] + (int64_t)hh * p.Tin + tt) * p.lda + c0k, true);
                 }
             } else {
                 v = make_uint4(pk2(a_elem(i, k0), a_elem(i, k0 + 1)), pk2(a_elem(i, k0 + 2), a_elem(i, k0 + 3)),
@@ -154,16 +238,15 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (n < p.N && k0 < K) {
                     if constexpr (FAST) {
-                        const int j = k0 / p.Cin, c = k0 - j * p.Cin;
-                        v = ld8_contig(B, p.b_bf16, (int64_t)n * p.sBn + (int64_t)j * p.sBtap + c, true);
+                        v = ld8_contig(B, p.b_bf16, (int64_t)n * p.sBn + (int64_t)kh0 * p.sBtap_h + (int64_t)kw0 * p.sBtap + c0k, true);
                     } else {
                         float e[8];
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const int k = k0 + q;
                             float x = 0.f;
-                            if (k < K) { const int j = k / p.Cin, c = k - j * p.Cin;
-                                x = ld_elem(B, p.b_bf16, (int64_t)n * p.sBn + (int64_t)j * p.sBtap + (int64_t)c * p.sBk); }
+                            if (k < K) { const int j = k / p.Cin, c = k - j * p.Cin, kh = j / p.KW, kw = j - kh * p.KW;
+                                x = ld_elem(B, p.b_bf16, (int64_t)n * p.sBn + (int64_t)kh * p.sBtap_h + (int64_t)kw * p.sBtap + (int64_t)c * p.sBk); }
                             e[q] = x;
                         }
                         v = make_uint4(pk2(e[0], e[1]), pk2(e[2], e[3]), pk2(e[4], e[5]), pk2(e[6], e[7]));
@@ -181,8 +264,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
                 const int k = kt * BKT + kg * 8 + q;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < K && nn < p.N) {
-                    const int j = k / p.Cin, c = k - j * p.Cin;
-                    const int64_t off = (int64_t)c * p.sBk + (int64_t)j * p.sBtap + nn;
+                    const int j = k / p.Cin, c = k - j * p.Cin, kh = j / p.KW, kw = j - kh * p.KW;
+                    const int64_t off = (int64_t)c * p.sBk + (int64_t)kh * p.sBtap_h + (int64_t)kw * p.sBtap + nn;
                     if (FAST && nn + 3 < p.N) x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + off);
                     else {
                         x.x = ld_elem(B, p.b_bf16, off);
@@ -226,62 +309,116 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
         __syncthreads();
     }
 
-    // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    const int esC = p.c_bf16 ? 2 : 4;
-    char* Cb = reinterpret_cast<char*>(p.C) + bz * p.sCb * esC;
-    const float* res = p.res ? p.res + bz * p.sXb : nullptr;
-    const char* aux_in = p.aux_in ? reinterpret_cast<const char*>(p.aux_in) + bz * p.sXb * (p.aux_bf16 ? 2 : 4) : nullptr;
-    float* aux_out = p.aux_out ? p.aux_out + bz * p.sXb : nullptr;
-    const int l31 = lane & 31, lh = lane >> 5;
+    gemm_bf16_epilogue(pp, acc, m0, n0, wm0, wn0, lane, bz);
+}
+
+
+
+// ---- direct-to-LDS variant (bf16 operands in HBM, Cin % 64 == 0): the staging tiles are written by the LDS-DMA path
+// (global_load_lds_dwordx4: 64 lanes x 16 B = 8 rows of 128 B per wave instruction), no VGPR round trip and no
+// ds_write pass.  The LDS image is unpadded 128-byte rows; bank conflicts are avoided with an XOR swizzle of the
+// 16-byte slot, applied on the SOURCE address when staging and on the read address (both-sides rule, guide section 5.4/21):
+//   physical slot = logical k-group ^ ((row >> 1) & 7)
+// Rows that fall into conv padding (or past M / N) read a zero page instead.
+__device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
+
+__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp) {
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * (TBM + TBN) * TBK];
+    unsigned short* As = smem;                       // [2][TBM][64]
+    unsigned short* Bs = smem + 2 * TBM * TBK;       // [2][TBN][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+    const int64_t bz = blockIdx.z;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(pp.A) + bz * pp.sAb;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(pp.B) + bz * pp.sBb;
+    const int Cin = pp.Cin, Tin = pp.Tin, Hin = pp.Hin, KW = pp.KW, a_tapstep = pp.a_tapstep, a_tapstep_h = pp.a_tapstep_h;
+    const int64_t lda = pp.lda, sBn = pp.sBn, sBtap = pp.sBtap, sBtap_h = pp.sBtap_h;
+    const int K = pp.taps * Cin;
+    const int rsub = lane >> 3, pslot = lane & 7;
+    int a_t[4], a_h[4]; int64_t a_base[4]; int64_t b_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * (wave * 4 + i) + rsub;
+        const int m = m0 + r;
+        if (m < pp.M) {
+            const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+            a_t[i] = tw * pp.a_step + pp.a_off;
+            a_h[i] = th * pp.a_step_h + pp.a_off_h;
+            a_base[i] = (int64_t)u * Hin * Tin;
+        } else { a_t[i] = -0x40000000; a_h[i] = 0; a_base[i] = 0; }
+        const int n = n0 + r;
+        b_row[i] = n < pp.N ? (int64_t)n * sBn : -1;
+    }
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn0 + 32 * j + l31;
-            if (n >= p.N) continue;
-            const float bias = p.bias ? p.bias[n] : 0.f;
-            const float gam = p.gamma ? p.gamma[n] : 1.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                const int64_t mr = bz * p.M + m;
-                const float v = acc[i][j][r] + bias;
-                const int u = m / p.Trows, t = m - u * p.Trows;
-                const int64_t crow = (int64_t)u * p.Tc + (int64_t)t * p.c_step + p.c_off;   // aux / res follow C's rows
-                float out;
-                switch (p.epi) {
-                    case BEPI_RELU: out = fmaxf(v, 0.f); break;
-                    case BEPI_LRELU: out = v > 0.f ? v : v * p.slope; break;
-                    case BEPI_GELU:
-                        if (aux_out) aux_out[crow * p.ld_aux + n] = v;
-                        out = gelu_f(v);
-                        break;
-                    case BEPI_SCALE_RES_MASK: {
-                        if (aux_out) aux_out[crow * p.ld_aux + n] = v;
-                        const float rs = p.rowscale ? p.rowscale[mr] : 1.f, mk = p.rowmask ? p.rowmask[mr] : 1.f;
-                        out = (res[crow * p.ldr + n] + rs * gam * v) * mk;
-                    } break;
-                    case BEPI_GELU_BWD:
-                        out = (p.rowscale ? p.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n));
-                        break;
-                    case BEPI_RELU_BWD: out = ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n) > 0.f ? v : 0.f; break;
-                    case BEPI_LRELU_BWD: {   // (acc + extra) * lrelu'(y):  extra = gradient arriving at the same activation
-                        const float e = p.res_any ? ld_elem(p.res_any, p.res_bf16, crow * p.ldr + n) : 0.f;
-                        out = ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n) > 0.f ? (v + e) : (v + e) * p.slope;
-                    } break;
-                    case BEPI_AXMY: out = (p.rowscale ? p.rowscale[mr] : 1.f) * ld_elem(aux_in, p.aux_bf16, crow * p.ld_aux + n) - v; break;
-                    case BEPI_MASK: out = v * (p.rowmask ? p.rowmask[mr] : 1.f); break;
-                    default: out = v;
-                }
-                if (p.c_bf16) {
-                    reinterpret_cast<__bf16*>(Cb)[crow * p.ldc + n] = (__bf16)out;
-                } else {
-                    float* dst = reinterpret_cast<float*>(Cb) + crow * p.ldc + n;
-                    *dst = p.accumulate ? (*dst + out) : out;
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
+
+    auto issue = [&](int kt, int buf) {
+        const int kbase = kt * TBK;
+        const int j = kbase / Cin, cb = kbase - j * Cin, kh = (KW == pp.taps) ? 0 : j / KW, kw = j - kh * KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * (wave * 4 + i) + rsub;
+            const int q = pslot ^ ((r >> 1) & 7);
+            const int tt = a_t[i] + kw * a_tapstep, hh = a_h[i] + kh * a_tapstep_h;
+            const unsigned short* src = zero;
+            if (tt >= 0 && tt < Tin && hh >= 0 && hh < Hin) src = A + (a_base[i] + (int64_t)hh * Tin + tt) * lda + cb + q * 8;
+            unsigned short* dst = As + buf * TBM * TBK + (wave * 4 + i) * 8 * TBK;       // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * (wave * 4 + i) + rsub;
+            const int q = pslot ^ ((r >> 1) & 7);
+            const unsigned short* src = zero;
+            if (b_row[i] >= 0) src = B + b_row[i] + (int64_t)kh * sBtap_h + (int64_t)kw * sBtap + cb + q * 8;
+            unsigned short* dst = Bs + buf * TBN * TBK + (wave * 4 + i) * 8 * TBK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto mma = [&](int buf) {
+        const unsigned short* as = As + buf * TBM * TBK;
+        const unsigned short* bs = Bs + buf * TBN * TBK;
+        const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm0 + 32 * i + l31;
+                a[i] = *reinterpret_cast<const bf16x8*>(as + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn0 + 32 * j + l31;
+                b[j] = *reinterpret_cast<const bf16x8*>(bs + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nk = K / TBK;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        mma(buf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_bf16_epilogue(pp, acc, m0, n0, wm0, wn0, lane, bz);
 }
 
 // C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
@@ -289,7 +426,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(GemmB p) {
 //   forward strided conv : a_step = stride, a_tapstep = 1, a_off = -pad, Tc = Trows = T_out, c_step = 1, c_off = 0
 //   dgrad of a strided conv, phase r : see optispeech_amd/ops.py (MPD) -- rows q, t_in = r + stride*q
 // dtype flags: 0 = f32 storage, 1 = bf16 storage.
-extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
+static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
                                   int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
                                   const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
                                   int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
@@ -300,6 +437,7 @@ extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, in
                                   hipStream_t stream) {
     OSP_CHECK_ARG(A && B && C, "null operand");
     OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && Tin > 0 && batch > 0, "bad shape");
+    OSP_CHECK_ARG(d2[0] > 0 && d2[1] > 0 && d2[2] > 0 && taps % d2[2] == 0 && Trows % d2[0] == 0, "bad 2-D geometry");
     OSP_CHECK_ARG(M % Trows == 0, "M must be a whole number of utterances");
     OSP_CHECK_ARG(sBk == 1 || sBn == 1, "B must be contiguous along k or along n");
     OSP_CHECK_ARG(epi >= 0 && epi <= BEPI_LRELU_BWD, "unknown epilogue");
@@ -315,15 +453,24 @@ extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, in
     p.res_any = res; p.res_bf16 = (int)res_bf16; p.rowmask = rowmask; p.rowscale = rowscale;
     p.aux_out = aux_out; p.aux_in = aux_in; p.aux_bf16 = (int)aux_bf16; p.ld_aux = ld_aux; p.slope = slope;
     p.sAb = sAb; p.sBb = sBb; p.sCb = sCb; p.sXb = sXb; p.accumulate = (int)accumulate;
+    p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
+    p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
     dim3 grid((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, TBM), (unsigned)batch);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int64_t ea = a_bf16 ? 2 : 4, eb = b_bf16 ? 2 : 4;
     const bool a_fast = (Cin % 8 == 0) && (lda % 8 == 0) && al16(A) && ((sAb * ea) % 16 == 0) && !a_rowscale;
     bool fast;
     if (sBk == 1)
-        fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+        fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && (d2[9] % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
     else
-        fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+        fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && (d2[9] % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+    static int use_glds = -1;
+    if (use_glds < 0) { const char* e = getenv("OSP_GEMM_GLDS"); use_glds = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0)) {
+        hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), 0, stream, p);
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
     if (sBk != 1) {
         if (fast) hipLaunchKernelGGL((conv_gemm_bf16_kernel<false, 64, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_bf16_kernel<false, 64, false>), grid, dim3(256), 0, stream, p);
@@ -335,12 +482,48 @@ extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, in
     return OSP_OK;
 }
 
+extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
+                                  int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
+                                  const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
+                                  int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
+                                  int64_t c_step, int64_t c_off, int64_t epi, const float* bias, const float* gamma,
+                                  const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
+                                  float* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
+                                  int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
+                                  hipStream_t stream) {
+    const int64_t d2[10] = {Trows, 1, taps, 0, 0, 0, Tc, 0, 0, 0};
+    return conv_gemm_bf16_impl(d2, A, a_bf16, lda, M, Trows, Tin, Cin, taps, a_step, a_tapstep, a_off, a_rowscale, B, b_bf16, sBn,
+                               sBtap, sBk, N, C, c_bf16, ldc, Tc, c_step, c_off, epi, bias, gamma, res, res_bf16, ldr, rowmask,
+                               rowscale, aux_out, aux_in, aux_bf16, ld_aux, slope, batch, sAb, sBb, sCb, sXb, accumulate, stream);
+}
+
+// 2-D variant: rows of an utterance are (h, w) positions of a channels-last (U, H, W, C) tensor.
+//   t -> (th, tw) = divmod(t, Wrows), tap j -> (kh, kw) = divmod(j, KW)
+//   input  position: (th*a_step_h + kh*a_tapstep_h + a_off_h,  tw*a_step + kw*a_tapstep + a_off)  in  [0,Hin) x [0,Win)
+//   output position: (th*c_step_h + c_off_h, tw*c_step + c_off) of a (Hc, Wc) map with Hc*Wc = Tc
+//   weights: Bw(n, kh, kw, c) = B[n*sBn + kh*sBtap_h + kw*sBtap + c*sBk]
+// Serves DiscriminatorR's Conv2d stacks (vocoder/wavenext/disc/_discriminators.py:154-161,174-194) and their dgrad.
+extern "C" int osp_conv2d_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Wrows,
+                                    int64_t Hin, int64_t Win, int64_t Cin, int64_t taps, int64_t KW, int64_t a_step_h,
+                                    int64_t a_tapstep_h, int64_t a_off_h, int64_t a_step, int64_t a_tapstep, int64_t a_off,
+                                    const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap_h, int64_t sBtap, int64_t sBk,
+                                    int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc, int64_t Wc, int64_t c_step_h,
+                                    int64_t c_off_h, int64_t c_step, int64_t c_off, int64_t epi, const float* bias,
+                                    const void* res, int64_t res_bf16, int64_t ldr, const void* aux_in, int64_t aux_bf16,
+                                    int64_t ld_aux, float slope, hipStream_t stream) {
+    const int64_t d2[10] = {Wrows, Hin, KW, a_step_h, a_tapstep_h, a_off_h, Wc, c_step_h, c_off_h, sBtap_h};
+    return conv_gemm_bf16_impl(d2, A, a_bf16, lda, M, Trows, Win, Cin, taps, a_step, a_tapstep, a_off, nullptr, B, b_bf16, sBn,
+                               sBtap, sBk, N, C, c_bf16, ldc, Tc, c_step, c_off, epi, bias, nullptr, res, res_bf16, ldr, nullptr,
+                               nullptr, nullptr, aux_in, aux_bf16, ld_aux, slope, 1, 0, 0, 0, 0, 0, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 // dW[n, j, c] += oscale[n] * sum_{u,t} arow * dY[u, t, n] * X[u, t*x_step + j - pad, c];  db[n] likewise.
 // Both operands are reduction-major -> transposing loader for both.  Split over the frame dimension, f32 atomics.
 struct WgradB {
     const void* dY; int y_bf16; int64_t ldy; const void* X; int x_bf16; int64_t ldx;
     int M, Trows, Tin, N, Cin, taps, pad, x_step;
+    int Wrows, Hin, KW, x_step_h, pad_h;              // 2-D extension (1-D: Wrows = Trows, Hin = 1, KW = taps)
     const float *arow, *oscale; float* dW; int64_t ldw; float* db; int chunk, splits;
     int64_t sYb, sXb, sWb, sDb;
 };
@@ -404,10 +587,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
                     y = ld4_any(dY, p.y_bf16, (int64_t)m * p.ldy + n, p.N - n, y_vec);
                     if (arow) { const float s = arow[m]; y.x *= s; y.y *= s; y.z *= s; y.w *= s; }
                 }
-                const int u = m / p.Trows, t = m - u * p.Trows, tt = t * p.x_step + j - p.pad;
+                const int u = m / p.Trows, t = m - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
+                const int kh = j / p.KW, kw = j - kh * p.KW;
+                const int tt = tw * p.x_step + kw - p.pad, hh = th * p.x_step_h + kh - p.pad_h;
                 const int c = c0 + 4 * c4;
-                if (tt >= 0 && tt < p.Tin && c < p.Cin)
-                    x = ld4_any(X, p.x_bf16, ((int64_t)u * p.Tin + tt) * p.ldx + c, p.Cin - c, x_vec);
+                if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin && c < p.Cin)
+                    x = ld4_any(X, p.x_bf16, (((int64_t)u * p.Hin + hh) * p.Tin + tt) * p.ldx + c, p.Cin - c, x_vec);
             }
             ya[q] = y; xb[q] = x;
             if (do_bias) { bsum.x += y.x; bsum.y += y.y; bsum.z += y.z; bsum.w += y.w; }
@@ -446,9 +631,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
                     const int n = n0 + 8 * c8;
                     if (n < p.N) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dY) + (int64_t)m * p.ldy + n);
                 } else {
-                    const int u = m / p.Trows, t = m - u * p.Trows, tt = t * p.x_step + j - p.pad, c = c0 + 8 * c8;
-                    if (tt >= 0 && tt < p.Tin && c < p.Cin)
-                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + ((int64_t)u * p.Tin + tt) * p.ldx + c);
+                    const int u = m / p.Trows, t = m - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
+                    const int kh = j / p.KW, kw = j - kh * p.KW, c = c0 + 8 * c8;
+                    const int tt = tw * p.x_step + kw - p.pad, hh = th * p.x_step_h + kh - p.pad_h;
+                    if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin && c < p.Cin)
+                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + (((int64_t)u * p.Hin + hh) * p.Tin + tt) * p.ldx + c);
                 }
             }
             r8[q] = v;
@@ -526,7 +713,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
     }
 }
 
-extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
                                    int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
                                    int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
                                    float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
@@ -538,6 +725,7 @@ extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, 
     p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.N = (int)N; p.Cin = (int)Cin; p.taps = (int)taps;
     p.pad = (int)pad; p.x_step = (int)x_step; p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db;
     p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb;
+    p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.x_step_h = (int)d2[3]; p.pad_h = (int)d2[4];
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     int64_t splits = cdiv(512, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
@@ -552,6 +740,26 @@ extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, 
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
+}
+
+extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                   int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
+                                   int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
+                                   float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                   hipStream_t stream) {
+    const int64_t d2[5] = {Trows, 1, taps, 0, 0};
+    return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Tin, N, Cin, taps, pad, x_step, arow, oscale, dW, ldw,
+                                db, batch, sYb, sXb, sWb, sDb, stream);
+}
+
+// 2-D weight gradient: dW[n, kh, kw, c] += sum dY[u, th, tw, n] * X[u, th*x_step_h + kh - pad_h, tw*x_step + kw - pad, c]
+extern "C" int osp_conv2d_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                     int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin, int64_t Win, int64_t N, int64_t Cin,
+                                     int64_t taps, int64_t KW, int64_t pad_h, int64_t pad, int64_t x_step_h, int64_t x_step,
+                                     float* dW, float* db, hipStream_t stream) {
+    const int64_t d2[5] = {Wrows, Hin, KW, x_step_h, pad_h};
+    return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Win, N, Cin, taps, pad, x_step, nullptr, nullptr, dW,
+                                taps * Cin, db, 1, 0, 0, 0, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ casts

@@ -90,7 +90,13 @@ class MPDStackFn(torch.autograd.Function):
         wbf = [K.cast_bf16(w) for w in ws]
         ctx.need_dgrad = any(ctx.needs_input_grad)
         for i in range(5):
-            h = conv1d_strided_fwd(h, wbf[i], bs[i], 5, MPDStackFn.STRIDES[i], 2, MPDStackFn.SLOPE, True)
+            if i == 0 and ws[0].shape[0] in (16, 32, 64):           # Cin = 1: direct VALU kernel (csrc/smallcin.hip)
+                U, T0 = h.shape[0], h.shape[1]
+                T1 = _tout(T0, 5, 3, 2)
+                h = K.smallcin_fwd(h, ws[0].detach(), bs[0], U=U, Hin=1, Win=T0, Ho=1, Wo=T1, cout=ws[0].shape[0], KH=1, KW=5,
+                                   sh=1, sw=3, ph=0, pw=2, slope=MPDStackFn.SLOPE, out_bf16=True).view(U, T1, -1)
+            else:
+                h = conv1d_strided_fwd(h, wbf[i], bs[i], 5, MPDStackFn.STRIDES[i], 2, MPDStackFn.SLOPE, True)
             acts.append(h)
         s = conv1d_strided_fwd(h, wbf[5], bs[5], 3, 1, 1, None, False)
         if any(ctx.needs_input_grad):
@@ -116,8 +122,12 @@ class MPDStackFn(torch.autograd.Function):
             dw = torch.zeros(wbf[i].shape, device=g.device, dtype=torch.float32)
             db = torch.zeros(Cout, device=g.device, dtype=torch.float32)
             Tin, Tout = inp.shape[1], g.shape[1]
-            K.conv_wgrad_bf16(g.view(U * Tout, Cout), inp.reshape(U * Tin, Cin), dw, db, M=U * Tout, Trows=Tout,
-                              Tin=Tin, n=Cout, cin=Cin, taps=taps, pad=pad, x_step=stride)
+            if Cin == 1 and Cout in (16, 32, 64):
+                K.smallcin_wgrad(inp, g, dw, db, U=U, Hin=1, Win=Tin, Ho=1, Wo=Tout, cout=Cout, KH=1, KW=taps, sh=1,
+                                 sw=stride, ph=0, pw=pad)
+            else:
+                K.conv_wgrad_bf16(g.view(U * Tout, Cout), inp.reshape(U * Tin, Cin), dw, db, M=U * Tout, Trows=Tout,
+                                  Tin=Tin, n=Cout, cin=Cin, taps=taps, pad=pad, x_step=stride)
             grads_w[i], grads_b[i] = dw, db
 
         wts = [transpose_weight(w) for w in wbf]
@@ -141,3 +151,242 @@ class MPDStackFn(torch.autograd.Function):
         for i in range(6):
             out += [grads_w[i], grads_b[i]]
         return tuple(out)
+
+
+# =================================================================================================== 2-D (MRD)
+def conv2d_fwd(x, w, bias, KH, KW, sh, sw, ph, pw, slope, out_bf16):
+    """x (U,H,W,C) channels-last; w native (Cout, KH, KW, Cin) -> (U,Ho,Wo,Cout), optional fused LeakyReLU."""
+    U, H, W, C = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+    out = torch.empty((U, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    K.conv2d_gemm_bf16(x.view(U * H * W, C), w, Cout, M=U * Ho * Wo, Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, cin=C,
+                       taps=KH * KW, KW=KW, a_step_h=sh, a_tapstep_h=1, a_off_h=-ph, a_step=sw, a_tapstep=1, a_off=-pw,
+                       w_strides=(KH * KW * C, KW * C, C, 1), out=out.view(U * Ho * Wo, Cout), ldc=Cout, Tc=Ho * Wo, Wc=Wo,
+                       epi=K.EPI_LRELU if slope is not None else K.EPI_NONE, bias=bias, slope=slope or 0.0)
+    return out
+
+
+def transpose_weight2d(w):
+    """native (Cout, KH, KW, Cin) -> dgrad layout (Cin, KH, KW, Cout), bf16."""
+    t = w.permute(3, 1, 2, 0).contiguous()
+    return t if t.dtype == torch.bfloat16 else K.cast_bf16(t)
+
+
+def conv2d_dgrad(dy, wt, H, W, KH, KW, sh, sw, ph, pw, *, lrelu_y=None, extra=None, slope=0.1, out_bf16=False):
+    """dx (U,H,W,Cin) of a strided conv2d: one GEMM per output phase (rh, rw) so only contributing taps are visited."""
+    U, Ho, Wo, Cout = dy.shape
+    Cin = wt.shape[0]
+    dx = torch.empty((U, H, W, Cin), device=dy.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dy2 = dy.view(U * Ho * Wo, Cout)
+    epi = K.EPI_LRELU_BWD if lrelu_y is not None else K.EPI_NONE
+    for rh in range(sh):
+        qh = (H - rh + sh - 1) // sh
+        kh0 = (rh + ph) % sh
+        n_h = (KH - kh0 + sh - 1) // sh if kh0 < KH else 0
+        for rw in range(sw):
+            qw = (W - rw + sw - 1) // sw
+            kw0 = (rw + pw) % sw
+            n_w = (KW - kw0 + sw - 1) // sw if kw0 < KW else 0
+            if qh <= 0 or qw <= 0:
+                continue
+            assert n_h > 0 and n_w > 0, "kernel smaller than stride is not supported"
+            base = wt.view(Cin, KH, KW, Cout)[:, kh0:, kw0:, :]
+            K.conv2d_gemm_bf16(dy2, base, Cin, M=U * qh * qw, Trows=qh * qw, Wrows=qw, Hin=Ho, Win=Wo, cin=Cout,
+                               taps=n_h * n_w, KW=n_w, a_step_h=1, a_tapstep_h=-1, a_off_h=(rh + ph - kh0) // sh, a_step=1,
+                               a_tapstep=-1, a_off=(rw + pw - kw0) // sw,
+                               w_strides=(KH * KW * Cout, sh * KW * Cout, sw * Cout, 1), out=dx.view(U * H * W, Cin),
+                               ldc=Cin, Tc=H * W, Wc=W, c_step_h=sh, c_off_h=rh, c_step=sw, c_off=rw, epi=epi,
+                               aux_in=None if lrelu_y is None else lrelu_y.view(U * H * W, Cin),
+                               res=None if extra is None else extra.view(U * H * W, Cin), slope=slope)
+    return dx
+
+
+def conv2d_wgrad(dy, x, KH, KW, sh, sw, ph, pw):
+    U, Ho, Wo, Cout = dy.shape
+    _, H, W, Cin = x.shape
+    dw = torch.zeros((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+    db = torch.zeros((Cout,), device=dy.device, dtype=torch.float32)
+    K.conv2d_wgrad_bf16(dy.view(U * Ho * Wo, Cout), x.view(U * H * W, Cin), dw, db, M=U * Ho * Wo, Trows=Ho * Wo, Wrows=Wo,
+                        Hin=H, Win=W, n=Cout, cin=Cin, taps=KH * KW, KW=KW, pad_h=ph, pad_w=pw, step_h=sh, step_w=sw)
+    return dw, db
+
+
+class MRDStackFn(torch.autograd.Function):
+    """The six Conv2d of one DiscriminatorR (vocoder/wavenext/disc/_discriminators.py:154-194) on the channels-last
+    magnitude spectrogram (U, H = frames, W = freq bins, 1) -- i.e. the STFT kernel's output as is.
+
+    spec rows: (KH, KW, sh, sw, ph, pw) in (frames, freq) order.  inputs: x, then (w_i native (Cout,KH,KW,Cin), b_i) x 6.
+    outputs: y1..y5 (bf16, LeakyReLU applied) and the score map s (U,H5,W5,1) f32 -- all six are the reference's fmap.
+    """
+    SPEC = ((5, 7, 2, 2, 2, 3), (3, 5, 1, 2, 1, 2), (3, 5, 2, 2, 1, 2), (3, 3, 1, 2, 1, 1), (3, 3, 2, 2, 1, 1),
+            (3, 3, 1, 1, 1, 1))
+    SLOPE = 0.1
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        ctx.set_materialize_grads(False)
+        ws, bs = wb[0::2], wb[1::2]
+        wbf = [K.cast_bf16(w) for w in ws]
+        acts, h = [], x.contiguous()
+        for i in range(5):
+            if i == 0 and ws[0].shape[0] in (16, 32, 64) and h.shape[-1] == 1:   # Cin = 1: direct VALU kernel
+                KH, KW, sh, sw, ph, pw = MRDStackFn.SPEC[0]
+                U, H, W = h.shape[0], h.shape[1], h.shape[2]
+                Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+                h = K.smallcin_fwd(h, ws[0].detach().reshape(ws[0].shape[0], -1), bs[0], U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo,
+                                   cout=ws[0].shape[0], KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=MRDStackFn.SLOPE,
+                                   out_bf16=True).view(U, Ho, Wo, -1)
+            else:
+                h = conv2d_fwd(h, wbf[i], bs[i], *MRDStackFn.SPEC[i], MRDStackFn.SLOPE, True)
+            acts.append(h)
+        s = conv2d_fwd(h, wbf[5], bs[5], *MRDStackFn.SPEC[5], None, False)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, *acts, *wbf)
+            ctx.wneed = [w.requires_grad or b.requires_grad for w, b in zip(ws, bs)]
+        return (*acts, s)
+
+    @staticmethod
+    def backward(ctx, d1, d2, d3, d4, d5, ds):
+        saved = ctx.saved_tensors
+        x, acts, wbf = saved[0], saved[1:6], saved[6:12]
+        extras = [d.contiguous() if d is not None else None for d in (d1, d2, d3, d4, d5)]
+        if ds is None:
+            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
+        gw, gb = [None] * 6, [None] * 6
+        g = ds.contiguous()
+        for i in range(5, -1, -1):
+            inp = acts[i - 1] if i > 0 else x
+            sp = MRDStackFn.SPEC[i]
+            if ctx.wneed[i]:
+                if i == 0 and inp.shape[-1] == 1 and g.shape[-1] in (16, 32, 64):
+                    KH, KW, sh, sw, ph, pw = sp
+                    cout = g.shape[-1]
+                    gw[i] = torch.zeros((cout, KH, KW, 1), device=g.device, dtype=torch.float32)
+                    gb[i] = torch.zeros((cout,), device=g.device, dtype=torch.float32)
+                    K.smallcin_wgrad(inp, g, gw[i], gb[i], U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
+                                     Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+                else:
+                    gw[i], gb[i] = conv2d_wgrad(g, inp, *sp)
+            if i > 0:
+                g = conv2d_dgrad(g, transpose_weight2d(wbf[i]), inp.shape[1], inp.shape[2], *sp, lrelu_y=inp,
+                                 extra=extras[i - 1], slope=MRDStackFn.SLOPE, out_bf16=True)
+            elif ctx.needs_input_grad[0]:
+                g = conv2d_dgrad(g, transpose_weight2d(wbf[0]), inp.shape[1], inp.shape[2], *sp, out_bf16=False)
+            else:
+                g = None
+        out = [g]
+        for i in range(6):
+            out += [gw[i], gb[i]]
+        return tuple(out)
+
+
+# =================================================================================================== generic stack
+class ConvStackFn(torch.autograd.Function):
+    """A whole DiscriminatorP / DiscriminatorR conv stack with weight norm folded in.
+
+    forward(x (U,H,W,1) f32, spec, slope, v0, g0, b0, ..., v5, g5, b5)  -- the *raw* weight_norm parameters (leaves).
+    ``spec`` rows (KH, KW, sh, sw, ph, pw) in native (H, W) orientation; layers 0..4 get LeakyReLU, layer 5 is conv_post.
+    Per layer one osp_wnorm_fwd packs g*v/||v|| into the bf16 native / transposed layouts; the backward turns the native
+    f32 weight gradient into (dv, dg) with osp_wnorm_bwd and ACCUMULATES into the parameters' gradient-arena slots
+    (so the Function returns None for parameters, like every other op of this package).
+    outputs: y1..y5 (bf16, LeakyReLU applied) and the score map s (U,H5,W5,1) f32.
+    """
+
+    @staticmethod
+    def forward(ctx, x, spec, slope, *params):
+        ctx.set_materialize_grads(False)
+        vs, gs, bs = params[0::3], params[1::3], params[2::3]
+        need_w = [bool(ctx.needs_input_grad[3 + 3 * i]) for i in range(6)]
+        need_x = bool(ctx.needs_input_grad[0])
+        packs = []
+        acts, h = [], x.contiguous()
+        for i in range(6):
+            KH, KW, sh, sw, ph, pw = spec[i]
+            cout, cin = vs[i].shape[0], vs[i].shape[1]
+            small = (cin == 1 and cout in (16, 32, 64) and KH * KW <= cout)
+            wn, wn32, wt, inv = K.wnorm_fwd(vs[i].detach(), gs[i].detach(), want_f32=small,
+                                            want_t=(i > 0 and (need_x or any(need_w[:i]))) or (i == 0 and need_x))
+            packs.append((wn, wn32, wt, inv))
+            lr = slope if i < 5 else None
+            if small:
+                U, H, W = h.shape[0], h.shape[1], h.shape[2]
+                Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+                h = K.smallcin_fwd(h, wn32.view(cout, -1), bs[i].detach(), U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo, cout=cout, KH=KH,
+                                   KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=lr, out_bf16=i < 5).view(U, Ho, Wo, cout)
+            else:
+                h = conv2d_fwd(h, wn, bs[i].detach(), KH, KW, sh, sw, ph, pw, lr, i < 5)
+            acts.append(h)
+        if need_x or any(need_w):
+            ctx.save_for_backward(x, *acts[:5], *[t for pk in packs for t in (pk[0], pk[2], pk[3]) if t is not None])
+            ctx.pack_layout = [(pk[0] is not None, pk[2] is not None, pk[3] is not None) for pk in packs]
+            ctx.params = params
+            ctx.cfg = (spec, slope, need_x, need_w)
+        return tuple(acts)
+
+    @staticmethod
+    def backward(ctx, d1, d2, d3, d4, d5, ds):
+        from .ops import gsink
+        spec, slope, need_x, need_w = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        x, acts = saved[0], saved[1:6]
+        rest = saved[6:]
+        packs = []
+        for has in ctx.pack_layout:
+            item = []
+            for flag in has:
+                item.append(rest.pop(0) if flag else None)
+            packs.append(item)                                  # (wn, wt, inv)
+        vs, gs, bs = ctx.params[0::3], ctx.params[1::3], ctx.params[2::3]
+        extras = [d.contiguous() if d is not None else None for d in (d1, d2, d3, d4, d5)]
+        if ds is None:
+            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
+        g = ds.contiguous()
+        for i in range(5, -1, -1):
+            inp = acts[i - 1] if i > 0 else x
+            KH, KW, sh, sw, ph, pw = spec[i]
+            wn, wt, inv = packs[i]
+            cout, cin = vs[i].shape[0], vs[i].shape[1]
+            if need_w[i]:
+                dw = torch.zeros((cout, KH, KW, cin), device=g.device, dtype=torch.float32)
+                db = gsink(bs[i])
+                if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
+                    K.smallcin_wgrad(inp, g, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
+                                     Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+                else:
+                    U, Ho, Wo = g.shape[0], g.shape[1], g.shape[2]
+                    H, W = inp.shape[1], inp.shape[2]
+                    K.conv2d_wgrad_bf16(g.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
+                                        Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
+                                        pad_w=pw, step_h=sh, step_w=sw)
+                K.wnorm_bwd(dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i]))
+            if i > 0 and (need_x or any(need_w[:i])):
+                g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp, extra=extras[i - 1],
+                                 slope=slope, out_bf16=True)
+            elif i == 0 and need_x:
+                g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, out_bf16=False)
+            else:
+                g = None
+                break
+        return (g if need_x else None, None, None) + (None,) * len(ctx.params)
+
+
+MPD_SPEC = ((1, 5, 1, 3, 0, 2),) * 4 + ((1, 5, 1, 1, 0, 2), (1, 3, 1, 1, 0, 1))
+MRD_SPEC = MRDStackFn.SPEC
+
+
+class L1MeanFn(torch.autograd.Function):
+    """mean |target - y| with the gradient flowing to ``y`` only (FeatureMatchingLoss terms, disc/loss.py:71-85)."""
+
+    @staticmethod
+    def forward(ctx, target, y):
+        out = torch.zeros((), device=y.device, dtype=torch.float32)
+        target, y = target.contiguous(), y.contiguous()
+        K.l1_sum(target, y, 1.0 / y.numel(), out)
+        ctx.save_for_backward(target, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        target, y = ctx.saved_tensors
+        return None, K.l1_sign(target, y, 1.0 / y.numel(), gout.reshape(1).float().contiguous())

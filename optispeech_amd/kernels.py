@@ -5,6 +5,7 @@ plumbing only).  No arithmetic happens in Python.
 """
 import torch
 
+from . import precision as _precision
 from ._lib import call
 
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_SCALE_RES_MASK, EPI_GELU_BWD, EPI_RELU_BWD, EPI_AXMY, EPI_MASK = range(8)
@@ -34,6 +35,18 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
     if out is None:
         shape = (batch, M, n_out) if batch > 1 else (M, n_out)
         out = torch.empty(shape, device=a.device, dtype=torch.float32)
+    if _precision.is_bf16() and ((M + 127) // 128) * ((n_out + 127) // 128) * batch >= 128:
+        # performance mode: same contraction on the bf16 MFMA kernel (f32 storage, converted while staging)
+        ldc_ = out.stride(-2) if ldc is None else ldc
+        ld_aux_ = 0
+        for t in (aux_out, aux_in):
+            if t is not None:
+                ld_aux_ = t.stride(-2)
+        call("osp_conv_gemm_bf16", a, 0, lda, M, T, T, cin, taps, 1, 1, -pad, a_rowscale, w, 0, w_strides[0], w_strides[1],
+             w_strides[2], n_out, out, 0, ldc_, T, 1, 0, epi, bias, gamma, res, 0, res.stride(-2) if res is not None else 0,
+             rowmask, rowscale, aux_out, aux_in, 0, ld_aux_, 0.0, batch, batch_strides[0], batch_strides[1],
+             batch_strides[2], batch_strides[3], bool(accumulate))
+        return out
     ldc = out.stride(-2) if ldc is None else ldc
     ld_aux = 0
     for t in (aux_out, aux_in):
@@ -55,6 +68,10 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
     assert dw.is_contiguous() and dw.numel() == batch * N * taps * cin, (dw.shape, N, taps, cin)
     sy = dy.stride(0) if batch > 1 else 0
     sx = x.stride(0) if batch > 1 else 0
+    if _precision.is_bf16() and M >= 8192 and N >= 64 and cin >= 64:
+        call("osp_conv_wgrad_bf16", dy, 0, dy.stride(-2), x, 0, x.stride(-2), M, T, T, N, cin, taps, pad, 1, arow, oscale, dw,
+             taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
+        return
     call("osp_conv_wgrad_f32", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
          taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
 
@@ -311,3 +328,63 @@ def conv_wgrad_bf16(dy, x, dw, db=None, *, M, Trows, Tin, n, cin, taps=1, pad=0,
                     batch=1, strides=(0, 0, 0, 0)):
     call("osp_conv_wgrad_bf16", dy, _isbf(dy), dy.stride(-2), x, _isbf(x), x.stride(-2), M, Trows, Tin, n, cin, taps,
          pad, x_step, arow, oscale, dw, taps * cin, db, batch, strides[0], strides[1], strides[2], strides[3])
+
+
+def conv2d_gemm_bf16(a, w, n_out, *, M, Trows, Wrows, Hin, Win, cin, taps, KW, a_step_h, a_tapstep_h, a_off_h, a_step,
+                     a_tapstep, a_off, w_strides, out, ldc, Tc, Wc, c_step_h=1, c_off_h=0, c_step=1, c_off=0,
+                     epi=EPI_NONE, bias=None, res=None, aux_in=None, slope=0.1, lda=None):
+    """2-D (channels-last conv2d) form of conv_gemm_bf16; w_strides = (sBn, sBtap_h, sBtap_w, sBk)."""
+    lda = a.stride(-2) if lda is None else lda
+    ld_aux = aux_in.stride(-2) if aux_in is not None else 0
+    ldr = res.stride(-2) if res is not None else 0
+    call("osp_conv2d_gemm_bf16", a, _isbf(a), lda, M, Trows, Wrows, Hin, Win, cin, taps, KW, a_step_h, a_tapstep_h, a_off_h,
+         a_step, a_tapstep, a_off, w, _isbf(w), w_strides[0], w_strides[1], w_strides[2], w_strides[3], n_out, out,
+         _isbf(out), ldc, Tc, Wc, c_step_h, c_off_h, c_step, c_off, epi, bias, res, _isbf(res), ldr, aux_in, _isbf(aux_in),
+         ld_aux, float(slope))
+    return out
+
+
+def conv2d_wgrad_bf16(dy, x, dw, db, *, M, Trows, Wrows, Hin, Win, n, cin, taps, KW, pad_h, pad_w, step_h, step_w):
+    call("osp_conv2d_wgrad_bf16", dy, _isbf(dy), dy.stride(-2), x, _isbf(x), x.stride(-2), M, Trows, Wrows, Hin, Win, n, cin,
+         taps, KW, pad_h, pad_w, step_h, step_w, dw, db)
+
+
+def smallcin_fwd(x, w, b, *, U, Hin, Win, Ho, Wo, cout, KH, KW, sh, sw, ph, pw, slope, out_bf16):
+    """Cin = 1 direct conv: x (U,Hin,Win) f32, w (cout, KH*KW) f32 -> (U*Ho*Wo, cout)."""
+    y = torch.empty((U * Ho * Wo, cout), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    call("osp_smallcin_conv_fwd", x, w, b, y, _isbf(y), U * Ho * Wo, Ho * Wo, Wo, Hin, Win, cout, KH * KW, KW, sh, sw, ph, pw,
+         slope is not None, float(slope or 0.0))
+    return y
+
+
+def smallcin_wgrad(x, dy, dw, db, *, U, Hin, Win, Ho, Wo, cout, KH, KW, sh, sw, ph, pw):
+    call("osp_smallcin_conv_wgrad", x, dy, _isbf(dy), dw, db, U * Ho * Wo, Ho * Wo, Wo, Hin, Win, cout, KH * KW, KW, sh, sw, ph,
+         pw)
+
+
+# ------------------------------------------------------------------------------------------------ weight norm / L1
+def wnorm_fwd(v, g, want_f32=False, want_t=True):
+    """v (Cout,Cin,P,Q) f32, g (Cout,1,1,1) -> wn bf16 (Cout,Q,P,Cin), wn32 or None, wt bf16 (Cin,Q,P,Cout) or None, inv_norm."""
+    Cout, Cin, P, Q = v.shape
+    dev = v.device
+    wn = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.bfloat16)
+    wn32 = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.float32) if want_f32 else None
+    wt = torch.empty((Cin, Q, P, Cout), device=dev, dtype=torch.bfloat16) if want_t else None
+    inv = torch.empty((Cout,), device=dev, dtype=torch.float32)
+    call("osp_wnorm_fwd", v, g, wn, wn32, wt, inv, Cout, Cin, P, Q)
+    return wn, wn32, wt, inv
+
+
+def wnorm_bwd(dwn, v, g, inv, dv, dg):
+    Cout, Cin, P, Q = v.shape
+    call("osp_wnorm_bwd", dwn, v, g, inv, dv, dg, Cout, Cin, P, Q)
+
+
+def l1_sum(a, b, scale, out):
+    call("osp_l1_sum", a, b, _isbf(a), a.numel(), float(scale), out)
+
+
+def l1_sign(a, b, scale, gscale):
+    gb = torch.empty_like(b)
+    call("osp_l1_sign", a, b, _isbf(a), a.numel(), float(scale), gscale, gb)
+    return gb

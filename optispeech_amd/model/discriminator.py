@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import precision, spectral
-from ..disc_ops import MPDStackFn
+from ..disc_ops import MPD_SPEC, MRD_SPEC, ConvStackFn, L1MeanFn
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -74,11 +74,11 @@ class DiscriminatorP(nn.Module):
             t = t + n_pad
         if precision.is_bf16():
             # channels-last sequences (B*period, T/period, 1): every period column is an independent 1-D signal
-            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, t // self.period, 1)
+            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)
             args = []
             for conv in list(self.convs) + [self.conv_post]:
-                args += [conv.native_weight(), conv.bias]
-            y1, y2, y3, y4, y5, s = MPDStackFn.apply(seq.contiguous(), *args)
+                args += [conv.weight_v, conv.weight_g, conv.bias]
+            y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
             return s.view(b, -1), [y2, y3, y4, y5, s]
         x = x.view(b, c, t // self.period, self.period)
         fmap = []
@@ -108,6 +108,15 @@ class DiscriminatorR(nn.Module):
         return spectral.stft_magnitude(x, n_fft, hop, None, None).transpose(1, 2)      # (B, freq, frames)
 
     def forward(self, x):
+        if precision.is_bf16():
+            n_fft, hop, win = self.resolution
+            spec = spectral.stft_magnitude(x, n_fft, hop, None, None)              # (B, frames, bins), channels-last
+            args = []
+            for conv in list(self.convs) + [self.conv_post]:
+                # reference weight (Cout, Cin, k_freq, k_time) is packed to native (Cout, KH = k_time, KW = k_freq, Cin)
+                args += [conv.weight_v, conv.weight_g, conv.bias]
+            y1, y2, y3, y4, y5, s = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
+            return s.reshape(s.shape[0], -1), [y1, y2, y3, y4, y5, s]
         fmap = []
         x = self.spectrogram(x).unsqueeze(1)
         for conv in self.convs:
@@ -167,7 +176,10 @@ def _feature_matching(fr, fg):                                 # FeatureMatching
     tot = 0
     for dr, dg in zip(fr, fg):
         for a, b in zip(dr, dg):
-            tot = tot + torch.mean(torch.abs(a - b))
+            if precision.is_bf16():
+                tot = tot + L1MeanFn.apply(a.detach(), b)          # fused |a-b| mean; gradient to the generated branch
+            else:
+                tot = tot + torch.mean(torch.abs(a - b))
     return tot / len(fr)
 
 

@@ -63,16 +63,18 @@ def test_conv_bf16_dgrad_wgrad_strided(nutt, Tin, cin, cout, taps, stride, pad):
     assert relerr(db, b.grad) < 1e-2
 
 
-def test_mpd_bf16_path_matches_f32_path():
-    """DiscriminatorP stacks on the bf16 GEMM vs the f32 (MIOpen conv2d) path: losses and gradients."""
+@pytest.mark.parametrize("which", ["multiperioddisc", "multiresddisc"])
+def test_mpd_bf16_path_matches_f32_path(which):
+    """DiscriminatorP / DiscriminatorR stacks on the bf16 GEMM vs the f32 (MIOpen conv2d) path: losses and gradients."""
     from optispeech_amd import precision
     from optispeech_amd.config import FeatureExtractorArgs
-    from optispeech_amd.model.discriminator import MultiPeriodDiscriminator, _feature_matching, _hinge_d, _hinge_g
+    from optispeech_amd.model.discriminator import (MultiPeriodDiscriminator, MultiResolutionDiscriminator,
+                                                    _feature_matching, _hinge_d, _hinge_g)
     from oracle import schema as S
     torch.manual_seed(0)
-    mpd = MultiPeriodDiscriminator().to(DEV)
-    W = {k[len("discriminator.multiperioddisc."):]: v for k, v in S.make_weights(S.discriminator_schema(), 4321).items()
-         if "multiperioddisc" in k}
+    mpd = (MultiPeriodDiscriminator() if which == "multiperioddisc" else MultiResolutionDiscriminator()).to(DEV)
+    W = {k[len("discriminator." + which + "."):]: v for k, v in S.make_weights(S.discriminator_schema(), 4321).items()
+         if which in k}
     mpd.load_state_dict(W)
     g = torch.Generator().manual_seed(1)
     y = (torch.rand(4, 16384, generator=g) * 2 - 1).to(DEV)
@@ -107,3 +109,27 @@ def test_mpd_bf16_path_matches_f32_path():
         if a[3][k].numel() > 64:
             c = torch.nn.functional.cosine_similarity(a[3][k].flatten(), b[3][k].flatten(), dim=0).item()
             assert c > 0.97, (k, c)
+
+
+@pytest.mark.parametrize("U,H,W,cin,cout,spec", [
+    (3, 33, 65, 1, 64, (5, 7, 2, 2, 2, 3)), (2, 17, 40, 64, 64, (3, 5, 1, 2, 1, 2)), (2, 20, 31, 64, 64, (3, 5, 2, 2, 1, 2)),
+    (2, 9, 17, 64, 64, (3, 3, 2, 2, 1, 1)), (2, 9, 17, 64, 1, (3, 3, 1, 1, 1, 1))])
+def test_conv2d_bf16_forward_dgrad_wgrad(U, H, W, cin, cout, spec):
+    """channels-last conv2d on the bf16 GEMM vs torch conv2d (asymmetric kernels/strides/paddings per dim)."""
+    from optispeech_amd import disc_ops as D, kernels as K
+    KH, KW, sh, sw, ph, pw = spec
+    x = bfr(rnd(U, cin, H, W, seed=1)).requires_grad_(True)
+    w = bfr(rnd(cout, cin, KH, KW, seed=2, scale=1.0 / np.sqrt(cin * KH * KW))).requires_grad_(True)
+    b = rnd(cout, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=(sh, sw), padding=(ph, pw))
+    dy = bfr(rnd(*y.shape, seed=4))
+    y.backward(dy)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    wn = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)                       # (Cout, KH, KW, Cin)
+    got = D.conv2d_fwd(xg, K.cast_bf16(wn), b.detach().to(DEV), *spec, None, False)
+    assert relerr(got.permute(0, 3, 1, 2), y) < 1e-2
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    dx = D.conv2d_dgrad(dyg, D.transpose_weight2d(wn), H, W, *spec)
+    assert relerr(dx.permute(0, 3, 1, 2), x.grad) < 1e-2
+    dw, db = D.conv2d_wgrad(dyg, xg, *spec)
+    assert relerr(dw.permute(0, 3, 1, 2), w.grad) < 1e-2 and relerr(db, b.grad) < 1e-2
