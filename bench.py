@@ -7,7 +7,7 @@
 
 One "step" = BaseLightningModule.training_step in the post-pre-training regime: generator forward, adversarial
 losses through MPD/MRD, G backward, clip + AdamW(G), discriminator forward/backward, clip + AdamW(D); train mode
-(dropout / drop-path active), fp32.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
+(dropout / drop-path active); --precision bf16 (default, BASELINE config[1]) or f32 (exact parity mode).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
 line; `value` is the whole-job aggregate (mel-frames/s over all ranks, weak scaling: 32 utterances per GPU).
 """
 import argparse
@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 B, T_TEXT, T_MEL = 32, 128, 800
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -33,7 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2, help="utterances in the bounded CPU-baseline sample")
+    ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the bounded CPU-baseline sample")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
     ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("OSP_PRECISION", "bf16"),
                     help="bf16 = BASELINE config[1] (bf16 MFMA operands, f32 accumulate, f32 master weights); "
@@ -42,11 +44,11 @@ def parse():
 
 
 class KernelTimer:
-    """HIP-event timing of one C-ABI entry point on the launch stream (torch's current stream), filtered by a
-    predicate on the call arguments, so `roofline.achieved` comes from launches inside the timed region."""
+    """HIP-event timing of selected C-ABI launches on the launch stream (torch's current stream) inside the timed region,
+    so `roofline.achieved` = algorithmic flops of those launches / their measured duration."""
 
-    def __init__(self, name, pred):
-        self.name, self.pred, self.events, self.enabled = name, pred, [], False
+    def __init__(self, select):
+        self.select, self.events, self.enabled = select, [], False
 
     def install(self):
         from optispeech_amd import _lib
@@ -55,20 +57,22 @@ class KernelTimer:
         timer = self
 
         def call(name, *args):
-            if timer.enabled and name == timer.name and timer.pred(args):
+            fl = timer.select(name, args) if timer.enabled else None
+            if fl:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 orig(name, *args)
                 e1.record()
-                timer.events.append((e0, e1))
+                timer.events.append((fl, e0, e1))
             else:
                 orig(name, *args)
         lib.call = call
 
-    def mean_ms(self):
+    def summary(self):
         if not self.events:
-            return None
-        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+            return None, None, 0
+        ms = sum(a.elapsed_time(b) for _, a, b in self.events)
+        return sum(f for f, _, _ in self.events), ms, len(self.events)
 
 
 def cpu_baseline(nb):
@@ -109,6 +113,27 @@ def cpu_baseline(nb):
     return nb * T_MEL / dt, threads, f"{nb} utterances x (T_text={T_TEXT}, T_mel={T_MEL}), 1 warm + 1 timed GAN step, {dt:.1f}s"
 
 
+def synthesise_rtf(model, dev, n_sent=64, seed=7):
+    """BASELINE config[4]: synthesise() on 64 batched sentences; durations overridden to U{4..8} frames/phoneme because
+    random-init weights predict degenerate durations.  RTF as the reference defines it
+    (generator/__init__.py:285-288): (t_acoustic + t_vocoder) / (padded wav length / sample_rate)."""
+    from optispeech_amd.values import InferenceInputs
+    g = torch.Generator().manual_seed(seed)
+    x_len = torch.randint(64, 129, (n_sent,), generator=g)
+    x_len[0] = 128
+    x = torch.randint(1, 159, (n_sent, 128), generator=g) * (torch.arange(128)[None] < x_len[:, None])
+    dur = torch.randint(4, 9, (n_sent, 128), generator=g)
+    inputs = InferenceInputs(clean_text="", x=x, x_lengths=x_len, d_factor=1.0, p_factor=1.0, e_factor=1.0)
+    model.eval()
+    outs = [model.synthesise(inputs, durations_override=dur) for _ in range(3)]
+    model.train()
+    o = outs[-1]
+    audio_s = float(o.wav_lengths.sum()) / model.sample_rate
+    return {"rtf": o.rtf, "am_rtf": o.am_rtf, "v_rtf": o.v_rtf, "latency_ms": o.latency, "sentences": n_sent,
+            "padded_audio_s": o.wav.shape[-1] / model.sample_rate, "total_audio_s": audio_s,
+            "aggregate_audio_s_per_s": audio_s / (o.latency * 1e-3)}
+
+
 def main():
     a = parse()
     from optispeech_amd import dp, precision, rng
@@ -127,9 +152,25 @@ def main():
     batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
     model.optimizers()
 
-    # dominant hand-written kernel: the decoder's pointwise GEMMs (M = B*T_mel frames, 256 <-> 1024 channels)
-    M = B * T_MEL
-    timer = KernelTimer("osp_conv_gemm_f32", lambda args: args[2] == M and args[4] * args[12] == 256 * 1024 and args[5] == 1)
+    # dominant hand-written kernel by time: conv_gemm_bf16_glds_kernel (csrc/gemm_bf16.hip), i.e. every conv-GEMM launch
+    # whose operands are bf16 in HBM with Cin % 64 == 0 (all large MPD / MRD forward and dgrad GEMMs).  Algorithmic
+    # flops per launch = 2 * M * taps * Cin * N; the launches are timed with HIP events on the launch
+    # stream, so sum(flops) / sum(time) is comparable with the kernel's average in the rocprofv3 summary under profiles/.
+    if a.precision == "bf16":
+        def select(name, args):
+            if name == "osp_conv2d_gemm_bf16" and args[1] == 1 and args[18] == 1 and args[22] == 1 and args[8] % 64 == 0:
+                return 2.0 * args[3] * args[9] * args[8] * args[23]                  # M, taps, Cin, N
+            return None
+        roof_kernel, roof_peak = "conv_gemm_bf16_glds_kernel (all MPD/MRD conv-GEMM forward + dgrad launches)", PEAK_BF16_MFMA_TFLOPS
+    else:
+        M = B * T_MEL
+
+        def select(name, args):
+            if name == "osp_conv_gemm_f32" and args[2] == M and args[4] * args[12] == 256 * 1024 and args[5] == 1:
+                return 2.0 * M * 256 * 1024
+            return None
+        roof_kernel, roof_peak = "conv_gemm_f32 (decoder pwconv1/pwconv2, M=25600, 256<->1024)", PEAK_F32_MFMA_TFLOPS
+    timer = KernelTimer(select)
     timer.install()
 
     def sync():
@@ -156,11 +197,11 @@ def main():
     value = world * B * T_MEL / (dt / a.steps)
 
     if rank == 0:
-        kms = timer.mean_ms()
-        flops = 2.0 * M * 256 * 1024                           # algorithmic flops of one launch
-        roof = {"bound": "mfma", "kernel": "conv_gemm_f32 (decoder pwconv1/pwconv2, M=25600, 256<->1024)",
-                "achieved": (flops / (kms * 1e-3) / 1e12) if kms else None, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "traffic": None, "launches_timed": len(timer.events)}
+        flops, kms, nlaunch = timer.summary()
+        roof = {"bound": "mfma", "kernel": roof_kernel,
+                "achieved": (flops / (kms * 1e-3) / 1e12) if kms else None, "peak": roof_peak,
+                "unit": "TFLOP/s", "traffic": None, "launches_timed": nlaunch,
+                "avg_launch_us": (kms / nlaunch * 1e3) if nlaunch else None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
         cpu = None
         if not a.no_cpu_baseline:
@@ -176,6 +217,7 @@ def main():
                           "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}",
                           "lengths": "ragged" if a.ragged else "fixed"},
                "per_gpu": value / world, "roofline": roof, "cpu_baseline": cpu,
+               "synthesise": None if a.no_infer else synthesise_rtf(model, dev),
                "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")}}
         print(json.dumps(out))
     if world > 1:

@@ -25,6 +25,23 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define TBK 64
 #define LDK (TBK + 8)
 
+// Division by a run-time constant via multiply-high (round-up method, exact for all 32-bit numerators < 2^31):
+// integer division costs ~40 VALU instructions on CDNA; the conv row maps need several per loaded row.
+struct FastDiv { unsigned magic, shift, d; };
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f; f.d = d;
+    if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+    unsigned s = 0; while ((1u << s) < d) ++s;
+    f.shift = s;
+    f.magic = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ int fd_div(int m, const FastDiv f) {
+    if (f.d <= 1) return m;
+    const unsigned hi = __umulhi((unsigned)m, f.magic);
+    return (int)((hi + (unsigned)m) >> f.shift);
+}
+
 enum { BEPI_NONE = 0, BEPI_RELU = 1, BEPI_GELU = 2, BEPI_SCALE_RES_MASK = 3, BEPI_GELU_BWD = 4, BEPI_RELU_BWD = 5,
        BEPI_AXMY = 6, BEPI_MASK = 7, BEPI_LRELU = 8, BEPI_LRELU_BWD = 9 };
 
@@ -86,74 +103,87 @@ __device__ __forceinline__ void mma_tile_bf16(const unsigned short* __restrict__
     }
 }
 
-// ---- shared epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-__device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
-                                                   int lane, int64_t bz) {
+// ---- shared epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+// The epilogue kind is a template parameter so that every instantiation is a small, fully unrolled, statically indexed
+// loop over the 64 accumulator values: a run-time `switch` inside the loop kept it from unrolling and pushed the
+// accumulators to scratch (tens of microseconds per workgroup on the short-K convolutions).
+template <int EPI>
+__device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+                                                     int lane, int64_t bz) {
     const int esC = pp.c_bf16 ? 2 : 4;
     char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * esC;
     const float* res = pp.res ? pp.res + bz * pp.sXb : nullptr;
     const char* aux_in = pp.aux_in ? reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
     float* aux_out = pp.aux_out ? pp.aux_out + bz * pp.sXb : nullptr;
-    // Pull the accumulators out with a branch-free, fully unrolled copy first: if the (large) epilogue loop below is
-    // not fully unrolled, a dynamically indexed copy may go to scratch -- but the MFMA accumulators themselves never do.
-    float vals[2][2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) vals[i][j][r] = acc[i][j][r];
     const int l31 = lane & 31, lh = lane >> 5;
+    const bool c_bf16 = pp.c_bf16 != 0, accumulate = pp.accumulate != 0;
+    const int Trows = pp.Trows, Wrows = pp.Wrows, Tc = pp.Tc, Wc = pp.Wc, c_step = pp.c_step, c_off = pp.c_off,
+              c_step_h = pp.c_step_h, c_off_h = pp.c_off_h, M = pp.M, N = pp.N;
+    const int64_t ldc = pp.ldc, ld_aux = pp.ld_aux, ldr = pp.ldr;
+    const float slope = pp.slope;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn0 + 32 * j + l31;
-            if (n >= pp.N) continue;
-            const float bias = pp.bias ? pp.bias[n] : 0.f;
-            const float gam = pp.gamma ? pp.gamma[n] : 1.f;
+            const bool n_ok = n < N;
+            const float bias = (pp.bias && n_ok) ? pp.bias[n] : 0.f;
+            const float gam = (EPI == BEPI_SCALE_RES_MASK && pp.gamma && n_ok) ? pp.gamma[n] : 1.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= pp.M) continue;
-                const int64_t mr = bz * pp.M + m;
-                const float v = vals[i][j][r] + bias;
-                const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
-                const int64_t crow = (int64_t)u * pp.Tc + (int64_t)(th * pp.c_step_h + pp.c_off_h) * pp.Wc +
-                                     (int64_t)tw * pp.c_step + pp.c_off;                       // aux / res follow C's rows
-                float out;
-                switch (pp.epi) {
-                    case BEPI_RELU: out = fmaxf(v, 0.f); break;
-                    case BEPI_LRELU: out = v > 0.f ? v : v * pp.slope; break;
-                    case BEPI_GELU:
-                        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+                if (n_ok && m < M) {
+                    const int64_t mr = bz * M + m;
+                    const float v = acc[i][j][r] + bias;
+                    const int u = m / Trows, t = m - u * Trows, th = t / Wrows, tw = t - th * Wrows;
+                    const int64_t crow = (int64_t)u * Tc + (int64_t)(th * c_step_h + c_off_h) * Wc + (int64_t)tw * c_step + c_off;
+                    float out = v;
+                    if constexpr (EPI == BEPI_RELU) out = fmaxf(v, 0.f);
+                    if constexpr (EPI == BEPI_LRELU) out = v > 0.f ? v : v * slope;
+                    if constexpr (EPI == BEPI_GELU) {
+                        if (aux_out) aux_out[crow * ld_aux + n] = v;
                         out = gelu_f(v);
-                        break;
-                    case BEPI_SCALE_RES_MASK: {
-                        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+                    }
+                    if constexpr (EPI == BEPI_SCALE_RES_MASK) {
+                        if (aux_out) aux_out[crow * ld_aux + n] = v;
                         const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
-                        out = (res[crow * pp.ldr + n] + rs * gam * v) * mk;
-                    } break;
-                    case BEPI_GELU_BWD:
-                        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n));
-                        break;
-                    case BEPI_RELU_BWD: out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? v : 0.f; break;
-                    case BEPI_LRELU_BWD: {   // (acc + extra) * lrelu'(y):  extra = gradient arriving at the same activation
-                        const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * pp.ldr + n) : 0.f;
-                        out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? (v + e) : (v + e) * pp.slope;
-                    } break;
-                    case BEPI_AXMY: out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) - v; break;
-                    case BEPI_MASK: out = v * (pp.rowmask ? pp.rowmask[mr] : 1.f); break;
-                    default: out = v;
-                }
-                if (pp.c_bf16) {
-                    reinterpret_cast<__bf16*>(Cb)[crow * pp.ldc + n] = (__bf16)out;
-                } else {
-                    float* dst = reinterpret_cast<float*>(Cb) + crow * pp.ldc + n;
-                    *dst = pp.accumulate ? (*dst + out) : out;
+                        out = (res[crow * ldr + n] + rs * gam * v) * mk;
+                    }
+                    if constexpr (EPI == BEPI_GELU_BWD)
+                        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n));
+                    if constexpr (EPI == BEPI_RELU_BWD) out = ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n) > 0.f ? v : 0.f;
+                    if constexpr (EPI == BEPI_LRELU_BWD) {   // (acc + extra) * lrelu'(y)
+                        const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * ldr + n) : 0.f;
+                        out = ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n) > 0.f ? (v + e) : (v + e) * slope;
+                    }
+                    if constexpr (EPI == BEPI_AXMY)
+                        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n) - v;
+                    if constexpr (EPI == BEPI_MASK) out = v * (pp.rowmask ? pp.rowmask[mr] : 1.f);
+                    if (c_bf16) {
+                        reinterpret_cast<__bf16*>(Cb)[crow * ldc + n] = (__bf16)out;
+                    } else {
+                        float* dst = reinterpret_cast<float*>(Cb) + crow * ldc + n;
+                        *dst = accumulate ? (*dst + out) : out;
+                    }
                 }
             }
         }
+}
+
+__device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+                                                   int lane, int64_t bz) {
+    switch (pp.epi) {
+        case BEPI_RELU: gemm_bf16_epilogue_t<BEPI_RELU>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_GELU: gemm_bf16_epilogue_t<BEPI_GELU>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_SCALE_RES_MASK: gemm_bf16_epilogue_t<BEPI_SCALE_RES_MASK>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_GELU_BWD: gemm_bf16_epilogue_t<BEPI_GELU_BWD>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_RELU_BWD: gemm_bf16_epilogue_t<BEPI_RELU_BWD>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_AXMY: gemm_bf16_epilogue_t<BEPI_AXMY>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_MASK: gemm_bf16_epilogue_t<BEPI_MASK>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_LRELU: gemm_bf16_epilogue_t<BEPI_LRELU>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_LRELU_BWD: gemm_bf16_epilogue_t<BEPI_LRELU_BWD>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        default: gemm_bf16_epilogue_t<BEPI_NONE>(pp, acc, m0, n0, wm0, wn0, lane, bz);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
@@ -524,6 +554,7 @@ struct WgradB {
     const void* dY; int y_bf16; int64_t ldy; const void* X; int x_bf16; int64_t ldx;
     int M, Trows, Tin, N, Cin, taps, pad, x_step;
     int Wrows, Hin, KW, x_step_h, pad_h;              // 2-D extension (1-D: Wrows = Trows, Hin = 1, KW = taps)
+    FastDiv fd_trows, fd_wrows;
     const float *arow, *oscale; float* dW; int64_t ldw; float* db; int chunk, splits;
     int64_t sYb, sXb, sWb, sDb;
 };
@@ -573,6 +604,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_bias = (p.db != nullptr) && (blockIdx.y == 0);
+    const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
 
     uint4 ra[4], rb[4];
     auto gload = [&](int mk) {
@@ -587,9 +619,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
                     y = ld4_any(dY, p.y_bf16, (int64_t)m * p.ldy + n, p.N - n, y_vec);
                     if (arow) { const float s = arow[m]; y.x *= s; y.y *= s; y.z *= s; y.w *= s; }
                 }
-                const int u = m / p.Trows, t = m - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
-                const int kh = j / p.KW, kw = j - kh * p.KW;
-                const int tt = tw * p.x_step + kw - p.pad, hh = th * p.x_step_h + kh - p.pad_h;
+                const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+                const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
                 const int c = c0 + 4 * c4;
                 if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin && c < p.Cin)
                     x = ld4_any(X, p.x_bf16, (((int64_t)u * p.Hin + hh) * p.Tin + tt) * p.ldx + c, p.Cin - c, x_vec);
@@ -618,7 +649,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
     // ---- fast path: both operands bf16 with 16-byte rows.  Threads 0-127 stage the dY tile, 128-255 the X tile:
     // 8 frames x 8 channels per thread (eight 16-byte loads), 8x8 bf16 transpose in registers, eight ds_write_b128.
     constexpr bool fast = FAST;
-    const int half = tid >> 7, ht = tid & 127, fkg = ht >> 4, c8 = ht & 15;
+    // lane -> (k-group, column-group): k-group fastest, so the 8 lanes of a ds_write_b128 group fill 128 contiguous
+    // bytes of ONE LDS row (column-group fastest put all 8 lanes on the same banks: 8-way conflict)
+    const int half = tid >> 7, ht = tid & 127, fkg = ht & 7, c8 = ht >> 3;
     uint4 r8[8];
     float bs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto gload_fast = [&](int mk) {
@@ -631,9 +664,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
                     const int n = n0 + 8 * c8;
                     if (n < p.N) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dY) + (int64_t)m * p.ldy + n);
                 } else {
-                    const int u = m / p.Trows, t = m - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
-                    const int kh = j / p.KW, kw = j - kh * p.KW, c = c0 + 8 * c8;
-                    const int tt = tw * p.x_step + kw - p.pad, hh = th * p.x_step_h + kh - p.pad_h;
+                    const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+                    const int c = c0 + 8 * c8;
+                    const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
                     if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin && c < p.Cin)
                         v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + (((int64_t)u * p.Hin + hh) * p.Tin + tt) * p.ldx + c);
                 }
@@ -688,7 +721,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (n >= p.N) continue;
-                atomicAdd(dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c, (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r]);
+                float* dst = dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c;
+                const float val = (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r];
+                if (p.splits == 1) *dst += val;            // this block owns the tile: no atomics
+                else atomicAdd(dst, val);
             }
         }
     if (do_bias) {
@@ -726,8 +762,9 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     p.pad = (int)pad; p.x_step = (int)x_step; p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db;
     p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb;
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.x_step_h = (int)d2[3]; p.pad_h = (int)d2[4];
+    p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
-    int64_t splits = cdiv(512, tiles);
+    int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
     if (chunk < 2 * TBK) chunk = 2 * TBK;
     splits = cdiv(M, chunk);

@@ -45,4 +45,9 @@ for k, v in agg.items():
 for k, v in sorted(byname.items(), key=lambda kv: -kv[1][0]):
     print(f"  {v[0]/N:8.3f} ms/step  x{v[1]/N:6.1f}  {k}")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("TOP", "30"))]:
-    print(f"{v[0]/N:8.3f} ms/step  x{v[1]/N:5.1f}  avg {v[0]/v[1]*1e3:8.1f} us  {k}")
+    tf = ""
+    if k[0] == "osp_conv2d_gemm_bf16":
+        tf = f"{2.0*k[2]*k[4]*k[6]*k[8]/(v[0]/v[1]*1e-3)/1e12:6.0f} TF"
+    if k[0] == "osp_conv2d_wgrad_bf16":
+        tf = f"{2.0*k[2]*k[4]*k[6]*k[8]/(v[0]/v[1]*1e-3)/1e12:6.0f} TF"
+    print(f"{v[0]/N:8.3f} ms/step  x{v[1]/N:5.1f}  avg {v[0]/v[1]*1e3:8.1f} us {tf}  {k}")
