@@ -107,8 +107,8 @@ __device__ __forceinline__ void mma_tile_bf16(const unsigned short* __restrict__
 // The epilogue kind is a template parameter so that every instantiation is a small, fully unrolled, statically indexed
 // loop over the 64 accumulator values: a run-time `switch` inside the loop kept it from unrolling and pushed the
 // accumulators to scratch (tens of microseconds per workgroup on the short-K convolutions).
-template <int EPI>
-__device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+template <int EPI, int TM_, int TN_>
+__device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wm0, int wn0,
                                                      int lane, int64_t bz) {
     const int esC = pp.c_bf16 ? 2 : 4;
     char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * esC;
@@ -122,9 +122,9 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     const int64_t ldc = pp.ldc, ld_aux = pp.ld_aux, ldr = pp.ldr;
     const float slope = pp.slope;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM_; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN_; ++j) {
             const int n = n0 + wn0 + 32 * j + l31;
             const bool n_ok = n < N;
             const float bias = (pp.bias && n_ok) ? pp.bias[n] : 0.f;
@@ -170,26 +170,27 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
         }
 }
 
-__device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc)[2][2], int m0, int n0, int wm0, int wn0,
+template <int TM_, int TN_>
+__device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wm0, int wn0,
                                                    int lane, int64_t bz) {
     switch (pp.epi) {
-        case BEPI_RELU: gemm_bf16_epilogue_t<BEPI_RELU>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_GELU: gemm_bf16_epilogue_t<BEPI_GELU>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_SCALE_RES_MASK: gemm_bf16_epilogue_t<BEPI_SCALE_RES_MASK>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_GELU_BWD: gemm_bf16_epilogue_t<BEPI_GELU_BWD>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_RELU_BWD: gemm_bf16_epilogue_t<BEPI_RELU_BWD>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_AXMY: gemm_bf16_epilogue_t<BEPI_AXMY>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_MASK: gemm_bf16_epilogue_t<BEPI_MASK>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_LRELU: gemm_bf16_epilogue_t<BEPI_LRELU>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_LRELU_BWD: gemm_bf16_epilogue_t<BEPI_LRELU_BWD>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        default: gemm_bf16_epilogue_t<BEPI_NONE>(pp, acc, m0, n0, wm0, wn0, lane, bz);
+        case BEPI_RELU: gemm_bf16_epilogue_t<BEPI_RELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_GELU: gemm_bf16_epilogue_t<BEPI_GELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_SCALE_RES_MASK: gemm_bf16_epilogue_t<BEPI_SCALE_RES_MASK, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_GELU_BWD: gemm_bf16_epilogue_t<BEPI_GELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_RELU_BWD: gemm_bf16_epilogue_t<BEPI_RELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_AXMY: gemm_bf16_epilogue_t<BEPI_AXMY, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_MASK: gemm_bf16_epilogue_t<BEPI_MASK, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_LRELU: gemm_bf16_epilogue_t<BEPI_LRELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        case BEPI_LRELU_BWD: gemm_bf16_epilogue_t<BEPI_LRELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
+        default: gemm_bf16_epilogue_t<BEPI_NONE, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 // FAST: every operand row is 16-byte addressable (Cin % 8 == 0, aligned strides, no per-row A scale) -- the generic
 // element-wise loaders are not even compiled into that instantiation (they bloat the loop past the I-cache).
-template <bool B_KCONTIG, int BKT, bool FAST>
+template <bool B_KCONTIG, int BKT, bool FAST, int BM_, int BN_>
 __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
     // hot-loop scalars in registers (the by-value struct must not be addressed inside the K loop)
     struct { int M, Trows, Wrows, Tin, Hin, Cin, taps, KW, a_step, a_step_h, a_off, a_off_h, a_tapstep, a_tapstep_h, N, a_bf16, b_bf16;
@@ -198,13 +199,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
     p.a_step = pp.a_step; p.a_step_h = pp.a_step_h; p.a_off = pp.a_off; p.a_off_h = pp.a_off_h; p.a_tapstep = pp.a_tapstep;
     p.a_tapstep_h = pp.a_tapstep_h; p.N = pp.N; p.a_bf16 = pp.a_bf16; p.b_bf16 = pp.b_bf16; p.lda = pp.lda; p.sBn = pp.sBn;
     p.sBtap = pp.sBtap; p.sBtap_h = pp.sBtap_h; p.sBk = pp.sBk; p.a_rowscale = pp.a_rowscale;
-    constexpr int LDK_ = BKT + 8, KG = BKT / 8, NI = TBM * KG / 256, RSTEP = 256 / KG;
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (TBM + TBN) * LDK_];
-    unsigned short* As = smem;                       // [2][TBM][LDK_]
-    unsigned short* Bs = smem + 2 * TBM * LDK_;      // [2][TBN][LDK_]
+    constexpr int LDK_ = BKT + 8, KG = BKT / 8, NI = BM_ * KG / 256, NJ = BN_ * KG / 256, RSTEP = 256 / KG;
+    constexpr int TM_ = BM_ / 64, TN_ = BN_ / 64;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BM_ + BN_) * LDK_];
+    unsigned short* As = smem;                       // [2][BM_][LDK_]
+    unsigned short* Bs = smem + 2 * BM_ * LDK_;      // [2][BN_][LDK_]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+    const int wm0 = (wave >> 1) * (BM_ / 2), wn0 = (wave & 1) * (BN_ / 2);
+    const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN_;
     const int64_t bz = blockIdx.z;
     const int esA = p.a_bf16 ? 2 : 4, esB = p.b_bf16 ? 2 : 4;
     const char* A = reinterpret_cast<const char*>(pp.A) + bz * pp.sAb * esA;
@@ -224,15 +226,15 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
             a_base[i] = (int64_t)u * p.Hin * p.Tin;
         } else { a_t[i] = -0x40000000; a_h[i] = 0; a_base[i] = 0; }
     }
-    f32x16 acc[2][2];
+    f32x16 acc[TM_][TN_];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM_; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN_; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[NI], rb[NI > 4 ? NI : 4];
+    uint4 ra[NI], rb[NJ > 4 ? NJ : 4];
     auto a_elem = [&](int i, int k) -> float {
         if (k >= K) return 0.f;
         const int j = k / p.Cin, c = k - j * p.Cin, kh = j / p.KW, kw = j - kh * p.KW;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
         }
         if constexpr (B_KCONTIG) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NJ; ++i) {
                 const int n = n0 + r0 + RSTEP * i;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (n < p.N && k0 < K) {
@@ -287,13 +289,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
         } else {
             // transposing loader: k-group kg (8 reduction rows) x 4 output columns per thread
             static_assert(BKT == 64, "the k-strided B loader is laid out for BK = 64");
-            const int kg = tid >> 5, n4 = tid & 31, nn = n0 + 4 * n4;
+            constexpr int N4 = BN_ / 4;                                  // column groups per tile
+            const int kg = tid / N4, n4 = tid % N4, nn = n0 + 4 * n4;     // kg >= 8 (only when BN_ < 128): idle
             float4 rows[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = kt * BKT + kg * 8 + q;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && nn < p.N) {
+                if (kg < 8 && k < K && nn < p.N) {
                     const int j = k / p.Cin, c = k - j * p.Cin, kh = j / p.KW, kw = j - kh * p.KW;
                     const int64_t off = (int64_t)c * p.sBk + (int64_t)kh * p.sBtap_h + (int64_t)kw * p.sBtap + nn;
                     if (FAST && nn + 3 < p.N) x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + off);
@@ -313,17 +316,20 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
         }
     };
     auto sstore = [&](int buf) {
-        unsigned short* as = As + buf * TBM * LDK_;
-        unsigned short* bs = Bs + buf * TBN * LDK_;
+        unsigned short* as = As + buf * BM_ * LDK_;
+        unsigned short* bs = Bs + buf * BN_ * LDK_;
 #pragma unroll
         for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(as + (r0 + RSTEP * i) * LDK_ + g * 8) = ra[i];
         if constexpr (B_KCONTIG) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(bs + (r0 + RSTEP * i) * LDK_ + g * 8) = rb[i];
+            for (int i = 0; i < NJ; ++i) *reinterpret_cast<uint4*>(bs + (r0 + RSTEP * i) * LDK_ + g * 8) = rb[i];
         } else {
-            const int kg = tid >> 5, n4 = tid & 31;
+            constexpr int N4 = BN_ / 4;
+            const int kg = tid / N4, n4 = tid % N4;
+            if (kg < 8) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(bs + (4 * n4 + q) * LDK_ + kg * 8) = rb[q];
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(bs + (4 * n4 + q) * LDK_ + kg * 8) = rb[q];
+            }
         }
     };
 
@@ -334,12 +340,12 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        mma_tile_bf16<2, 2, BKT>(As + buf * TBM * LDK_, Bs + buf * TBN * LDK_, wm0, wn0, lane, acc);
+        mma_tile_bf16<TM_, TN_, BKT>(As + buf * BM_ * LDK_, Bs + buf * BN_ * LDK_, wm0, wn0, lane, acc);
         if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
 
-    gemm_bf16_epilogue(pp, acc, m0, n0, wm0, wn0, lane, bz);
+    gemm_bf16_epilogue<TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz);
 }
 
 
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    gemm_bf16_epilogue(pp, acc, m0, n0, wm0, wn0, lane, bz);
+    gemm_bf16_epilogue<2, 2>(pp, acc, m0, n0, wm0, wn0, lane, bz);
 }
 
 // C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
@@ -485,7 +491,6 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     p.sAb = sAb; p.sBb = sBb; p.sCb = sCb; p.sXb = sXb; p.accumulate = (int)accumulate;
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
     p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
-    dim3 grid((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, TBM), (unsigned)batch);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int64_t ea = a_bf16 ? 2 : 4, eb = b_bf16 ? 2 : 4;
     const bool a_fast = (Cin % 8 == 0) && (lda % 8 == 0) && al16(A) && ((sAb * ea) % 16 == 0) && !a_rowscale;
@@ -494,20 +499,27 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
         fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && (d2[9] % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
     else
         fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && (d2[9] % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+    // tile shape: 128x128 by default; 128x64 for narrow outputs; 64x64 when the big tiles cannot fill the 256 CUs
+    int bm = 128, bn = 128;
+    if (N <= 64) bn = 64;
+    else if (cdiv(M, 128) * cdiv(N, 128) * batch < 160) { bm = 64; bn = 64; }
+    dim3 grid((unsigned)cdiv(N, bn), (unsigned)cdiv(M, bm), (unsigned)batch);
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("OSP_GEMM_GLDS"); use_glds = (e && atoi(e) == 0) ? 0 : 1; }
-    if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0)) {
+    if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 128) {
         hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), 0, stream, p);
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
-    if (sBk != 1) {
-        if (fast) hipLaunchKernelGGL((conv_gemm_bf16_kernel<false, 64, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<false, 64, false>), grid, dim3(256), 0, stream, p);
-    } else {
-        if (fast) hipLaunchKernelGGL((conv_gemm_bf16_kernel<true, 64, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<true, 64, false>), grid, dim3(256), 0, stream, p);
-    }
+#define OSP_LAUNCH_TILE(KC, F)                                                                                              \
+    do {                                                                                                                    \
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 128, 128>), grid, dim3(256), 0, stream, p); \
+        else if (bm == 128) hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 128, 64>), grid, dim3(256), 0, stream, p);  \
+        else hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 64, 64>), grid, dim3(256), 0, stream, p);                 \
+    } while (0)
+    if (sBk != 1) { if (fast) OSP_LAUNCH_TILE(false, true); else OSP_LAUNCH_TILE(false, false); }
+    else { if (fast) OSP_LAUNCH_TILE(true, true); else OSP_LAUNCH_TILE(true, false); }
+#undef OSP_LAUNCH_TILE
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

@@ -25,6 +25,30 @@ __device__ __forceinline__ float sc_tap_sample(const SmallCin& p, int64_t m, int
     return p.x[((int64_t)u * p.Hin + hh) * p.Win + ww];
 }
 
+// Broadcast of tap sample j inside a Cout-lane group.  With one row per wave (Cout == 64) the source lane is a
+// compile-time constant -> v_readlane_b32 (scalar broadcast, no LDS traffic); otherwise ds_bpermute via __shfl.
+template <int J>
+__device__ __forceinline__ float sc_bcast(float xs, int gbase, bool one_row) {
+    if (one_row) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), J));
+    return __shfl(xs, gbase + J, 64);
+}
+template <int J, int JMAX>
+struct ScFma {
+    static __device__ __forceinline__ void fwd(const float (&w)[SC_MAXTAPS], float xs, int gbase, bool one_row, int taps, float& acc) {
+        if (J < taps) acc = fmaf(w[J], sc_bcast<J>(xs, gbase, one_row), acc);
+        ScFma<J + 1, JMAX>::fwd(w, xs, gbase, one_row, taps, acc);
+    }
+    static __device__ __forceinline__ void bwd(float (&acc)[SC_MAXTAPS], float g, float xs, int gbase, bool one_row, int taps) {
+        if (J < taps) acc[J] = fmaf(g, sc_bcast<J>(xs, gbase, one_row), acc[J]);
+        ScFma<J + 1, JMAX>::bwd(acc, g, xs, gbase, one_row, taps);
+    }
+};
+template <int JMAX>
+struct ScFma<JMAX, JMAX> {
+    static __device__ __forceinline__ void fwd(const float (&)[SC_MAXTAPS], float, int, bool, int, float&) {}
+    static __device__ __forceinline__ void bwd(float (&)[SC_MAXTAPS], float, float, int, bool, int) {}
+};
+
 // rows per wave iteration RPW = 64 / Cout (Cout in {16, 32, 64}); requires taps <= Cout
 __global__ __launch_bounds__(256) void smallcin_fwd_kernel(SmallCin p) {
     const int lane = threadIdx.x & 63;
@@ -39,9 +63,7 @@ __global__ __launch_bounds__(256) void smallcin_fwd_kernel(SmallCin p) {
         const int64_t m = m0 + sub;
         const float xs = sc_tap_sample(p, m, n, dh, dw);
         float acc = bias;
-#pragma unroll
-        for (int j = 0; j < SC_MAXTAPS; ++j)
-            if (j < p.taps) acc = fmaf(w[j], __shfl(xs, gbase + j, 64), acc);
+        ScFma<0, SC_MAXTAPS>::fwd(w, xs, gbase, rpw == 1, p.taps, acc);
         if (m >= p.M) continue;
         if (p.lrelu) acc = acc > 0.f ? acc : acc * p.slope;
         if (p.y_bf16) reinterpret_cast<__bf16*>(const_cast<void*>(p.y))[m * p.Cout + n] = (__bf16)acc;
@@ -67,9 +89,7 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(SmallCin p) {
             g = p.y_bf16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(p.y)[m * p.Cout + n]) << 16)
                          : reinterpret_cast<const float*>(p.y)[m * p.Cout + n];
         bsum += g;
-#pragma unroll
-        for (int j = 0; j < SC_MAXTAPS; ++j)
-            if (j < p.taps) acc[j] = fmaf(g, __shfl(xs, gbase + j, 64), acc[j]);
+        ScFma<0, SC_MAXTAPS>::bwd(acc, g, xs, gbase, rpw == 1, p.taps);
     }
     // combine the `rpw` sub-rows of a wave (lanes n, n+Cout, ...), then the 4 waves, then one atomic per (n, j)
     for (int j = 0; j <= p.taps; ++j) {

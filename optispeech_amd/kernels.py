@@ -35,7 +35,7 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
     if out is None:
         shape = (batch, M, n_out) if batch > 1 else (M, n_out)
         out = torch.empty(shape, device=a.device, dtype=torch.float32)
-    if _precision.is_bf16() and ((M + 127) // 128) * ((n_out + 127) // 128) * batch >= 128:
+    if _precision.is_bf16() and M * n_out * cin * taps >= (1 << 22) and n_out >= 32:
         # performance mode: same contraction on the bf16 MFMA kernel (f32 storage, converted while staging)
         ldc_ = out.stride(-2) if ldc is None else ldc
         ld_aux_ = 0
