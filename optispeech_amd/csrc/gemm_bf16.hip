@@ -462,6 +462,168 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp
 //   forward strided conv : a_step = stride, a_tapstep = 1, a_off = -pad, Tc = Trows = T_out, c_step = 1, c_off = 0
 //   dgrad of a strided conv, phase r : see optispeech_amd/ops.py (MPD) -- rows q, t_in = r + stride*q
 // dtype flags: 0 = f32 storage, 1 = bf16 storage.
+// ------------------------------------------------------------------------------------------------ degenerate shapes
+// The discriminators' post convolutions (Cout = 1, _discriminators.py:60,160) and their dgrad (Cin = 1) are not GEMMs: a
+// 128-wide tile would be > 98 % padding.  They are HBM-bound streams over the activation (N = 1: read Cin*2 bytes per row
+// and tap; Cin = 1: write N*2 bytes per row), so they get VALU kernels that touch every byte once with 16-byte accesses.
+
+// one output element through the run-time epilogue (same semantics as gemm_bf16_epilogue_t)
+__device__ __forceinline__ void gemm_bf16_epi_elem(const GemmB& pp, float acc, int m, int n, int64_t bz) {
+    const float v = acc + (pp.bias ? pp.bias[n] : 0.f);
+    const int64_t mr = bz * pp.M + m;
+    const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+    const int64_t crow = (int64_t)u * pp.Tc + (int64_t)(th * pp.c_step_h + pp.c_off_h) * pp.Wc + (int64_t)tw * pp.c_step + pp.c_off;
+    const char* aux_in = pp.aux_in ? reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
+    float out = v;
+    switch (pp.epi) {
+        case BEPI_RELU: out = fmaxf(v, 0.f); break;
+        case BEPI_LRELU: out = v > 0.f ? v : v * pp.slope; break;
+        case BEPI_GELU:
+            if (pp.aux_out) (pp.aux_out + bz * pp.sXb)[crow * pp.ld_aux + n] = v;
+            out = gelu_f(v);
+            break;
+        case BEPI_SCALE_RES_MASK: {
+            if (pp.aux_out) (pp.aux_out + bz * pp.sXb)[crow * pp.ld_aux + n] = v;
+            const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
+            out = ((pp.res + bz * pp.sXb)[crow * pp.ldr + n] + rs * (pp.gamma ? pp.gamma[n] : 1.f) * v) * mk;
+            break;
+        }
+        case BEPI_GELU_BWD:
+            out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n));
+            break;
+        case BEPI_RELU_BWD: out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? v : 0.f; break;
+        case BEPI_LRELU_BWD: {
+            const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * pp.ldr + n) : 0.f;
+            out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? (v + e) : (v + e) * pp.slope;
+            break;
+        }
+        case BEPI_AXMY: out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) - v; break;
+        case BEPI_MASK: out = v * (pp.rowmask ? pp.rowmask[mr] : 1.f); break;
+        default: break;
+    }
+    const int esC = pp.c_bf16 ? 2 : 4;
+    char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * esC;
+    if (pp.c_bf16) reinterpret_cast<__bf16*>(Cb)[crow * pp.ldc + n] = (__bf16)out;
+    else {
+        float* dst = reinterpret_cast<float*>(Cb) + crow * pp.ldc + n;
+        *dst = pp.accumulate ? (*dst + out) : out;
+    }
+}
+
+__device__ __forceinline__ float dot8_bf16(const uint4 a, const uint4 b, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.x), __builtin_bit_cast(bf16x2, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.y), __builtin_bit_cast(bf16x2, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.z), __builtin_bit_cast(bf16x2, b.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.w), __builtin_bit_cast(bf16x2, b.w), acc, false);
+    return acc;
+}
+
+// N == 1: y[m] = epi(bias + sum_{tap, c} A[row(m, tap), c] * B[tap, c]).  L lanes share a row (each owns 16-byte channel
+// chunks lane, lane + L, ...), the weights (taps * Cin bf16) sit in LDS, products go through v_dot2c_f32_bf16.
+// Algorithmic bytes per row: taps * Cin * 2 read (L2 absorbs the tap overlap: unique bytes = Cin * 2) + 4 written.
+template <int L>
+__global__ __launch_bounds__(256) void conv_rowdot_bf16_kernel(const GemmB pp) {
+    extern __shared__ uint4 rd_w[];
+    const int C8 = pp.Cin >> 3, nchunk = pp.taps * C8;
+    for (int idx = threadIdx.x; idx < nchunk; idx += 256) {
+        const int tap = idx / C8, c8 = idx - tap * C8, kh = tap / pp.KW, kw = tap - kh * pp.KW;
+        rd_w[idx] = ld8_contig(pp.B, pp.b_bf16, kh * pp.sBtap_h + kw * pp.sBtap + c8 * 8, false);
+    }
+    __syncthreads();
+    const unsigned short* __restrict__ A = reinterpret_cast<const unsigned short*>(pp.A);
+    constexpr int RPB = 256 / L;
+    const int sub = threadIdx.x % L, rgrp = threadIdx.x / L;
+    const int KH = pp.taps / pp.KW;
+    for (int m = blockIdx.x * RPB + rgrp; m < pp.M; m += gridDim.x * RPB) {
+        const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+        const int at = tw * pp.a_step + pp.a_off, ah = th * pp.a_step_h + pp.a_off_h;
+        const int64_t base = (int64_t)u * pp.Hin * pp.Tin;
+        float acc = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int hh = ah + kh * pp.a_tapstep_h;
+            for (int kw = 0; kw < pp.KW; ++kw) {
+                const int tt = at + kw * pp.a_tapstep;
+                const bool ok = (unsigned)hh < (unsigned)pp.Hin && (unsigned)tt < (unsigned)pp.Tin;
+                const int64_t row = ok ? base + (int64_t)hh * pp.Tin + tt : 0;               // index select: the load stays unconditional
+                const uint4* __restrict__ ar = reinterpret_cast<const uint4*>(A + row * pp.lda);
+                const uint4* __restrict__ wr = rd_w + (kh * pp.KW + kw) * C8;
+                float d = 0.f;
+                for (int c8 = sub; c8 < C8; c8 += L) d = dot8_bf16(ar[c8], wr[c8], d);
+                acc += ok ? d : 0.f;
+            }
+        }
+#pragma unroll
+        for (int o = L >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (sub == 0) gemm_bf16_epi_elem(pp, acc, m, 0, 0);
+    }
+}
+
+// Cin == 1: y[m, n] = epi(bias[n] + sum_tap A[row(m, tap)] * B[n, tap]), taps <= 9.  One thread owns 8 consecutive n
+// (weights in registers) and walks rows; the LRELU_BWD epilogue on bf16 operands is vectorised (16-byte aux / res / C).
+// Algorithmic bytes per row: N * 2 written (+ N * 2 per bf16 epilogue operand read).
+#define OUTER_MAXT 9
+__global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
+    const int N8 = pp.N >> 3, rpb = 256 / N8 > 0 ? 256 / N8 : 1;
+    const int n8 = threadIdx.x % N8, rgrp = threadIdx.x / N8;
+    if (rgrp >= rpb) return;
+    const int n = n8 * 8;
+    float w[OUTER_MAXT][8], bias[8];
+#pragma unroll
+    for (int tap = 0; tap < OUTER_MAXT; ++tap) {
+        const int tp = tap < pp.taps ? tap : 0, kh = tp / pp.KW, kw = tp - kh * pp.KW;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float v = ld_elem(pp.B, pp.b_bf16, (int64_t)(n + q) * pp.sBn + kh * pp.sBtap_h + kw * pp.sBtap);
+            w[tap][q] = tap < pp.taps ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bias[q] = pp.bias ? pp.bias[n + q] : 0.f;
+    const bool vec_epi = pp.epi == BEPI_LRELU_BWD && pp.c_bf16 && pp.aux_bf16 && (!pp.res_any || pp.res_bf16) &&
+                         (pp.ldc & 7) == 0 && (pp.ld_aux & 7) == 0 && (pp.ldr & 7) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(pp.C) | reinterpret_cast<uintptr_t>(pp.aux_in) |
+                           reinterpret_cast<uintptr_t>(pp.res_any)) & 15) == 0;
+    for (int m = blockIdx.x * rpb + rgrp; m < pp.M; m += gridDim.x * rpb) {
+        const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+        const int at = tw * pp.a_step + pp.a_off, ah = th * pp.a_step_h + pp.a_off_h;
+        const int64_t base = (int64_t)u * pp.Hin * pp.Tin;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < OUTER_MAXT; ++tap) {
+            const int tp = tap < pp.taps ? tap : 0, kh = tp / pp.KW, kw = tp - kh * pp.KW;
+            const int hh = ah + kh * pp.a_tapstep_h, tt = at + kw * pp.a_tapstep;
+            const bool ok = tap < pp.taps && (unsigned)hh < (unsigned)pp.Hin && (unsigned)tt < (unsigned)pp.Tin;
+            const int64_t row = ok ? base + (int64_t)hh * pp.Tin + tt : 0;
+            const float a = ld_elem(pp.A, pp.a_bf16, row * pp.lda);
+            const float as = ok ? a : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fmaf(as, w[tap][q], acc[q]);
+        }
+        if (vec_epi) {
+            const int64_t crow = (int64_t)u * pp.Tc + (int64_t)(th * pp.c_step_h + pp.c_off_h) * pp.Wc + (int64_t)tw * pp.c_step + pp.c_off;
+            const uint4 y = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(pp.aux_in) + crow * pp.ld_aux + n);
+            uint4 e = make_uint4(0, 0, 0, 0);
+            if (pp.res_any) e = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(pp.res_any) + crow * pp.ldr + n);
+            const unsigned yy[4] = {y.x, y.y, y.z, y.w}, ee[4] = {e.x, e.y, e.z, e.w};
+            unsigned oo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y0 = __uint_as_float(yy[q] << 16), y1 = __uint_as_float(yy[q] & 0xffff0000u);
+                const float v0 = acc[2 * q] + bias[2 * q] + __uint_as_float(ee[q] << 16);
+                const float v1 = acc[2 * q + 1] + bias[2 * q + 1] + __uint_as_float(ee[q] & 0xffff0000u);
+                oo[q] = pk2(y0 > 0.f ? v0 : v0 * pp.slope, y1 > 0.f ? v1 : v1 * pp.slope);
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(pp.C) + crow * pp.ldc + n) = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+        } else {
+            GemmB q = pp; q.bias = nullptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gemm_bf16_epi_elem(q, acc[e] + bias[e], m, n + e, 0);
+        }
+    }
+}
+
 static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
                                   int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
                                   const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
@@ -499,6 +661,27 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
         fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && (d2[9] % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
     else
         fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && (d2[9] % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+    static int use_degen = -1;
+    if (use_degen < 0) { const char* e = getenv("OSP_GEMM_DEGEN"); use_degen = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_degen && N == 1 && batch == 1 && a_bf16 && a_fast && sBk == 1 && taps * Cin * 2 <= 65536) {
+        const int c8 = (int)(Cin / 8);
+        const int L = c8 >= 64 ? 64 : (c8 >= 32 ? 32 : (c8 >= 16 ? 16 : (c8 >= 8 ? 8 : (c8 >= 4 ? 4 : (c8 >= 2 ? 2 : 1)))));
+        const int64_t nb = cdiv(M, 256 / L);
+        const dim3 grid((unsigned)(nb < 4096 ? nb : 4096));
+        const size_t lds = (size_t)taps * Cin * 2;
+#define OSP_ROWDOT(L_) hipLaunchKernelGGL((conv_rowdot_bf16_kernel<L_>), grid, dim3(256), lds, stream, p)
+        switch (L) { case 64: OSP_ROWDOT(64); break; case 32: OSP_ROWDOT(32); break; case 16: OSP_ROWDOT(16); break;
+                     case 8: OSP_ROWDOT(8); break; case 4: OSP_ROWDOT(4); break; case 2: OSP_ROWDOT(2); break; default: OSP_ROWDOT(1); }
+#undef OSP_ROWDOT
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
+    if (use_degen && Cin == 1 && batch == 1 && !a_rowscale && taps <= OUTER_MAXT && N % 8 == 0 && N >= 8 && N <= 2048) {
+        const int64_t rpb = 256 / (N / 8) > 0 ? 256 / (N / 8) : 1, nb = cdiv(M, rpb * 4);
+        hipLaunchKernelGGL(conv_outer_bf16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, p);
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
     // tile shape: 128x128 by default; 128x64 for narrow outputs; 64x64 when the big tiles cannot fill the 256 CUs
     int bm = 128, bn = 128;
     if (N <= 64) bn = 64;

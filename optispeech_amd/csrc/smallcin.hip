@@ -7,6 +7,7 @@
 // Row geometry is the 2-D map of gemm_bf16.hip: m -> (u, th, tw); tap j -> (kh, kw);
 //   in = ((u*Hin + th*sh + kh - ph) * Win + tw*sw + kw - pw), zero outside [0,Hin) x [0,Win).
 #include "osp_common.h"
+#include <cstdlib>
 
 #define SC_MAXTAPS 40
 
@@ -110,9 +111,173 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_kernel(SmallCin p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ MFMA variants (bf16 y / dy)
+// The VALU kernels above are issue-bound (2 instructions per tap per row per wave, one dependent load per row).  With bf16
+// activations the same contraction maps on v_mfma_f32_32x32x16_bf16 with the taps as the (zero-padded) K dimension:
+//   forward : D[i = row][j = n]   = sum_tap X[row][tap] * W[tap][n]      (K = taps padded to 16 * KSTEPS)
+//   wgrad   : D[i = tap][j = n]   = sum_row X[row][tap] * dY[row][n]      (K = rows, 16 per MFMA; tap == taps is a column of ones = db)
+// X fragments are gathered straight from global memory (the (kh, kw) window of a row is a few cache lines that the taps of
+// the same and of neighbouring rows re-read through L1/L2); no LDS staging is needed because the kernels are bound by the
+// y / dy stream (Cout * 2 bytes per row), not by the gathers.
+typedef float sc_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 sc_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KSTEPS, int NT>
+__global__ __launch_bounds__(256) void smallcin_fwd_mfma_kernel(SmallCin p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5;
+    sc_bf16x8 bw[KSTEPS][NT];
+    int toff[KSTEPS][8], tdh[KSTEPS][8], tdw[KSTEPS][8];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tap = ks * 16 + kg * 8 + q, kh = tap / p.KW, kw = tap - kh * p.KW;
+            tdh[ks][q] = tap < p.taps ? kh : (1 << 20);                       // padded taps fail the row bound check
+            tdw[ks][q] = kw;
+            toff[ks][q] = kh * p.Win + kw;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+            {
+                const float wv = p.w[(nt * 32 + li) * p.taps + (tap < p.taps ? tap : 0)];   // unconditional load
+                bw[ks][nt][q] = (__bf16)(tap < p.taps ? wv : 0.f);
+            }
+        }
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = p.b ? p.b[nt * 32 + li] : 0.f;
+    const int ntiles = (p.M + 31) >> 5;
+    const int nwaves = gridDim.x * 4;
+    __bf16* __restrict__ y = reinterpret_cast<__bf16*>(const_cast<void*>(p.y));
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+        const int m = tile * 32 + li;
+        const bool valid = m < p.M;
+        const int mm = valid ? m : p.M - 1;
+        const int u = mm / p.Trows, t = mm - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
+        const int h0 = th * p.sh - p.ph, w0 = tw * p.sw - p.pw;
+        const int xbase = (u * p.Hin + h0) * p.Win + w0;                            // < 2^31 elements (checked on the host)
+        sc_f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        // the f32 input sample (a spectrogram magnitude / wav sample with a wide dynamic range) enters as hi + lo bf16
+        // halves, i.e. with ~16 mantissa bits; the weights are bf16 like in every other layer of the bf16 mode
+        sc_bf16x8 a[KSTEPS], al[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int hh = h0 + tdh[ks][q], ww = w0 + tdw[ks][q];
+                const bool ok = valid && (unsigned)hh < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win;
+                const float xv = p.x[ok ? xbase + toff[ks][q] : 0];              // unconditional load, index select (no branch)
+                const float xs = ok ? xv : 0.f;
+                a[ks][q] = (__bf16)xs;
+                al[ks][q] = (__bf16)(xs - (float)a[ks][q]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bw[ks][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bw[ks][nt], acc[nt], 0, 0, 0);
+            }
+        const int row0 = tile * 32 + kg * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r >> 2) * 8 + (r & 3);
+                float v = acc[nt][r] + bias[nt];
+                if (p.lrelu) v = v > 0.f ? v : v * p.slope;
+                if (row < p.M) y[(int64_t)row * p.Cout + nt * 32 + li] = (__bf16)v;
+            }
+    }
+}
+
+// dw[n][tap] (tap < taps) and db[n] (the ones column tap == taps); TT = tap tiles of 32, NT = Cout / 32.
+template <int TT, int NT>
+__global__ __launch_bounds__(256) void smallcin_wgrad_mfma_kernel(SmallCin p) {
+    __shared__ float red[TT * NT * 16 * 64];
+    const int lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5, wv = threadIdx.x >> 6;
+    int tdh[TT], tdw[TT], toff[TT];
+    float tfill[TT];                                                          // value of a non-tap column: 1 for the bias column
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int tap = tt * 32 + li, kh = tap / p.KW, kw = tap - kh * p.KW;
+        tfill[tt] = tap == p.taps ? 1.f : 0.f;
+        tdh[tt] = tap < p.taps ? kh : (1 << 20); tdw[tt] = kw; toff[tt] = kh * p.Win + kw;
+    }
+    sc_f32x16 acc[TT][NT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][nt][r] = 0.f;
+    const unsigned short* __restrict__ dy = reinterpret_cast<const unsigned short*>(p.y);
+    const int Ho = p.Trows / p.Wrows;
+    const int nsteps = (p.M + 15) >> 4, nwaves = gridDim.x * 4;
+    for (int step = blockIdx.x * 4 + wv; step < nsteps; step += nwaves) {
+        const int m0 = step * 16 + kg * 8;
+        int u = m0 / p.Trows, t = m0 - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
+        sc_bf16x8 a[TT], al[TT], b[NT];                                        // x as hi + lo bf16 halves (see the forward kernel)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = m0 + q;
+            const bool valid = m < p.M;
+            const int h0 = th * p.sh - p.ph, w0 = tw * p.sw - p.pw;
+            const int xbase = (u * p.Hin + h0) * p.Win + w0;
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const int hh = h0 + tdh[tt], ww = w0 + tdw[tt];
+                const bool ok = valid && (unsigned)hh < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win;   // tdh = 2^20 for non-taps
+                const float xv = p.x[ok ? xbase + toff[tt] : 0];                   // unconditional load, index select (no branch)
+                const float xs = ok ? xv : (valid ? tfill[tt] : 0.f);
+                a[tt][q] = (__bf16)xs;
+                al[tt][q] = (__bf16)(xs - (float)a[tt][q]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned short raw = dy[(valid ? m : 0) * p.Cout + nt * 32 + li];
+                b[nt][q] = __builtin_bit_cast(__bf16, valid ? raw : (unsigned short)0);
+            }
+            if (++tw == p.Wrows) { tw = 0; if (++th == Ho) { th = 0; ++u; } }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tt], b[nt], acc[tt][nt], 0, 0, 0);
+                acc[tt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tt], b[nt], acc[tt][nt], 0, 0, 0);
+            }
+    }
+    // sum the 4 waves in LDS (wave 0 stores, the others add in turn), then one atomic per valid (tap, n)
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* s = red + ((tt * NT + nt) * 16 + r) * 64 + lane;
+                        *s = (w == 0 ? 0.f : *s) + acc[tt][nt][r];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < TT * NT * 16 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, tile = e >> 10, nt = tile % NT, tt = tile / NT;
+        const int tap = tt * 32 + (r >> 2) * 8 + (l >> 5) * 4 + (r & 3), n = nt * 32 + (l & 31);
+        if (tap < p.taps) atomicAdd(p.dw + n * p.taps + tap, red[e]);
+        else if (tap == p.taps && p.db) atomicAdd(p.db + n, red[e]);
+    }
+}
+
 static int smallcin_fill(SmallCin& p, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin, int64_t Win, int64_t Cout,
                          int64_t taps, int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw) {
-    if (!(Cout == 16 || Cout == 32 || Cout == 64) || taps < 1 || taps > SC_MAXTAPS || taps > Cout || taps % KW != 0 || M <= 0 ||
+    if (!(Cout == 16 || Cout == 32 || Cout == 64) || taps < 1 || taps > 63 || taps % KW != 0 || M <= 0 ||
         M % Trows != 0 || Trows % Wrows != 0)
         return 0;
     p.M = (int)M; p.Trows = (int)Trows; p.Wrows = (int)Wrows; p.Hin = (int)Hin; p.Win = (int)Win; p.Cout = (int)Cout;
@@ -128,7 +293,20 @@ extern "C" int osp_smallcin_conv_fwd(const float* x, const float* w, const float
     OSP_CHECK_ARG(x && w && y, "null operand");
     SmallCin p;
     OSP_CHECK_ARG(smallcin_fill(p, M, Trows, Wrows, Hin, Win, Cout, taps, KW, sh, sw, ph, pw), "unsupported small-Cin geometry");
+    OSP_CHECK_ARG(M * Cout < (1ll << 31) && (M / Trows) * Hin * Win < (1ll << 31), "small-Cin operand exceeds 32-bit indexing");
     p.x = x; p.w = w; p.b = b; p.y = y; p.y_bf16 = (int)y_bf16; p.dw = nullptr; p.db = nullptr; p.lrelu = (int)lrelu; p.slope = slope;
+    if (y_bf16 && (Cout == 32 || Cout == 64) && taps <= 48 && !getenv("OSP_SMALLCIN_VALU")) {
+        const int64_t tiles = cdiv(M, 32), nb = cdiv(tiles, 4);
+        const dim3 grid((unsigned)(nb < 512 ? nb : 512)), block(256);       // 2 blocks / CU: the per-wave weight prologue is amortised
+        const int ks = (int)cdiv(taps, 16);
+#define SC_FWD(KS, NT_) hipLaunchKernelGGL((smallcin_fwd_mfma_kernel<KS, NT_>), grid, block, 0, stream, p)
+        if (Cout == 32) { if (ks == 1) SC_FWD(1, 1); else if (ks == 2) SC_FWD(2, 1); else SC_FWD(3, 1); }
+        else            { if (ks == 1) SC_FWD(1, 2); else if (ks == 2) SC_FWD(2, 2); else SC_FWD(3, 2); }
+#undef SC_FWD
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
+    OSP_CHECK_ARG(taps <= Cout && taps <= SC_MAXTAPS, "unsupported small-Cin geometry");
     const int64_t blocks = cdiv(M, 4 * (64 / Cout) * 8);
     hipLaunchKernelGGL(smallcin_fwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p);
     OSP_LAUNCH_CHECK();
@@ -142,7 +320,19 @@ extern "C" int osp_smallcin_conv_wgrad(const float* x, const void* dy, int64_t y
     OSP_CHECK_ARG(x && dy && dw, "null operand");
     SmallCin p;
     OSP_CHECK_ARG(smallcin_fill(p, M, Trows, Wrows, Hin, Win, Cout, taps, KW, sh, sw, ph, pw), "unsupported small-Cin geometry");
+    OSP_CHECK_ARG(M * Cout < (1ll << 31) && (M / Trows) * Hin * Win < (1ll << 31), "small-Cin operand exceeds 32-bit indexing");
     p.x = x; p.w = nullptr; p.b = nullptr; p.y = dy; p.y_bf16 = (int)y_bf16; p.dw = dw; p.db = db; p.lrelu = 0; p.slope = 0.f;
+    if (y_bf16 && (Cout == 32 || Cout == 64) && taps < 64 && !getenv("OSP_SMALLCIN_VALU")) {
+        const int64_t steps = cdiv(M, 16), nb = cdiv(steps, 4 * 8);
+        const dim3 grid((unsigned)(nb < 256 ? nb : 256)), block(256);       // one atomic epilogue per block: keep the grid at 1 / CU
+#define SC_WG(TT_, NT_) hipLaunchKernelGGL((smallcin_wgrad_mfma_kernel<TT_, NT_>), grid, block, 0, stream, p)
+        if (Cout == 32) { if (taps < 32) SC_WG(1, 1); else SC_WG(2, 1); }
+        else            { if (taps < 32) SC_WG(1, 2); else SC_WG(2, 2); }
+#undef SC_WG
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
+    OSP_CHECK_ARG(taps <= Cout && taps <= SC_MAXTAPS, "unsupported small-Cin geometry");
     const int64_t blocks = cdiv(M, 4 * (64 / Cout) * 64);
     hipLaunchKernelGGL(smallcin_wgrad_kernel, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, stream, p);
     OSP_LAUNCH_CHECK();

@@ -214,3 +214,38 @@ def test_gan_components_bf16_vs_f32_grads(golden, comp):
         assert abs(na - nb) <= 6e-2 * na, (k, na, nb)
         cos = torch.nn.functional.cosine_similarity(a[k].flatten(), b[k].flatten(), dim=0).item()
         assert cos > 0.98, (k, cos)
+
+
+@pytest.mark.parametrize("U,Hin,Win,cout,KH,KW,sh,sw,ph,pw", [
+    (3, 1, 1000, 32, 1, 5, 1, 3, 0, 2),        # DiscriminatorP convs[0] on the period-folded wav (rows = period columns)
+    (4, 33, 129, 64, 7, 5, 2, 2, 3, 2),        # DiscriminatorR convs[0] on the spectrogram
+    (2, 9, 40, 64, 3, 3, 1, 1, 1, 1),
+    (1, 5, 7, 32, 3, 9, 1, 2, 1, 4),
+])
+def test_smallcin_mfma_fwd_wgrad(U, Hin, Win, cout, KH, KW, sh, sw, ph, pw):
+    """Cin = 1 layers on the MFMA small-Cin kernels vs torch conv2d (f32 x, bf16-rounded w, f32 accumulate)."""
+    from optispeech_amd import kernels as K
+    torch.manual_seed(0)
+    x = torch.randn(U, Hin, Win, device=DEV)
+    w = torch.randn(cout, KH * KW, device=DEV) * 0.2
+    b = torch.randn(cout, device=DEV)
+    Ho, Wo = (Hin + 2 * ph - KH) // sh + 1, (Win + 2 * pw - KW) // sw + 1
+    xr, wr = x, w.bfloat16().float()                                     # x enters as hi+lo bf16 halves (~f32), w as bf16
+    ref = torch.nn.functional.conv2d(xr[:, None], wr.view(cout, 1, KH, KW), b, stride=(sh, sw), padding=(ph, pw))
+    ref = torch.nn.functional.leaky_relu(ref, 0.1).permute(0, 2, 3, 1).reshape(-1, cout)
+    y = K.smallcin_fwd(x, w, b, U=U, Hin=Hin, Win=Win, Ho=Ho, Wo=Wo, cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw,
+                       slope=0.1, out_bf16=True)
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+    assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2), (y.float() - ref).abs().max().item()
+    dy = torch.randn(U * Ho * Wo, cout, device=DEV).bfloat16()
+    dw = torch.zeros(cout, KH * KW, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    K.smallcin_wgrad(x, dy, dw, db, U=U, Hin=Hin, Win=Win, Ho=Ho, Wo=Wo, cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+    g = dy.float().view(U, Ho, Wo, cout).permute(0, 3, 1, 2)
+    xp = torch.nn.functional.pad(xr[:, None], (pw, pw, ph, ph))
+    cols = torch.nn.functional.unfold(xp, (KH, KW), stride=(sh, sw))                     # (U, KH*KW, Ho*Wo)
+    dw_ref = torch.einsum("ukm,unm->nk", cols.double(), g.reshape(U, cout, -1).double()).float()
+    db_ref = g.sum((0, 2, 3))
+    scale = dw_ref.abs().max().item()
+    assert (dw - dw_ref).abs().max().item() <= 2e-3 * scale + 1e-3, ((dw - dw_ref).abs().max().item(), scale)
+    assert torch.allclose(db, db_ref, rtol=1e-3, atol=1e-2 + 1e-3 * db_ref.abs().max().item())
