@@ -158,10 +158,14 @@ def main():
     # stream, so sum(flops) / sum(time) is comparable with the kernel's average in the rocprofv3 summary under profiles/.
     if a.precision == "bf16":
         def select(name, args):
+            # exactly the launches conv_gemm_bf16_impl routes to conv_gemm_bf16_glds_kernel: bf16 A and B, k-contiguous B,
+            # Cin % 64 == 0, N > 64 and at least 160 tiles of 128x128 (csrc/gemm_bf16.hip, tile selection)
             if name == "osp_conv2d_gemm_bf16" and args[1] == 1 and args[18] == 1 and args[22] == 1 and args[8] % 64 == 0:
-                return 2.0 * args[3] * args[9] * args[8] * args[23]                  # M, taps, Cin, N
+                M_, N_ = args[3], args[23]
+                if N_ > 64 and -(-M_ // 128) * -(-N_ // 128) >= 160:
+                    return 2.0 * M_ * args[9] * args[8] * N_                          # M, taps, Cin, N
             return None
-        roof_kernel, roof_peak = "conv_gemm_bf16_glds_kernel (all MPD/MRD conv-GEMM forward + dgrad launches)", PEAK_BF16_MFMA_TFLOPS
+        roof_kernel, roof_peak = "conv_gemm_bf16_glds_kernel (MPD conv-GEMM forward + dgrad launches, N >= 128)", PEAK_BF16_MFMA_TFLOPS
     else:
         M = B * T_MEL
 

@@ -14,6 +14,7 @@
 // Sources whose reduction index is NOT the contiguous one (dgrad weights, both wgrad operands) go through a
 // transposing loader: 8 strided rows x float4 per thread, packed to k-contiguous 16-byte LDS slots.
 #include "osp_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -55,7 +56,8 @@ struct GemmB {
     const void* res_any; int res_bf16;   // LRELU_BWD extra addend (f32 or bf16)
     // 2-D (conv2d over channels-last (U,H,W,C)) extension; the 1-D case has Hin = 1, Wrows = Trows, KW = taps
     int Wrows, Hin, KW, a_step_h, a_tapstep_h, a_off_h, Wc, c_step_h, c_off_h; int64_t sBtap_h;
-    int64_t sAb, sBb, sCb, sXb; int accumulate;
+    int64_t sAb, sBb, sCb, sXb; int accumulate; int dbg;
+    FastDiv fd_trows, fd_wrows;
 };
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
@@ -107,9 +109,45 @@ __device__ __forceinline__ void mma_tile_bf16(const unsigned short* __restrict__
 // The epilogue kind is a template parameter so that every instantiation is a small, fully unrolled, statically indexed
 // loop over the 64 accumulator values: a run-time `switch` inside the loop kept it from unrolling and pushed the
 // accumulators to scratch (tens of microseconds per workgroup on the short-K convolutions).
+// lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ float dpp_swap1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+}
+
+template <int EPI>
+__device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, int64_t mr, int64_t crow, int n, float gam,
+                                                     const float* res, const char* aux_in, float* aux_out) {
+    float out = v;
+    if constexpr (EPI == BEPI_RELU) out = fmaxf(v, 0.f);
+    if constexpr (EPI == BEPI_LRELU) out = v > 0.f ? v : v * pp.slope;
+    if constexpr (EPI == BEPI_GELU) {
+        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+        out = gelu_f(v);
+    }
+    if constexpr (EPI == BEPI_SCALE_RES_MASK) {
+        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+        const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
+        out = (res[crow * pp.ldr + n] + rs * gam * v) * mk;
+    }
+    if constexpr (EPI == BEPI_GELU_BWD)
+        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n));
+    if constexpr (EPI == BEPI_RELU_BWD) out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? v : 0.f;
+    if constexpr (EPI == BEPI_LRELU_BWD) {   // (acc + extra) * lrelu'(y)
+        const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * pp.ldr + n) : 0.f;
+        out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? (v + e) : (v + e) * pp.slope;
+    }
+    if constexpr (EPI == BEPI_AXMY)
+        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) - v;
+    if constexpr (EPI == BEPI_MASK) out = v * (pp.rowmask ? pp.rowmask[mr] : 1.f);
+    return out;
+}
+
+// Row geometry (two divisions per row, done with the multiply-high dividers) is computed once per accumulator row and
+// shared by the TN_ column tiles.  bf16 destinations are written as 4-byte pairs: lanes n / n+1 swap the values of two
+// consecutive rows (DPP), the even lane stores (row r, cols n..n+1), the odd lane (row r+1, cols n-1..n).
 template <int EPI, int TM_, int TN_>
 __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wm0, int wn0,
-                                                     int lane, int64_t bz) {
+                                                     int lane, int64_t bz, unsigned short* stage) {
     const int esC = pp.c_bf16 ? 2 : 4;
     char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * esC;
     const float* res = pp.res ? pp.res + bz * pp.sXb : nullptr;
@@ -119,72 +157,124 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     const bool c_bf16 = pp.c_bf16 != 0, accumulate = pp.accumulate != 0;
     const int Trows = pp.Trows, Wrows = pp.Wrows, Tc = pp.Tc, Wc = pp.Wc, c_step = pp.c_step, c_off = pp.c_off,
               c_step_h = pp.c_step_h, c_off_h = pp.c_off_h, M = pp.M, N = pp.N;
-    const int64_t ldc = pp.ldc, ld_aux = pp.ld_aux, ldr = pp.ldr;
-    const float slope = pp.slope;
+    const int64_t ldc = pp.ldc;
+    const FastDiv fd_trows = pp.fd_trows, fd_wrows = pp.fd_wrows;
+    const bool pair_ok = c_bf16 && (ldc & 1) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 3) == 0) && (N & 1) == 0;
+    // bf16 destinations with 16-byte addressable rows go through a wave-private LDS tile (the operand buffers are dead by
+    // now): the MFMA layout (lane = column) is turned into 16-byte row chunks, so every store instruction writes 8 full
+    // 128-byte lines instead of 64-byte fragments of 4 different lines.
+    constexpr int SP = 32 * TN_ + 8;                                              // staging pitch (elements)
+    const bool staged = stage != nullptr && pair_ok && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
+    float bias[TN_], gam[TN_];
+    int ncol[TN_];
+#pragma unroll
+    for (int j = 0; j < TN_; ++j) {
+        ncol[j] = n0 + wn0 + 32 * j + l31;
+        const bool n_ok = ncol[j] < N;
+        bias[j] = (pp.bias && n_ok) ? pp.bias[ncol[j]] : 0.f;
+        gam[j] = (EPI == BEPI_SCALE_RES_MASK && pp.gamma && n_ok) ? pp.gamma[ncol[j]] : 1.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM_; ++i)
 #pragma unroll
-        for (int j = 0; j < TN_; ++j) {
-            const int n = n0 + wn0 + 32 * j + l31;
-            const bool n_ok = n < N;
-            const float bias = (pp.bias && n_ok) ? pp.bias[n] : 0.f;
-            const float gam = (EPI == BEPI_SCALE_RES_MASK && pp.gamma && n_ok) ? pp.gamma[n] : 1.f;
+        for (int rp = 0; rp < 8; ++rp) {                       // row pair (r, r + 1): consecutive rows m, m + 1
+            int64_t crow[2]; int mrow[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * rp + h;
                 const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m < M) {
-                    const int64_t mr = bz * M + m;
-                    const float v = acc[i][j][r] + bias;
-                    const int u = m / Trows, t = m - u * Trows, th = t / Wrows, tw = t - th * Wrows;
-                    const int64_t crow = (int64_t)u * Tc + (int64_t)(th * c_step_h + c_off_h) * Wc + (int64_t)tw * c_step + c_off;
-                    float out = v;
-                    if constexpr (EPI == BEPI_RELU) out = fmaxf(v, 0.f);
-                    if constexpr (EPI == BEPI_LRELU) out = v > 0.f ? v : v * slope;
-                    if constexpr (EPI == BEPI_GELU) {
-                        if (aux_out) aux_out[crow * ld_aux + n] = v;
-                        out = gelu_f(v);
+                mrow[h] = m;
+                const int u = fd_div(m, fd_trows), t = m - u * Trows, th = fd_div(t, fd_wrows), tw = t - th * Wrows;
+                crow[h] = (int64_t)u * Tc + (int64_t)(th * c_step_h + c_off_h) * Wc + (int64_t)tw * c_step + c_off;
+            }
+#pragma unroll
+            for (int j = 0; j < TN_; ++j) {
+                const int n = ncol[j];
+                const bool n_ok = n < N;
+                float out[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    out[h] = 0.f;
+                    if (n_ok && mrow[h] < M)
+                        out[h] = gemm_bf16_epi_value<EPI>(pp, acc[i][j][2 * rp + h] + bias[j], bz * M + mrow[h], crow[h], n, gam[j],
+                                                          res, aux_in, aux_out);
+                }
+                if (pair_ok) {
+                    const bool odd = (lane & 1) != 0;
+                    const float give = odd ? out[0] : out[1], got = dpp_swap1(give);
+                    const int h = odd ? 1 : 0;
+                    if (staged) {
+                        const int r = 2 * rp + h, lrow = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        *reinterpret_cast<unsigned*>(stage + lrow * SP + 32 * j + (l31 & ~1)) = odd ? pk2(got, out[1]) : pk2(out[0], got);
+                    } else if (n_ok && mrow[h] < M) {
+                        const unsigned pk = odd ? pk2(got, out[1]) : pk2(out[0], got);
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(Cb) + crow[h] * ldc + (n & ~1)) = pk;
                     }
-                    if constexpr (EPI == BEPI_SCALE_RES_MASK) {
-                        if (aux_out) aux_out[crow * ld_aux + n] = v;
-                        const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
-                        out = (res[crow * ldr + n] + rs * gam * v) * mk;
-                    }
-                    if constexpr (EPI == BEPI_GELU_BWD)
-                        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n));
-                    if constexpr (EPI == BEPI_RELU_BWD) out = ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n) > 0.f ? v : 0.f;
-                    if constexpr (EPI == BEPI_LRELU_BWD) {   // (acc + extra) * lrelu'(y)
-                        const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * ldr + n) : 0.f;
-                        out = ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n) > 0.f ? (v + e) : (v + e) * slope;
-                    }
-                    if constexpr (EPI == BEPI_AXMY)
-                        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * ld_elem(aux_in, pp.aux_bf16, crow * ld_aux + n) - v;
-                    if constexpr (EPI == BEPI_MASK) out = v * (pp.rowmask ? pp.rowmask[mr] : 1.f);
-                    if (c_bf16) {
-                        reinterpret_cast<__bf16*>(Cb)[crow * ldc + n] = (__bf16)out;
-                    } else {
-                        float* dst = reinterpret_cast<float*>(Cb) + crow * ldc + n;
-                        *dst = accumulate ? (*dst + out) : out;
-                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (n_ok && mrow[h] < M) {
+                            if (c_bf16) reinterpret_cast<__bf16*>(Cb)[crow[h] * ldc + n] = (__bf16)out[h];
+                            else {
+                                float* dst = reinterpret_cast<float*>(Cb) + crow[h] * ldc + n;
+                                *dst = accumulate ? (*dst + out[h]) : out[h];
+                            }
+                        }
                 }
             }
         }
+    if (staged) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int CPR = 4 * TN_;                                              // 16-byte chunks per staged row
+        constexpr int RPI = 64 / CPR;                                             // rows per wave instruction
+        const int cc = lane % CPR, rr = lane / CPR;
+#pragma unroll
+        for (int it = 0; it < 32 * TM_ / RPI; ++it) {
+            const int lrow = it * RPI + rr, m = m0 + wm0 + lrow, n = n0 + wn0 + cc * 8;
+            if (m < M && n < N) {
+                const int u = fd_div(m, fd_trows), t = m - u * Trows, th = fd_div(t, fd_wrows), tw = t - th * Wrows;
+                const int64_t crow = (int64_t)u * Tc + (int64_t)(th * c_step_h + c_off_h) * Wc + (int64_t)tw * c_step + c_off;
+                *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(Cb) + crow * ldc + n) =
+                    *reinterpret_cast<const uint4*>(stage + lrow * SP + cc * 8);
+            }
+        }
+    }
 }
 
 template <int TM_, int TN_>
 __device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wm0, int wn0,
-                                                   int lane, int64_t bz) {
+                                                   int lane, int64_t bz, unsigned short* stage = nullptr) {
     switch (pp.epi) {
-        case BEPI_RELU: gemm_bf16_epilogue_t<BEPI_RELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_GELU: gemm_bf16_epilogue_t<BEPI_GELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_SCALE_RES_MASK: gemm_bf16_epilogue_t<BEPI_SCALE_RES_MASK, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_GELU_BWD: gemm_bf16_epilogue_t<BEPI_GELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_RELU_BWD: gemm_bf16_epilogue_t<BEPI_RELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_AXMY: gemm_bf16_epilogue_t<BEPI_AXMY, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_MASK: gemm_bf16_epilogue_t<BEPI_MASK, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_LRELU: gemm_bf16_epilogue_t<BEPI_LRELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        case BEPI_LRELU_BWD: gemm_bf16_epilogue_t<BEPI_LRELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz); break;
-        default: gemm_bf16_epilogue_t<BEPI_NONE, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz);
+        case BEPI_RELU: gemm_bf16_epilogue_t<BEPI_RELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_GELU: gemm_bf16_epilogue_t<BEPI_GELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_SCALE_RES_MASK: gemm_bf16_epilogue_t<BEPI_SCALE_RES_MASK, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_GELU_BWD: gemm_bf16_epilogue_t<BEPI_GELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_RELU_BWD: gemm_bf16_epilogue_t<BEPI_RELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_AXMY: gemm_bf16_epilogue_t<BEPI_AXMY, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_MASK: gemm_bf16_epilogue_t<BEPI_MASK, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_LRELU: gemm_bf16_epilogue_t<BEPI_LRELU, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        case BEPI_LRELU_BWD: gemm_bf16_epilogue_t<BEPI_LRELU_BWD, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage); break;
+        default: gemm_bf16_epilogue_t<BEPI_NONE, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, stage);
     }
+}
+
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs in linear block order (x fastest), and each
+// XCD has its own 4 MB L2.  The linear id is first folded so that every XCD owns one contiguous range of tile ids, then
+// tiles are ordered in groups of 8 row blocks x all column blocks: the ~64 workgroups resident on one XCD share 8 A row
+// panels and the B column panels through that XCD's L2 instead of streaming 64 different A panels from HBM.
+__device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
+    const int NB = gridDim.x, MB = gridDim.y, total = NB * MB;
+    const int lin = blockIdx.y * NB + blockIdx.x;
+    const int xcd = lin & 7, local = lin >> 3;
+    const int per = total >> 3, rem = total & 7;               // XCDs < rem own per + 1 tiles
+    const int pid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + local;
+    constexpr int GM = 8;
+    const int gsize = GM * NB, group = pid / gsize, first = group * GM;
+    const int gm = MB - first < GM ? MB - first : GM;
+    const int in_g = pid - group * gsize;
+    mb = first + in_g % gm;
+    nb = in_g / gm;
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
@@ -206,7 +296,9 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
     unsigned short* Bs = smem + 2 * BM_ * LDK_;      // [2][BN_][LDK_]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (BM_ / 2), wn0 = (wave & 1) * (BN_ / 2);
-    const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN_;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_);
+    const int m0 = mb_ * BM_, n0 = nb_ * BN_;
     const int64_t bz = blockIdx.z;
     const int esA = p.a_bf16 ? 2 : 4, esB = p.b_bf16 ? 2 : 4;
     const char* A = reinterpret_cast<const char*>(pp.A) + bz * pp.sAb * esA;
@@ -345,7 +437,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
         __syncthreads();
     }
 
-    gemm_bf16_epilogue<TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz);
+    __syncthreads();                                  // operand tiles are dead: reuse them as the epilogue staging tiles
+    gemm_bf16_epilogue<TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * (32 * TN_ + 8));
 }
 
 
@@ -358,77 +451,122 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
 // Rows that fall into conv padding (or past M / N) read a zero page instead.
 __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
 
-__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp) {
-    __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * (TBM + TBN) * TBK];
-    unsigned short* As = smem;                       // [2][TBM][64]
-    unsigned short* Bs = smem + 2 * TBM * TBK;       // [2][TBN][64]
+// BM_ = 128: 4 waves of 64x64, two 32 KB stages, 2 workgroups / CU (prefetch distance 1; the second workgroup hides the wait).
+// BM_ = 256: 4 waves of 128x64 (128 accumulator registers), three 48 KB stages, 1 workgroup / CU, prefetch distance 2.
+//   Per k-slab a CU then reads (128 + 64) * 64 * 2 B * 4 waves = 96 KB of fragments for 2 * 256*128*64 flop, i.e. LDS
+//   traffic per flop is 2/3 of the 128x128 tile's (which is LDS-bandwidth bound: 96 KB + 32 KB DMA per 512 MFMA clocks).
+template <int BM_, int NST>
+__device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsigned short* smem) {
+    constexpr int RA = BM_ / 32, RB = TBN / 32, TM_ = BM_ / 64;   // rows staged per thread (A, B); 32x32 tiles per wave along M
+    unsigned short* As = smem;                       // [NST][BM_][64]
+    unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][TBN][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+    const int wm0 = (wave >> 1) * (BM_ / 2), wn0 = (wave & 1) * 64;
+    int mb_, nb_;
+    xcd_tile(mb_, nb_);
+    const int m0 = mb_ * BM_, n0 = nb_ * TBN;
     const int64_t bz = blockIdx.z;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(pp.A) + bz * pp.sAb;
     const unsigned short* B = reinterpret_cast<const unsigned short*>(pp.B) + bz * pp.sBb;
     const int Cin = pp.Cin, Tin = pp.Tin, Hin = pp.Hin, KW = pp.KW, a_tapstep = pp.a_tapstep, a_tapstep_h = pp.a_tapstep_h;
+    const int taps = pp.taps;
     const int64_t lda = pp.lda, sBn = pp.sBn, sBtap = pp.sBtap, sBtap_h = pp.sBtap_h;
-    const int K = pp.taps * Cin;
+    const int K = taps * Cin;
     const int rsub = lane >> 3, pslot = lane & 7;
-    int a_t[4], a_h[4]; int64_t a_base[4]; int64_t b_row[4];
+    // wave w stages rows 8 * (w * RA + i) + rsub of A (i < RA) and 8 * (w * RB + i) + rsub of B (i < RB)
+    int a_t[RA], a_h[RA]; int64_t a_base[RA]; int64_t b_row[RB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 8 * (wave * 4 + i) + rsub;
-        const int m = m0 + r;
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + 8 * (wave * RA + i) + rsub;
         if (m < pp.M) {
-            const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+            const int u = fd_div(m, pp.fd_trows), t = m - u * pp.Trows, th = fd_div(t, pp.fd_wrows), tw = t - th * pp.Wrows;
             a_t[i] = tw * pp.a_step + pp.a_off;
             a_h[i] = th * pp.a_step_h + pp.a_off_h;
             a_base[i] = (int64_t)u * Hin * Tin;
         } else { a_t[i] = -0x40000000; a_h[i] = 0; a_base[i] = 0; }
-        const int n = n0 + r;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + 8 * (wave * RB + i) + rsub;
         b_row[i] = n < pp.N ? (int64_t)n * sBn : -1;
     }
-    f32x16 acc[2][2];
+    // accumulators as 64-row halves: the epilogue is instantiated per half with compile-time indices only (one 512-byte
+    // array indexed through the epilogue's nested loops stayed a stack object and was stored to scratch every iteration)
+    f32x16 acc0[2][2], acc1[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
 
-    auto issue = [&](int kt, int buf) {
-        const int kbase = kt * TBK;
-        const int j = kbase / Cin, cb = kbase - j * Cin, kh = (KW == pp.taps) ? 0 : j / KW, kw = j - kh * KW;
+    // Staging state: per owned row a source pointer for the current tap (or the zero page, with a zero channel stride);
+    // advancing k inside a tap is one 64-bit add per row, the row / bounds arithmetic runs once per tap.
+    const unsigned short* a_src[RA]; const unsigned short* b_src[RB]; int a_inc[RA], b_inc[RB];
+    int cur_tap = -1;
+    auto set_tap = [&](int j) {
+        const int kh = (KW == taps) ? 0 : j / KW, kw = j - kh * KW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 8 * (wave * 4 + i) + rsub;
+        for (int i = 0; i < RA; ++i) {
+            const int r = 8 * (wave * RA + i) + rsub;
             const int q = pslot ^ ((r >> 1) & 7);
             const int tt = a_t[i] + kw * a_tapstep, hh = a_h[i] + kh * a_tapstep_h;
-            const unsigned short* src = zero;
-            if (tt >= 0 && tt < Tin && hh >= 0 && hh < Hin) src = A + (a_base[i] + (int64_t)hh * Tin + tt) * lda + cb + q * 8;
-            unsigned short* dst = As + buf * TBM * TBK + (wave * 4 + i) * 8 * TBK;       // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            const bool ok = tt >= 0 && tt < Tin && hh >= 0 && hh < Hin;
+            a_src[i] = ok ? A + (a_base[i] + (int64_t)hh * Tin + tt) * lda + q * 8 : zero;
+            a_inc[i] = ok ? 1 : 0;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 8 * (wave * 4 + i) + rsub;
+        for (int i = 0; i < RB; ++i) {
+            const int r = 8 * (wave * RB + i) + rsub;
             const int q = pslot ^ ((r >> 1) & 7);
-            const unsigned short* src = zero;
-            if (b_row[i] >= 0) src = B + b_row[i] + (int64_t)kh * sBtap_h + (int64_t)kw * sBtap + cb + q * 8;
-            unsigned short* dst = Bs + buf * TBN * TBK + (wave * 4 + i) * 8 * TBK;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            b_src[i] = b_row[i] >= 0 ? B + b_row[i] + (int64_t)kh * sBtap_h + (int64_t)kw * sBtap + q * 8 : zero;
+            b_inc[i] = b_row[i] >= 0 ? 1 : 0;
+        }
+        cur_tap = j;
+    };
+    int is_j = 0, is_cb = 0;                                   // (tap, channel offset) of the next k-slab to stage
+    // one of the RA + RB row loads of a slab (compile-time index): the loads are spread over the 4 k-steps of the MFMA
+    // phase -- issued back to back at the top of an iteration they queue behind each other in the texture-address unit
+    // (4 waves x 12 x 1 KB at 64 B/clk) and the MFMA pipe idles until the last one has been accepted.
+    auto issue_one = [&](int buf, auto idx) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I < RA) {
+            unsigned short* dst = As + buf * BM_ * TBK + (wave * RA + I) * 8 * TBK;      // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[I] + is_cb * a_inc[I]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else {
+            constexpr int J = I - RA;
+            unsigned short* dst = Bs + buf * TBN * TBK + (wave * RB + J) * 8 * TBK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[J] + is_cb * b_inc[J]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    auto mma = [&](int buf) {
-        const unsigned short* as = As + buf * TBM * TBK;
+    auto issue_quarter = [&](int buf, auto qidx) {             // loads [Q * NL / 4, (Q + 1) * NL / 4)
+        constexpr int Q = decltype(qidx)::value, NL = RA + RB, L0 = Q * NL / 4;
+        issue_one(buf, std::integral_constant<int, L0>{});
+        if constexpr (NL / 4 > 1) issue_one(buf, std::integral_constant<int, L0 + 1>{});
+        if constexpr (NL / 4 > 2) issue_one(buf, std::integral_constant<int, L0 + 2>{});
+    };
+    auto issue_begin = [&]() { if (is_j != cur_tap) set_tap(is_j); };          // wave-uniform branch
+    auto issue_end = [&]() { is_cb += TBK; if (is_cb == Cin) { is_cb = 0; ++is_j; } };
+    auto issue = [&](int buf) {
+        issue_begin();
+        issue_quarter(buf, std::integral_constant<int, 0>{}); issue_quarter(buf, std::integral_constant<int, 1>{});
+        issue_quarter(buf, std::integral_constant<int, 2>{}); issue_quarter(buf, std::integral_constant<int, 3>{});
+        issue_end();
+    };
+    // MFMA phase over slab `buf`; when `ld` >= 0 the next slab's loads go to buffer `ld`, a quarter per k-step
+    auto mma = [&](int buf, int ld) {
+        const unsigned short* as = As + buf * BM_ * TBK;
         const unsigned short* bs = Bs + buf * TBN * TBK;
         const int l31 = lane & 31, lh = lane >> 5;
+        if (ld >= 0) issue_begin();
+        auto kstep = [&](auto ksidx) {
+            constexpr int ks = decltype(ksidx)::value;
+            bf16x8 a[TM_], b[2];
 #pragma unroll
-        for (int ks = 0; ks < TBK / 16; ++ks) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM_; ++i) {
                 const int row = wm0 + 32 * i + l31;
                 a[i] = *reinterpret_cast<const bf16x8*>(as + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
             }
@@ -437,24 +575,62 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp
                 const int row = wn0 + 32 * j + l31;
                 b[j] = *reinterpret_cast<const bf16x8*>(bs + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
             }
+            if (ld >= 0) issue_quarter(ld, ksidx);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < 2; ++j) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc0[i][j], 0, 0, 0);
+                    if constexpr (TM_ == 4) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + i], b[j], acc1[i][j], 0, 0, 0);
+                }
+        };
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
+        if (ld >= 0) issue_end();
     };
     const int nk = K / TBK;
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-        mma(buf);
+    if constexpr (NST == 2) {
+        issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            mma(buf, kt + 1 < nk ? (buf ^ 1) : -1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // three stages, prefetch distance 2: slab kt+2 is issued into the buffer slab kt-1 was read from (every wave has
+        // passed this iteration's barrier, hence finished computing kt-1); the wait leaves slab kt+1's loads in flight.
+        issue(0);
+        if (nk > 1) issue(1);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // bare s_barrier: __syncthreads() carries a workgroup fence that the compiler lowers to vmcnt(0), which would
+            // drain slab kt+1's LDS-DMA loads at every iteration (i.e. no prefetch at all).  Every wave has waited for its
+            // own slab-kt loads above, so after the barrier the whole slab is in LDS; all ds_reads of the previous
+            // iteration have been consumed by MFMAs (lgkmcnt(0)) before a wave arrives here.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            mma(buf, kt + 2 < nk ? (buf >= 1 ? buf - 1 : 2) : -1);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        __syncthreads();
     }
-    gemm_bf16_epilogue<2, 2>(pp, acc, m0, n0, wm0, wn0, lane, bz);
+    gemm_bf16_epilogue<2, 2>(pp, acc0, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * 72);
+    if constexpr (TM_ == 4) gemm_bf16_epilogue<2, 2>(pp, acc1, m0, n0, wm0 + 64, wn0, lane, bz, smem + wave * (32 * TM_) * 72 + 64 * 72);
+}
+
+extern __shared__ __attribute__((aligned(1024))) unsigned short glds_smem[];
+__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp) {
+    conv_gemm_bf16_glds_body<128, 2>(pp, glds_smem);
+}
+// one workgroup per CU (144 KB of LDS): let the register allocator use the whole 512-entry file of a single wave / SIMD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_bf16_glds256_kernel(const GemmB pp) {
+    conv_gemm_bf16_glds_body<256, 3>(pp, glds_smem);
 }
 
 // C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
@@ -651,6 +827,8 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     p.res_any = res; p.res_bf16 = (int)res_bf16; p.rowmask = rowmask; p.rowscale = rowscale;
     p.aux_out = aux_out; p.aux_in = aux_in; p.aux_bf16 = (int)aux_bf16; p.ld_aux = ld_aux; p.slope = slope;
     p.sAb = sAb; p.sBb = sBb; p.sCb = sCb; p.sXb = sXb; p.accumulate = (int)accumulate;
+    { const char* e = getenv("OSP_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
     p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -690,13 +868,36 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("OSP_GEMM_GLDS"); use_glds = (e && atoi(e) == 0) ? 0 : 1; }
     if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 128) {
-        hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), 0, stream, p);
+        static int big = -1, attr_done = 0;
+        if (big < 0) { const char* e = getenv("OSP_GEMM_BIG"); big = (e && atoi(e) == 1) ? 1 : 0; }
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds256_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + TBN) * TBK * 2);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + TBN) * TBK * 2);
+            attr_done = 1;
+        }
+        // 256-row / three-stage variant: opt-in (OSP_GEMM_BIG=1).  Measured on MI355X it does not beat the 128x128
+        // kernel at 2 workgroups / CU (M=13056, N=1024, K=5120: 218 vs 209 us): with one wave per SIMD the barrier per
+        // k-slab and the LDS latency of the first k-step are exposed.  Kept for the next round's 8-wave version.
+        if (big && cdiv(M, 256) * cdiv(N, TBN) * batch >= 200) {
+            const dim3 g256((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, 256), (unsigned)batch);
+            hipLaunchKernelGGL(conv_gemm_bf16_glds256_kernel, g256, dim3(256), 3 * (256 + TBN) * TBK * 2, stream, p);
+        } else {
+            hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), 2 * (128 + TBN) * TBK * 2, stream, p);
+        }
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
+    // narrow outputs (N <= 64, the DiscriminatorR stacks): short K loops are latency-bound at 2 workgroups / CU; the
+    // BK = 32 instantiation halves the LDS footprint (5 workgroups / CU) -- pays off once there are many row tiles
+    static int bk32_env = -2;
+    if (bk32_env == -2) { const char* e = getenv("OSP_GEMM_BK32"); bk32_env = e ? atoi(e) : -1; }
+    const bool bk32 = bk32_env >= 0 ? bk32_env != 0 : (M >= 65536);
 #define OSP_LAUNCH_TILE(KC, F)                                                                                              \
     do {                                                                                                                    \
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 128, 128>), grid, dim3(256), 0, stream, p); \
+        else if (bm == 128 && KC && bk32) hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, (KC ? 32 : 64), F, 128, 64>), grid, dim3(256), 0, stream, p);  \
         else if (bm == 128) hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 128, 64>), grid, dim3(256), 0, stream, p);  \
         else hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 64, 64>), grid, dim3(256), 0, stream, p);                 \
     } while (0)

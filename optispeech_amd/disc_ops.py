@@ -282,6 +282,25 @@ class MRDStackFn(torch.autograd.Function):
 
 
 # =================================================================================================== generic stack
+def wnorm_packed(v, g, want_f32, want_t):
+    """osp_wnorm_fwd with a per-parameter cache: inside one training step the discriminator weights are packed once and
+    reused by the real / generated passes of the generator phase and by the discriminator phase (the reference
+    re-evaluates torch's weight_norm parametrisation on every call).  The pack lives on the ``weight_v`` Parameter object
+    (so it dies with the module; a re-used allocation can never alias it) and is valid while neither the optimizer
+    (values.param_epoch: the fused AdamW writes the arena through a raw pointer) nor a torch in-place op
+    (Tensor._version) nor a re-binding of ``.data`` (data_ptr) touched v / g."""
+    from . import values
+    stamp = (values.param_epoch(), v._version, g._version, v.data_ptr(), g.data_ptr())
+    hit = getattr(v, "_osp_wn_pack", None)
+    if hit is not None and hit[0] == stamp and (hit[1][1] is not None or not want_f32) and (hit[1][2] is not None or not want_t):
+        return hit[1]
+    if hit is not None and hit[0] == stamp:                       # same weights, more outputs wanted: keep the union
+        want_f32, want_t = want_f32 or hit[1][1] is not None, want_t or hit[1][2] is not None
+    pack = K.wnorm_fwd(v.detach(), g.detach(), want_f32=want_f32, want_t=want_t)
+    v._osp_wn_pack = (stamp, pack)
+    return pack
+
+
 class ConvStackFn(torch.autograd.Function):
     """A whole DiscriminatorP / DiscriminatorR conv stack with weight norm folded in.
 
@@ -305,8 +324,8 @@ class ConvStackFn(torch.autograd.Function):
             KH, KW, sh, sw, ph, pw = spec[i]
             cout, cin = vs[i].shape[0], vs[i].shape[1]
             small = (cin == 1 and cout in (16, 32, 64) and KH * KW <= cout)
-            wn, wn32, wt, inv = K.wnorm_fwd(vs[i].detach(), gs[i].detach(), want_f32=small,
-                                            want_t=(i > 0 and (need_x or any(need_w[:i]))) or (i == 0 and need_x))
+            wn, wn32, wt, inv = wnorm_packed(vs[i], gs[i], small,
+                                             (i > 0 and (need_x or any(need_w[:i]))) or (i == 0 and need_x))
             packs.append((wn, wn32, wt, inv))
             lr = slope if i < 5 else None
             if small:

@@ -9,6 +9,8 @@ import math
 
 import torch
 
+from . import values
+
 from ._lib import call
 
 
@@ -90,6 +92,7 @@ class FusedAdamW:
     def step(self, max_norm=None, grad_scale=1.0):
         self.step_count += 1
         ss = self.grad_sumsq() if max_norm else None
+        values.bump_param_epoch()                 # derived weight packs (disc_ops weight-norm cache) are stale from here on
         call("osp_adamw_clip", self.arena.data, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.arena.numel, ss,
              None, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
              float(self.weight_decay), int(self.step_count), float(max_norm or 0.0), float(grad_scale))

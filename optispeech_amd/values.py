@@ -70,3 +70,19 @@ class InferenceOutputs(_Container):
 
     def unbatched_wavs(self):
         return [self.wav[i, : int(n)] for i, n in enumerate(self.wav_lengths)]
+
+
+# ---------------------------------------------------------------------------------------------- parameter epoch
+# The fused optimizer updates the flat parameter arena through a raw pointer, which does not bump torch's tensor version
+# counters.  Caches of quantities derived from parameters (the packed weight-norm operands of the discriminators) are
+# keyed on this epoch in addition to ``Tensor._version``.
+_param_epoch = 0
+
+
+def param_epoch() -> int:
+    return _param_epoch
+
+
+def bump_param_epoch() -> None:
+    global _param_epoch
+    _param_epoch += 1

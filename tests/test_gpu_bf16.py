@@ -249,3 +249,33 @@ def test_smallcin_mfma_fwd_wgrad(U, Hin, Win, cout, KH, KW, sh, sw, ph, pw):
     scale = dw_ref.abs().max().item()
     assert (dw - dw_ref).abs().max().item() <= 2e-3 * scale + 1e-3, ((dw - dw_ref).abs().max().item(), scale)
     assert torch.allclose(db, db_ref, rtol=1e-3, atol=1e-2 + 1e-3 * db_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("nutt,Tin,cin,cout,taps,stride,pad", [(55, 500, 128, 1024, 3, 1, 1), (100, 517, 64, 256, 5, 2, 2)])
+def test_conv_gemm_bf16_large_tiles(nutt, Tin, cin, cout, taps, stride, pad):
+    """shapes large enough for the 256-row / three-stage direct-to-LDS kernel (>= 200 tiles), incl. ragged last tiles,
+    zero-padded taps and the staged bf16 epilogue; reference on the same bf16-rounded operands."""
+    from optispeech_amd import kernels as K
+    x = rnd(nutt, Tin, cin, seed=1).to(DEV)
+    w = (rnd(cout, cin, taps, seed=2) / np.sqrt(cin * taps)).to(DEV)
+    b = rnd(cout, seed=3).to(DEV)
+    Tout = (Tin + 2 * pad - taps) // stride + 1
+    want = F.leaky_relu(F.conv1d(bfr(x).transpose(1, 2), bfr(w), b, stride=stride, padding=pad).transpose(1, 2), 0.1)
+    wn = K.cast_bf16(w.permute(0, 2, 1).contiguous())
+    assert -(-nutt * Tout // 256) * (cout // 128) >= 200
+    got = K.conv_gemm_bf16(x.to(torch.bfloat16).view(nutt * Tin, cin), wn, cout, M=nutt * Tout, Trows=Tout, Tin=Tin, cin=cin,
+                           taps=taps, a_step=stride, a_off=-pad, bias=b, epi=K.EPI_LRELU, slope=0.1, out_bf16=True)
+    assert relerr(got.view(nutt, Tout, cout), want.cpu()) < 1e-2
+    got32 = K.conv_gemm_bf16(x.to(torch.bfloat16).view(nutt * Tin, cin), wn, cout, M=nutt * Tout, Trows=Tout, Tin=Tin, cin=cin,
+                             taps=taps, a_step=stride, a_off=-pad, bias=b, epi=K.EPI_LRELU, slope=0.1)
+    assert relerr(got32.view(nutt, Tout, cout), want.cpu()) < 3e-3
+
+
+def test_conv_gemm_bf16_large_tiles_256_variant():
+    """the opt-in 256-row / three-stage kernel (OSP_GEMM_BIG=1, read once per process) in a subprocess"""
+    import os, subprocess, sys
+    env = dict(os.environ, OSP_GEMM_BIG="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "test_conv_gemm_bf16_large_tiles and not variant",
+                        os.path.join(root, "tests", "test_gpu_bf16.py")], env=env, cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
