@@ -1145,6 +1145,147 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
     }
 }
 
+// ---- transposed-read variant (both operands bf16 with 16-byte rows, N % 128 == 0, Cin % 128 == 0, no row scale).
+// The reduction index (frames) is the SLOW index of both dY (M, N) and X (rows, Cin); the kernel above transposes 8x8
+// blocks in registers while staging, which makes it VALU-bound (~500 VALU instructions per k-slab and wave, PMC).  Here
+// the slabs are copied as they lie in HBM with global_load_lds (64 frames x 128 channels per operand, 256-byte rows), and
+// the MFMA fragments (8 consecutive frames of one channel per lane) are produced by ds_read_b64_tr_b16, which transposes
+// a 4 (frames) x 16 (channels) block per 16-lane group on the way out of LDS.
+// Bank mapping: a 256-byte row covers all 64 banks, so the 4 frame rows of one transposed read would collide 4-way; the
+// 16-byte slot index is XOR-ed with 4 * (row & 3) (applied to the global source address when staging and to the LDS
+// address when reading), which puts the 8 (row, 16-channel group) segments of a 32-lane pass on 8 distinct bank ranges.
+// T = 128: 4 waves of 64x64, 256-byte rows, slot ^= 4 * (row & 3).
+// T = 64 (the 64-channel DiscriminatorR layers): 4 waves of 32x32, 128-byte rows (two rows per 64 banks), the 4 frame
+// rows of a transposed read alternate bank halves and slot ^= 4 * ((row >> 1) & 1) separates the pairs.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int T>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
+    constexpr int SK = 64;                                   // frames per slab
+    constexpr int S = T / 8, RPI = 64 / S, NI = SK / RPI / 4, TI = T / 64;   // slots/row, rows/instruction, instr/wave/operand
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * 2 * SK * T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * (T / 2), wn0 = (wave & 1) * (T / 2);
+    const int ctiles = p.Cin / T;
+    const int j = blockIdx.y / ctiles, c0 = (blockIdx.y - j * ctiles) * T;
+    const int n0 = blockIdx.x * T;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z - bz * p.splits;
+    const unsigned short* dY = reinterpret_cast<const unsigned short*>(p.dY) + (int64_t)bz * p.sYb;
+    const unsigned short* X = reinterpret_cast<const unsigned short*>(p.X) + (int64_t)bz * p.sXb;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
+    const bool do_bias = (p.db != nullptr) && (blockIdx.y == 0);
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
+    const int64_t ldy = p.ldy, ldx = p.ldx;
+    auto swz = [](int row) { return T == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };
+
+    f32x16 acc[TI][TI], accb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < TI; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    }
+    // staging: wave w, instruction i covers slab rows RPI * (NI * w + i) + (lane / S); physical 16-byte slot = lane % S
+    const int srow = lane / S, lslot = (lane % S) ^ swz(srow);
+    // one (dY row, X row) pair of loads; `i` = instruction index 0..NI-1
+    auto issue_pair = [&](int mk, int buf, int i) {
+        unsigned short* ys = smem + buf * (2 * SK * T);
+        unsigned short* xs = ys + SK * T;
+        const int row0 = RPI * (NI * wave + i), m = mk + row0 + srow;
+        const bool mv = m < mend;
+        const unsigned short* src = mv ? dY + (int64_t)m * ldy + n0 + lslot * 8 : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, 0, 0);
+        const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+        const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+        const bool xv = mv && tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin;
+        const unsigned short* xsrc = xv ? X + (((int64_t)u * p.Hin + hh) * p.Tin + tt) * ldx + c0 + lslot * 8 : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
+                                         (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, 0, 0);
+    };
+    auto issue = [&](int mk, int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_pair(mk, buf, i);
+    };
+    // fragment of operand tile `base` ([SK][T]) for the 32 channels starting at `col0`, k-step ks: 8 consecutive frames
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1, kg = lane >> 5;
+    auto frag = [&](const unsigned short* base, int col0, int ks) -> bf16x8 {
+        const int col = col0 + 16 * g16 + 4 * (r16 & 3);                          // first of this lane's 4 source channels
+        const int pslot = (col >> 3) ^ swz(r16 >> 2);
+        const unsigned short* a0 = base + (16 * ks + 8 * kg + (r16 >> 2)) * T + pslot * 8 + (col & 7);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * T));
+        union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+        u.s.l = lo; u.s.h = hi;
+        return u.v;
+    };
+    bf16x8 ones;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+    // MFMA phase over slab `buf`; the next slab (frames from `mk_next`, < 0 = none) is staged one row pair per k-step
+    auto mma = [&](int buf, int mk_next) {
+        const unsigned short* ys = smem + buf * (2 * SK * T);
+        const unsigned short* xs = ys + SK * T;
+#pragma unroll
+        for (int ks = 0; ks < SK / 16; ++ks) {
+            bf16x8 a[TI], b[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = frag(ys, wm0 + 32 * i, ks);
+#pragma unroll
+            for (int jj = 0; jj < TI; ++jj) b[jj] = frag(xs, wn0 + 32 * jj, ks);
+            if (mk_next >= 0 && ks < NI) issue_pair(mk_next, buf ^ 1, ks);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TI; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+            if (do_bias && wn0 == 0) {                                            // block-uniform x wave-uniform
+#pragma unroll
+                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    };
+    const int niter = (mend - mbeg + SK - 1) / SK;
+    if (niter > 0) {
+        issue(mbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const int buf = it & 1;
+            mma(buf, it + 1 < niter ? mbeg + (it + 1) * SK : -1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TI; ++jj) {
+            const int c = c0 + wn0 + 32 * jj + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* dst = dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c;
+                const float val = (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r];
+                if (p.splits == 1) *dst += val;            // this block owns the tile: no atomics
+                else atomicAdd(dst, val);
+            }
+        }
+    if (do_bias && wn0 == 0 && l31 == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                atomicAdd(p.db + (int64_t)bz * p.sDb + n, (p.oscale ? p.oscale[n] : 1.f) * accb[i][r]);
+            }
+    }
+}
+
 static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
                                    int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
                                    int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
@@ -1169,7 +1310,24 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     const bool fast = y_bf16 && x_bf16 && !arow && (ldy % 8 == 0) && (ldx % 8 == 0) && (N % 8 == 0) && (Cin % 8 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dY) & 15) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                       (sYb % 8 == 0) && (sXb % 8 == 0);
-    if (fast) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p);
+    static int use_tr = -1;
+    if (use_tr < 0) { const char* e = getenv("OSP_WGRAD_TR"); use_tr = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_tr && fast && N % 64 == 0 && Cin % 64 == 0) {
+        // 128-tiles when both channel counts allow it, 64-tiles otherwise (DiscriminatorR).  The frames are split so that
+        // the grid is close to a multiple of the resident workgroup count (2 / CU for T = 128, 4 / CU for T = 64);
+        // partial sums meet in f32 atomics
+        const int64_t T_ = (N % 128 == 0 && Cin % 128 == 0) ? 128 : 64;
+        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = T_ == 128 ? 1024 : 2048;
+        int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
+        int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
+        if (ch < 4 * TBK) ch = 4 * TBK;
+        sp = cdiv(M, ch);
+        p.chunk = (int)ch; p.splits = (int)sp;
+        const dim3 g((unsigned)(N / T_), (unsigned)(taps * (Cin / T_)), (unsigned)(sp * batch));
+        if (T_ == 128) hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<64>, g, dim3(256), 0, stream, p);
+    }
+    else if (fast) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p);
     OSP_LAUNCH_CHECK();
     return OSP_OK;

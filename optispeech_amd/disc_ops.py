@@ -324,8 +324,9 @@ class ConvStackFn(torch.autograd.Function):
             KH, KW, sh, sw, ph, pw = spec[i]
             cout, cin = vs[i].shape[0], vs[i].shape[1]
             small = (cin == 1 and cout in (16, 32, 64) and KH * KW <= cout)
-            wn, wn32, wt, inv = wnorm_packed(vs[i], gs[i], small,
-                                             (i > 0 and (need_x or any(need_w[:i]))) or (i == 0 and need_x))
+            # the transposed (dgrad) pack is always produced: the no-grad real pass of the generator phase comes first
+            # and would otherwise force a second osp_wnorm_fwd for the generated pass
+            wn, wn32, wt, inv = wnorm_packed(vs[i], gs[i], small, True)
             packs.append((wn, wn32, wt, inv))
             lr = slope if i < 5 else None
             if small:
