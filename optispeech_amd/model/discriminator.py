@@ -128,10 +128,28 @@ class DiscriminatorR(nn.Module):
 
 
 class _Multi(nn.Module):
-    def forward(self, y, y_hat):
+    def forward_real(self, y):
+        """Real-wave branch only -> (scores, feature maps) per sub-discriminator, under the caller's grad mode.  Inside
+        one training step the discriminator weights and the real waves are the same in the generator phase and in the
+        discriminator phase (the D optimizer steps after both), so OptiSpeech.training_step evaluates this branch once,
+        WITH the autograd graph, and hands the result to both phases (the reference evaluates it twice)."""
+        rs, frs = [], []
+        for d in self.discriminators:
+            r, fr = d(y)
+            rs.append(r); frs.append(fr)
+        return rs, frs
+
+    def forward(self, y, y_hat, real=None):
         """Real and generated waves go through separately: in the generator phase the real branch needs no
-        backward at all (it only feeds the feature-matching targets), so it runs under no_grad."""
+        backward at all (it only feeds the feature-matching targets), so it runs under no_grad -- unless ``real``
+        (a forward_real result) is supplied, in which case only the generated branch runs."""
         rs, gs, frs, fgs = [], [], [], []
+        if real is not None:
+            rs, frs = real
+            for d in self.discriminators:
+                g, fg = d(y_hat)
+                gs.append(g); fgs.append(fg)
+            return rs, gs, frs, fgs
         real_needs_grad = any(p.requires_grad for p in self.parameters())
         B = y.shape[0]
         for d in self.discriminators:
@@ -179,7 +197,7 @@ def _feature_matching(fr, fg):                                 # FeatureMatching
             if precision.is_bf16():
                 tot = tot + L1MeanFn.apply(a.detach(), b)          # fused |a-b| mean; gradient to the generated branch
             else:
-                tot = tot + torch.mean(torch.abs(a - b))
+                tot = tot + torch.mean(torch.abs(a.detach() - b))   # target side carries no gradient (frozen D in the reference)
     return tot / len(fr)
 
 
@@ -200,16 +218,19 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
                                                                fe.n_feats, fe.f_min, fe.f_max)
         self.mr_stft_loss = spectral.MultiResolutionSTFTLoss()
 
-    def forward_disc(self, wav, wav_hat):
-        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat)
-        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat)
+    def forward_real(self, wav):
+        return self.multiperioddisc.forward_real(wav), self.multiresddisc.forward_real(wav)
+
+    def forward_disc(self, wav, wav_hat, real=None):
+        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None)
+        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None)
         loss_mp, loss_mrd = _hinge_d(r_mp, g_mp), _hinge_d(r_mr, g_mr)
         loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd
         return loss, dict(loss_mp=loss_mp.detach(), loss_mrd=loss_mrd.detach())
 
-    def forward_gen(self, wav, wav_hat):
-        _, g_mp, fr_mp, fg_mp = self.multiperioddisc(y=wav, y_hat=wav_hat)
-        _, g_mr, fr_mr, fg_mr = self.multiresddisc(y=wav, y_hat=wav_hat)
+    def forward_gen(self, wav, wav_hat, real=None):
+        _, g_mp, fr_mp, fg_mp = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None)
+        _, g_mr, fr_mr, fg_mr = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None)
         loss_gen_mp, loss_gen_mrd = _hinge_g(g_mp), _hinge_g(g_mr)
         loss_fm_mp, loss_fm_mrd = _feature_matching(fr_mp, fg_mp), _feature_matching(fr_mr, fg_mr)
         mel_loss = self._get_mel_loss(wav, wav_hat)

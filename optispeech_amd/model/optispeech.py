@@ -12,6 +12,8 @@ import pickle
 from functools import partial
 from types import SimpleNamespace
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -75,6 +77,7 @@ class OptiSpeech(nn.Module):
         self.global_step = 0
         self.max_steps = 2_000_000
         self._opts = None
+        self.share_real_pass = os.environ.get("OSP_SHARE_REAL", "0") == "1"
         self._reducers = None
         self.last_logs = {}
 
@@ -141,10 +144,10 @@ class OptiSpeech(nn.Module):
         red_g, red_d = self._reducers
         rng.advance()
         logs = {}
-        # ---- generator phase (discriminator weights frozen = toggle_optimizer)
-        for p in self.discriminator.parameters():
-            p.requires_grad_(False)
-        loss_g, (wav, wav_hat) = self.training_step_g(batch, train_discriminator, logs)
+        # ---- generator phase (discriminator weights frozen = toggle_optimizer; training_step_g freezes them after the
+        # shared real-wave pass, which needs the parameter graph for the discriminator phase)
+        loss_g, (wav, wav_hat) = self.training_step_g(batch, train_discriminator, logs,
+                                                       share_real=train_discriminator and self.share_real_pass)
         if apply:
             opt_g.zero_grad()
         (loss_g / scale).backward()
@@ -171,8 +174,11 @@ class OptiSpeech(nn.Module):
                 self.global_step += 1
         self.last_logs = logs
 
-    def training_step_g(self, batch, train_discriminator, logs):
-        """base_lightning_module.py:128-161 (log values stay on the device; see fetch_logs)."""
+    def training_step_g(self, batch, train_discriminator, logs, share_real=False):
+        """base_lightning_module.py:128-161 (log values stay on the device; see fetch_logs).
+
+        share_real: evaluate the discriminators on the real waves once, with the parameter graph, and keep the result
+        for training_step_d of the same step (same weights, same waves -> same values as the reference's two passes)."""
         gen_outputs = self._process_batch(batch)
         gen_am_loss = gen_outputs["loss"]
         logs.update({"total_loss/train_am_loss": gen_am_loss.detach(),
@@ -181,8 +187,13 @@ class OptiSpeech(nn.Module):
                      "gen_subloss/train_pitch_loss": gen_outputs["pitch_loss"],
                      "gen_subloss/train_energy_loss": gen_outputs["energy_loss"]})
         wav, wav_hat = gen_outputs["wav"], gen_outputs["wav_hat"]
+        self._real_pass = None
         if train_discriminator:
-            gen_adv_loss, log_dict = self.discriminator.forward_gen(wav, wav_hat)
+            if share_real:
+                self._real_pass = self.discriminator.forward_real(wav)
+            for p in self.discriminator.parameters():
+                p.requires_grad_(False)
+            gen_adv_loss, log_dict = self.discriminator.forward_gen(wav, wav_hat, real=self._real_pass)
             logs["total_loss/train_gen_adv_loss"] = gen_adv_loss.detach()
             logs.update({f"gen_adv_loss/train_{k}": v for k, v in log_dict.items()})
             loss = gen_am_loss + gen_adv_loss
@@ -195,7 +206,8 @@ class OptiSpeech(nn.Module):
     def training_step_d(self, batch, wav_outputs, logs):
         """base_lightning_module.py:163-186; D sees wav_hat.detach()."""
         wav, wav_hat = wav_outputs
-        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat)
+        real, self._real_pass = getattr(self, "_real_pass", None), None
+        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real)
         logs["total_loss/discriminator"] = loss.detach()
         logs.update({f"discriminator/{k}": v for k, v in log_dict.items()})
         return loss
