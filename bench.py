@@ -207,6 +207,15 @@ def main():
                 "unit": "TFLOP/s", "traffic": None, "launches_timed": nlaunch,
                 "avg_launch_us": (kms / nlaunch * 1e3) if nlaunch else None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read inside the timed
+        # run); the committed summary of that pass is reported here when it matches the measured configuration
+        pmc = os.path.join(ROOT, "profiles", "r01b_pmc_glds.json")
+        if a.precision == "bf16" and not a.ragged and os.path.exists(pmc):
+            with open(pmc) as fh:
+                pj = json.load(fh)
+            roof["traffic"] = pj["traffic_bytes_per_launch"]
+            roof["traffic_unit"] = "bytes/launch (TCC_EA0 read x 128 B + write x 64 B, " + os.path.basename(pmc) + ")"
+            roof["algorithmic_flop_per_launch"] = flops / nlaunch if nlaunch else None
         cpu = None
         if not a.no_cpu_baseline:
             v, threads, note = cpu_baseline(a.cpu_batch)
