@@ -1370,3 +1370,38 @@ extern "C" int osp_cast_bf16(const float* x, void* y, int64_t n, hipStream_t str
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// out[n][tap][k] (bf16, contiguous) = w[n*sN + tap*sT + k*sK] (f32; any strides, sT may be negative for a flipped kernel).
+// The dgrad GEMMs of the generator address the weights transposed (k-strided); packing them once per call into the
+// k-contiguous bf16 layout lets the GEMM use 16-byte operand loads instead of its transposing element loader, which is
+// ~2x slower than the GEMM itself on these small shapes.  32x32 tiles through LDS, reads along the unit-stride axis.
+// Algorithmic bytes: 4 read + 2 written per weight.
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int N, int taps,
+                                                        int K, int64_t sN, int64_t sT, int64_t sK) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + (int64_t)tap * sT;
+    const bool along_n = (sN < 0 ? -sN : sN) < (sK < 0 ? -sK : sK);
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = along_n ? n0 + tx : n0 + r, k = along_n ? k0 + r : k0 + tx;
+        const float v = (n < N && k < K) ? src[(int64_t)n * sN + (int64_t)k * sK] : 0.f;
+        if (along_n) tile[r][tx] = v; else tile[tx][r] = v;      // tile[k_local][n_local]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) out[((int64_t)n * taps + tap) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][r]);
+    }
+}
+extern "C" int osp_pack_bf16(const float* w, void* out, int64_t N, int64_t taps, int64_t K, int64_t sN, int64_t sT, int64_t sK,
+                             hipStream_t stream) {
+    OSP_CHECK_ARG(w && out && N > 0 && taps > 0 && K > 0, "bad args");
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32), (unsigned)taps), dim3(256), 0, stream, w,
+                       (unsigned short*)out, (int)N, (int)taps, (int)K, sN, sT, sK);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

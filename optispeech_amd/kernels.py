@@ -42,7 +42,13 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
         for t in (aux_out, aux_in):
             if t is not None:
                 ld_aux_ = t.stride(-2)
-        call("osp_conv_gemm_bf16", a, 0, lda, M, T, T, cin, taps, 1, 1, -pad, a_rowscale, w, 0, w_strides[0], w_strides[1],
+        w_bf16 = 0
+        if batch == 1 and w_strides[2] != 1:
+            # k-strided (transposed / flipped) weights: one pack launch into the k-contiguous bf16 layout
+            wp = torch.empty((n_out, taps, cin), device=a.device, dtype=torch.bfloat16)
+            call("osp_pack_bf16", w, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
+            w, w_bf16, w_strides = wp, 1, (taps * cin, cin, 1)
+        call("osp_conv_gemm_bf16", a, 0, lda, M, T, T, cin, taps, 1, 1, -pad, a_rowscale, w, w_bf16, w_strides[0], w_strides[1],
              w_strides[2], n_out, out, 0, ldc_, T, 1, 0, epi, bias, gamma, res, 0, res.stride(-2) if res is not None else 0,
              rowmask, rowscale, aux_out, aux_in, 0, ld_aux_, 0.0, batch, batch_strides[0], batch_strides[1],
              batch_strides[2], batch_strides[3], bool(accumulate))
@@ -59,6 +65,9 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
     return out
 
 
+_WGRAD_BF16_MIN_M = int(__import__('os').environ.get('OSP_WGRAD_BF16_MIN_M', '2048'))
+
+
 def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=None, batch=1):
     """dw[n, j, c] += oscale[n] * sum_m arow[m] dy[m, n] x[m + j - pad, c];  db[n] += oscale[n] * sum_m arow[m] dy[m, n]."""
     _f32(dy, x, dw, db, arow, oscale)
@@ -68,7 +77,7 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
     assert dw.is_contiguous() and dw.numel() == batch * N * taps * cin, (dw.shape, N, taps, cin)
     sy = dy.stride(0) if batch > 1 else 0
     sx = x.stride(0) if batch > 1 else 0
-    if _precision.is_bf16() and M >= 8192 and N >= 64 and cin >= 64:
+    if _precision.is_bf16() and M >= _WGRAD_BF16_MIN_M and N >= 64 and cin >= 64:
         call("osp_conv_wgrad_bf16", dy, 0, dy.stride(-2), x, 0, x.stride(-2), M, T, T, N, cin, taps, pad, 1, arow, oscale, dw,
              taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
         return

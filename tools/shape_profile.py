@@ -25,7 +25,10 @@ def sig(name, args):
     if name == "osp_conv2d_wgrad_bf16": return (name, "M", args[6], "N", args[11], "Cin", args[12], "taps", args[13])
     if name == "osp_conv_wgrad_f32": return (name, "M", args[4], "N", args[6], "Cin", args[7], "taps", args[8])
     return (name,) + tuple(ints[:4])
+SYNC = os.environ.get("SYNC", "0") == "1"      # drain the stream before every call: kernel time without launch gaps
 def call(name, *args):
+    if SYNC:
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); orig(name, *args); e1.record()
     events.append((sig(name, args), e0, e1))
