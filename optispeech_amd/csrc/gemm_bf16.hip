@@ -455,16 +455,16 @@ __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
 // BM_ = 256: 4 waves of 128x64 (128 accumulator registers), three 48 KB stages, 1 workgroup / CU, prefetch distance 2.
 //   Per k-slab a CU then reads (128 + 64) * 64 * 2 B * 4 waves = 96 KB of fragments for 2 * 256*128*64 flop, i.e. LDS
 //   traffic per flop is 2/3 of the 128x128 tile's (which is LDS-bandwidth bound: 96 KB + 32 KB DMA per 512 MFMA clocks).
-template <int BM_, int NST>
+template <int BM_, int NST, int BN_ = TBN>
 __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsigned short* smem) {
-    constexpr int RA = BM_ / 32, RB = TBN / 32, TM_ = BM_ / 64;   // rows staged per thread (A, B); 32x32 tiles per wave along M
+    constexpr int RA = BM_ / 32, RB = BN_ / 32, TM_ = BM_ / 64, TN_ = BN_ / 64;   // rows staged per thread (A, B); 32x32 tiles per wave along M
     unsigned short* As = smem;                       // [NST][BM_][64]
-    unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][TBN][64]
+    unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][BN_][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * (BM_ / 2), wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * (BM_ / 2), wn0 = (wave & 1) * (BN_ / 2);
     int mb_, nb_;
     xcd_tile(mb_, nb_);
-    const int m0 = mb_ * BM_, n0 = nb_ * TBN;
+    const int m0 = mb_ * BM_, n0 = nb_ * BN_;
     const int64_t bz = blockIdx.z;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(pp.A) + bz * pp.sAb;
     const unsigned short* B = reinterpret_cast<const unsigned short*>(pp.B) + bz * pp.sBb;
@@ -492,11 +492,11 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsign
     }
     // accumulators as 64-row halves: the epilogue is instantiated per half with compile-time indices only (one 512-byte
     // array indexed through the epilogue's nested loops stayed a stack object and was stored to scratch every iteration)
-    f32x16 acc0[2][2], acc1[2][2];
+    f32x16 acc0[2][TN_], acc1[2][TN_];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN_; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
@@ -537,16 +537,16 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsign
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         } else {
             constexpr int J = I - RA;
-            unsigned short* dst = Bs + buf * TBN * TBK + (wave * RB + J) * 8 * TBK;
+            unsigned short* dst = Bs + buf * BN_ * TBK + (wave * RB + J) * 8 * TBK;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[J] + is_cb * b_inc[J]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
     auto issue_quarter = [&](int buf, auto qidx) {             // loads [Q * NL / 4, (Q + 1) * NL / 4)
-        constexpr int Q = decltype(qidx)::value, NL = RA + RB, L0 = Q * NL / 4;
-        issue_one(buf, std::integral_constant<int, L0>{});
-        if constexpr (NL / 4 > 1) issue_one(buf, std::integral_constant<int, L0 + 1>{});
-        if constexpr (NL / 4 > 2) issue_one(buf, std::integral_constant<int, L0 + 2>{});
+        constexpr int Q = decltype(qidx)::value, NL = RA + RB, L0 = Q * NL / 4, L1 = (Q + 1) * NL / 4;
+        if constexpr (L1 - L0 > 0) issue_one(buf, std::integral_constant<int, L0>{});
+        if constexpr (L1 - L0 > 1) issue_one(buf, std::integral_constant<int, L0 + 1>{});
+        if constexpr (L1 - L0 > 2) issue_one(buf, std::integral_constant<int, L0 + 2>{});
     };
     auto issue_begin = [&]() { if (is_j != cur_tap) set_tap(is_j); };          // wave-uniform branch
     auto issue_end = [&]() { is_cb += TBK; if (is_cb == Cin) { is_cb = 0; ++is_j; } };
@@ -559,19 +559,19 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsign
     // MFMA phase over slab `buf`; when `ld` >= 0 the next slab's loads go to buffer `ld`, a quarter per k-step
     auto mma = [&](int buf, int ld) {
         const unsigned short* as = As + buf * BM_ * TBK;
-        const unsigned short* bs = Bs + buf * TBN * TBK;
+        const unsigned short* bs = Bs + buf * BN_ * TBK;
         const int l31 = lane & 31, lh = lane >> 5;
         if (ld >= 0) issue_begin();
         auto kstep = [&](auto ksidx) {
             constexpr int ks = decltype(ksidx)::value;
-            bf16x8 a[TM_], b[2];
+            bf16x8 a[TM_], b[TN_];
 #pragma unroll
             for (int i = 0; i < TM_; ++i) {
                 const int row = wm0 + 32 * i + l31;
                 a[i] = *reinterpret_cast<const bf16x8*>(as + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN_; ++j) {
                 const int row = wn0 + 32 * j + l31;
                 b[j] = *reinterpret_cast<const bf16x8*>(bs + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
             }
@@ -579,7 +579,7 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsign
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TN_; ++j) {
                     acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc0[i][j], 0, 0, 0);
                     if constexpr (TM_ == 4) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + i], b[j], acc1[i][j], 0, 0, 0);
                 }
@@ -620,13 +620,18 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsign
         }
         __syncthreads();
     }
-    gemm_bf16_epilogue<2, 2>(pp, acc0, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * 72);
-    if constexpr (TM_ == 4) gemm_bf16_epilogue<2, 2>(pp, acc1, m0, n0, wm0 + 64, wn0, lane, bz, smem + wave * (32 * TM_) * 72 + 64 * 72);
+    constexpr int SP_ = 32 * TN_ + 8;
+    gemm_bf16_epilogue<2, TN_>(pp, acc0, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * SP_);
+    if constexpr (TM_ == 4) gemm_bf16_epilogue<2, TN_>(pp, acc1, m0, n0, wm0 + 64, wn0, lane, bz, smem + wave * (32 * TM_) * SP_ + 64 * SP_);
 }
 
 extern __shared__ __attribute__((aligned(1024))) unsigned short glds_smem[];
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp) {
     conv_gemm_bf16_glds_body<128, 2>(pp, glds_smem);
+}
+// narrow outputs (N <= 64: the DiscriminatorR stacks): 128x64 tiles, 48 KB of LDS -> 3 workgroups / CU
+__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const GemmB pp) {
+    conv_gemm_bf16_glds_body<128, 2, 64>(pp, glds_smem);
 }
 // one workgroup per CU (144 KB of LDS): let the register allocator use the whole 512-entry file of a single wave / SIMD
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_bf16_glds256_kernel(const GemmB pp) {
@@ -867,6 +872,17 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     dim3 grid((unsigned)cdiv(N, bn), (unsigned)cdiv(M, bm), (unsigned)batch);
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("OSP_GEMM_GLDS"); use_glds = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 64 && N > 8) {
+        static int attr64 = 0;
+        if (!attr64) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_n64_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * TBK * 2);
+            attr64 = 1;
+        }
+        hipLaunchKernelGGL(conv_gemm_bf16_glds_n64_kernel, grid, dim3(256), 2 * (128 + 64) * TBK * 2, stream, p);
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
     if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 128) {
         static int big = -1, attr_done = 0;
         if (big < 0) { const char* e = getenv("OSP_GEMM_BIG"); big = (e && atoi(e) == 1) ? 1 : 0; }
