@@ -17,6 +17,32 @@ class OspError(RuntimeError):
     pass
 
 
+_CTYPE = {"int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double, "int": ctypes.c_int}
+
+
+def _header_signatures():
+    """argtypes of every entry point, parsed from include/osp.h (the header IS the boundary; it is generated from the
+    sources and checked by tests/test_abi.py).  Pointers and hipStream_t -> void*."""
+    path = os.path.join(os.path.dirname(_HERE), "include", "osp.h")
+    sigs = {}
+    if not os.path.exists(path):
+        return sigs
+    import re
+    text = open(path).read()
+    for m in re.finditer(r"^\s*int\s+(osp_\w+)\s*\(([^;]*)\)\s*;", text, flags=re.M):
+        types = []
+        for prm in m.group(2).split(","):
+            prm = prm.strip()
+            if not prm or prm == "void":
+                continue
+            if "*" in prm or prm.startswith("hipStream_t"):
+                types.append(ctypes.c_void_p)
+            else:
+                types.append(_CTYPE[prm.replace("const ", "").split()[0]])
+        sigs[m.group(1)] = types
+    return sigs
+
+
 class _Lib:
     def __init__(self):
         if not os.path.exists(LIB_PATH):
@@ -25,34 +51,37 @@ class _Lib:
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.cdll.osp_last_error.restype = ctypes.c_char_p
         self._fn = {}
+        self._sigs = _header_signatures()
 
     def fn(self, name):
         f = self._fn.get(name)
         if f is None:
             f = getattr(self.cdll, name)
             f.restype = ctypes.c_int
+            if name in self._sigs:
+                f.argtypes = self._sigs[name]       # ctypes converts ints / floats / None itself: no per-argument wrappers
             self._fn[name] = f
         return f
 
     def call(self, name, *args):
+        f = self.fn(name)
         cargs = []
         for a in args:
-            if a is None:
-                cargs.append(ctypes.c_void_p(0))
-            elif isinstance(a, torch.Tensor):
+            if isinstance(a, torch.Tensor):
                 if not a.is_cuda:
                     raise OspError(f"{name}: tensor argument is not on the GPU")
-                cargs.append(ctypes.c_void_p(a.data_ptr()))
-            elif isinstance(a, bool):
-                cargs.append(ctypes.c_int64(int(a)))
-            elif isinstance(a, int):
-                cargs.append(ctypes.c_int64(a))
-            elif isinstance(a, float):
-                cargs.append(ctypes.c_float(a))
+                cargs.append(a.data_ptr())
+            elif a is None or isinstance(a, (int, float)):
+                cargs.append(a)
             else:
                 raise TypeError(f"{name}: unsupported argument type {type(a)}")
-        cargs.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-        rc = self.fn(name)(*cargs)
+        # torch's current HIP stream of the current device (raw handle; torch.cuda.current_stream() costs ~9 us per call)
+        cargs.append(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+        if f.argtypes is None:
+            raise OspError(f"{name} is not declared in include/osp.h (regenerate it with tools/gen_header.py)")
+        if len(cargs) != len(f.argtypes):
+            raise TypeError(f"{name}: {len(cargs) - 1} arguments given, include/osp.h declares {len(f.argtypes) - 1}")
+        rc = f(*cargs)
         if rc != 0:
             raise OspError(f"{name} failed ({rc}): {self.cdll.osp_last_error().decode()}")
 

@@ -181,3 +181,40 @@ extern "C" int osp_stft_mag_bwd(const float* x, const float* window, const float
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ log-mel + energy
+// Offline feature extraction of the reference (dataset/feature_extractors/__init__.py:114-147,176-200): per frame
+//   m'[k] = sqrt(|X[k]|^2 + eps)      mel[j] = log(max(sum_k fb[j][k] m'[k], clip))      energy = sqrt(sum_k m'[k]^2)
+// mag: (F, bins) magnitudes from osp_stft_mag_fwd (clamp_min < 0); fbT: (bins, n_mels) transposed mel basis (coalesced over
+// the mel index); mel_out: (n_mels, F) -- the reference's (n_feats, T) layout; energy_out: (F).  One workgroup per frame.
+// HBM-bound: (bins + n_mels + 1) * 4 bytes per frame, the basis (bins * n_mels * 4 B) stays in L2.
+__global__ __launch_bounds__(128) void logmel_energy_kernel(const float* __restrict__ mag, const float* __restrict__ fbT,
+                                                            float* __restrict__ mel_out, float* __restrict__ energy_out, int F,
+                                                            int bins, int n_mels, float eps, float clip) {
+    extern __shared__ float lm_m[];                      // bins magnitudes + 2 partial sums
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float part = 0.f;
+    for (int k = tid; k < bins; k += 128) {
+        const float m = mag[(int64_t)f * bins + k], m2 = m * m + eps;
+        lm_m[k] = sqrtf(m2);
+        part += m2;
+    }
+    part = wave_sum(part);
+    if ((tid & 63) == 0) lm_m[bins + (tid >> 6)] = part;
+    __syncthreads();
+    if (tid == 0 && energy_out) energy_out[f] = sqrtf(lm_m[bins] + lm_m[bins + 1]);
+    for (int j = tid; j < n_mels; j += 128) {
+        float acc = 0.f;
+        for (int k = 0; k < bins; ++k) acc = fmaf(fbT[(int64_t)k * n_mels + j], lm_m[k], acc);
+        mel_out[(int64_t)j * F + f] = logf(fmaxf(acc, clip));
+    }
+}
+
+extern "C" int osp_logmel_energy(const float* mag, const float* fbT, float* mel_out, float* energy_out, int64_t F, int64_t bins,
+                                 int64_t n_mels, float eps, float clip, hipStream_t stream) {
+    OSP_CHECK_ARG(mag && fbT && mel_out && F > 0 && bins > 0 && n_mels > 0 && bins <= 8192, "bad log-mel arguments");
+    hipLaunchKernelGGL(logmel_energy_kernel, dim3((unsigned)F), dim3(128), (size_t)(bins + 2) * 4, stream, mag, fbT, mel_out,
+                       energy_out, (int)F, (int)bins, (int)n_mels, eps, clip);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

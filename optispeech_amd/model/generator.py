@@ -77,6 +77,8 @@ class OptiSpeechGenerator(nn.Module):
         log_p_attn = self.alignment_module(text=h, feats=feats, text_lengths=x_lengths, feats_lengths=mel_lengths,
                                            x_masks=input_padding_mask)      # :120-126
         durations, path, bin_item = viterbi_decode(log_p_attn, x_lengths, mel_lengths)      # :127
+        # :174 -- issued here (side stream) so that it overlaps everything up to the loss sum; joined below
+        forwardsum_loss, bin_loss = ops.AlignLossFn.apply(log_p_attn, x_lengths, mel_lengths, path, bin_item)
         duration_hat = self.duration_predictor(h.detach(), input_padding_mask)              # :128
         p_avg, e_avg = average_by_duration(durations, pitches, energies, x_lengths, mel_lengths)   # :131-132
         h, pitch_hat = self.pitch_predictor(h, input_padding_mask, p_avg)                   # :135
@@ -95,7 +97,7 @@ class OptiSpeechGenerator(nn.Module):
         c = self.loss_coeffs
         duration_loss, pitch_loss, energy_loss = ops.VarianceLossFn.apply(
             duration_hat, pitch_hat, energy_hat, durations, p_avg, e_avg, x_lengths)        # :165-173
-        forwardsum_loss, bin_loss = ops.AlignLossFn.apply(log_p_attn, x_lengths, mel_lengths, path, bin_item)  # :174
+        ops.join_side_stream()                                                              # the CTC recursion ran alongside
         align_loss = forwardsum_loss + bin_loss                                             # :175
         loss = (align_loss * c.lambda_align + duration_loss * c.lambda_duration + pitch_loss * c.lambda_pitch
                 + energy_loss * c.lambda_energy)                                            # :176-181

@@ -300,6 +300,24 @@ class AlignLogProbFn(torch.autograd.Function):
         return df, de, None, None, None
 
 
+_side_streams = {}
+_pending_side = []
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=key)
+    return _side_streams[key]
+
+
+def join_side_stream():
+    """Make the current stream wait for everything queued on the side stream so far (no host sync)."""
+    main = torch.cuda.current_stream()
+    while _pending_side:
+        main.wait_event(_pending_side.pop())
+
+
 class AlignLossFn(torch.autograd.Function):
     """(forwardsum_loss, bin_loss) from log_p_attn: ForwardSumLoss (loss.py:150-194) and the binarisation term of
     viterbi_decode (alignments.py:236-238); `path`/`bin_item` come from the MAS kernel."""
@@ -308,10 +326,26 @@ class AlignLossFn(torch.autograd.Function):
     def forward(ctx, lp, x_len, y_len, path, bin_item):
         B = lp.shape[0]
         need = ctx.needs_input_grad[0]
-        loss_item, grad = K.forwardsum_ctc(lp.contiguous(), x_len, y_len, want_grad=need)
+        lp = lp.contiguous()
+        # The forward-sum recursion is latency-bound (2*T_mel dependent steps on one workgroup per utterance, ~1.3 ms at
+        # B=32) and occupies 32 of the 256 CUs: it runs on a side stream next to the decoder / vocoder forward.  The
+        # caller joins with ``join_side_stream()`` before it consumes the loss (generator.forward does, right before the
+        # loss sum); the gradient saved here is only read in backward, i.e. after that join.
+        main = torch.cuda.current_stream()
+        side = _side_stream(lp.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            loss_item, grad = K.forwardsum_ctc(lp, x_len, y_len, want_grad=need)
+            fs = loss_item.sum() / B
+        for t in (lp, x_len, y_len):
+            t.record_stream(side)
+        for t in (fs, grad):
+            if t is not None:
+                t.record_stream(main)
+        _pending_side.append(side.record_event())
         if need:
             ctx.save_for_backward(grad, path, y_len)
-        return loss_item.sum() / B, bin_item.sum() / B
+        return fs, bin_item.sum() / B
 
     @staticmethod
     def backward(ctx, g_fs, g_bin):
