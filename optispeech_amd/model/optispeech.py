@@ -275,6 +275,21 @@ class OptiSpeech(nn.Module):
                                                       p_factor=p_factor or ia.p_factor, e_factor=e_factor or ia.e_factor)
         return inputs.as_torch().to(self.device)
 
+    # ------------------------------------------------------------------------------------------ ONNX-compatible I/O
+    @torch.inference_mode()
+    def onnx_io(self, x, x_lengths, scales, sids=None, lids=None):
+        """The signature of the reference's exported graph (onnx/export.py:40-81): inputs ``x`` (B, T) int64,
+        ``x_lengths`` (B,), ``scales`` = [d_factor, p_factor, e_factor] -> (wav, wav_lengths, durations), so consumers of
+        the ``ospeech`` runtime (onnx/infer.py:24-145) can call the native model with the tensors they already build."""
+        sc = [float(v) for v in (scales.tolist() if hasattr(scales, "tolist") else scales)]
+        dev = self.device
+        as_t = lambda v, dt: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(dtype=dt)   # noqa: E731
+        out = self.generator.synthesise(x=as_t(x, torch.long).to(dev), x_lengths=as_t(x_lengths, torch.long).to("cpu"),
+                                        sids=as_t(sids, torch.long).to(dev) if sids is not None else None,
+                                        lids=as_t(lids, torch.long).to(dev) if lids is not None else None,
+                                        d_factor=sc[0], p_factor=sc[1], e_factor=sc[2])
+        return out["wav"], out["wav_lengths"], out["durations"]
+
     # ------------------------------------------------------------------------------------------ checkpoints
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, config=None, strict=False, **kwargs):
@@ -292,6 +307,50 @@ class OptiSpeech(nn.Module):
             raise RuntimeError(f"checkpoint mismatch: missing {bad[:5]}, unexpected {list(unexpected)[:5]}")
         model.ckpt_loaded_epoch = ckpt.get("epoch") if isinstance(ckpt, dict) else None    # on_load_checkpoint :305-306
         return model
+
+
+    def _moment_views(self, opt):
+        """(reference key, to_ref, to_native, exp_avg view, exp_avg_sq view) for every parameter of a FusedAdamW arena."""
+        by_id = {}
+        for mprefix, mod in self.named_modules():
+            for name, prm in mod._parameters.items():
+                if prm is None:
+                    continue
+                key, to_native, to_ref = mod._ref(name) if hasattr(mod, "_ref") else (name, None, None)
+                by_id[id(prm)] = ((mprefix + "." if mprefix else "") + key, to_ref, to_native)
+        for prm, off in zip(opt.arena.params, opt.arena.offsets):
+            key, to_ref, to_native = by_id[id(prm)]
+            n = prm.numel()
+            yield key, to_ref, to_native, opt.exp_avg[off:off + n].view(prm.shape), opt.exp_avg_sq[off:off + n].view(prm.shape)
+
+    def save_checkpoint(self, path):
+        """Write a checkpoint the reference can read: ``state_dict`` in the reference's key / layout schema (weight-norm
+        g / v, conv kernels (Cout, Cin, k), un-padded head) plus ``epoch`` / ``global_step``
+        (base_lightning_module.py:305-306 reads ``epoch``).  The native extras (AdamW moments keyed by reference
+        parameter name and stored in the reference layout, step counters, schedule positions, dropout RNG position)
+        live under ``"osp"`` so that a resumed run continues exactly."""
+        from .. import rng
+        opts = self.optimizers()
+        extra = {"rng": dict(rng._state), "global_step": self.global_step, "optimizers": []}
+        for opt, sch in zip(opts, self.lr_schedulers()):
+            mom = {k: ((to_ref(a) if to_ref else a).detach().cpu().clone(), (to_ref(b) if to_ref else b).detach().cpu().clone())
+                   for k, to_ref, _, a, b in self._moment_views(opt)}
+            extra["optimizers"].append({"step": opt.step_count, "lr": opt.lr, "last_step": sch.last_step, "moments": mom})
+        torch.save({"state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+                    "epoch": getattr(self, "ckpt_loaded_epoch", None) or 0, "global_step": self.global_step, "osp": extra}, path)
+
+    def load_training_state(self, ckpt):
+        """Restore what save_checkpoint put under ``"osp"`` (after the weights were loaded and the model moved to its device)."""
+        from .. import rng
+        extra = ckpt["osp"] if "osp" in ckpt else ckpt
+        rng._state.update(extra["rng"])
+        self.global_step = int(extra["global_step"])
+        for opt, sch, st in zip(self.optimizers(), self.lr_schedulers(), extra["optimizers"]):
+            opt.step_count, opt.lr, sch.last_step = int(st["step"]), float(st["lr"]), int(st["last_step"])
+            for key, _, to_native, a, b in self._moment_views(opt):
+                ea, eb = st["moments"][key]
+                a.copy_((to_native(ea) if to_native else ea).to(a.device))
+                b.copy_((to_native(eb) if to_native else eb).to(b.device))
 
 
 class _Dummy:
