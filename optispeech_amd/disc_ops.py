@@ -314,6 +314,12 @@ class ConvStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, spec, slope, *params):
+        # ``slope`` may be (slope, u0): the first u0 sequences are a no-grad branch (the real waves in the generator
+        # phase) that shares the forward launches with the rest; the outputs then come as 6 no-grad tensors followed by
+        # 6 differentiable ones (views of the same buffers) and the backward runs over the sequences from u0 on only.
+        u0 = 0
+        if isinstance(slope, tuple):
+            slope, u0 = slope
         ctx.set_materialize_grads(False)
         vs, gs, bs = params[0::3], params[1::3], params[2::3]
         need_w = [bool(ctx.needs_input_grad[3 + 3 * i]) for i in range(6)]
@@ -338,15 +344,22 @@ class ConvStackFn(torch.autograd.Function):
                 h = conv2d_fwd(h, wn, bs[i].detach(), KH, KW, sh, sw, ph, pw, lr, i < 5)
             acts.append(h)
         if need_x or any(need_w):
-            ctx.save_for_backward(x, *acts[:5], *[t for pk in packs for t in (pk[0], pk[2], pk[3]) if t is not None])
+            ctx.save_for_backward(x[u0:], *[a[u0:] for a in acts[:5]],
+                                  *[t for pk in packs for t in (pk[0], pk[2], pk[3]) if t is not None])
             ctx.pack_layout = [(pk[0] is not None, pk[2] is not None, pk[3] is not None) for pk in packs]
             ctx.params = params
             ctx.cfg = (spec, slope, need_x, need_w)
+            ctx.u0, ctx.U = u0, x.shape[0]
+        if u0:
+            head = tuple(a[:u0] for a in acts)
+            ctx.mark_non_differentiable(*head)
+            return head + tuple(a[u0:] for a in acts)
         return tuple(acts)
 
     @staticmethod
-    def backward(ctx, d1, d2, d3, d4, d5, ds):
+    def backward(ctx, *douts):
         from .ops import gsink
+        d1, d2, d3, d4, d5, ds = douts[-6:]                      # (with a no-grad head the first 6 gradients are None)
         spec, slope, need_x, need_w = ctx.cfg
         saved = list(ctx.saved_tensors)
         x, acts = saved[0], saved[1:6]
@@ -388,6 +401,10 @@ class ConvStackFn(torch.autograd.Function):
             else:
                 g = None
                 break
+        if need_x and ctx.u0:                                    # gradient of the whole input: zeros for the no-grad head
+            full = torch.zeros((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+            full[ctx.u0:] = g
+            g = full
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)
 
 

@@ -65,7 +65,9 @@ class DiscriminatorP(nn.Module):
                                    + [_WNConv2d(1024, 1024, (kernel_size, 1), (1, 1), p)])
         self.conv_post = _WNConv2d(1024, 1, (3, 1), (1, 1), (1, 0))
 
-    def forward(self, x):
+    def forward(self, x, nograd_head=0):
+        """nograd_head = B0 (bf16 mode only): the first B0 waves are a no-grad branch sharing the launches; returns
+        ((score, fmap) of the head, (score, fmap) of the rest)."""
         x = x.unsqueeze(1)
         b, c, t = x.shape
         if t % self.period != 0:
@@ -78,6 +80,10 @@ class DiscriminatorP(nn.Module):
             args = []
             for conv in list(self.convs) + [self.conv_post]:
                 args += [conv.weight_v, conv.weight_g, conv.bias]
+            if nograd_head:
+                o = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, (self.lrelu_slope, nograd_head * self.period), *args)
+                (_, r2, r3, r4, r5, rs), (_, y2, y3, y4, y5, s) = o[:6], o[6:]
+                return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
             return s.view(b, -1), [y2, y3, y4, y5, s]
         x = x.view(b, c, t // self.period, self.period)
@@ -107,7 +113,7 @@ class DiscriminatorR(nn.Module):
         n_fft, hop, win = self.resolution
         return spectral.stft_magnitude(x, n_fft, hop, None, None).transpose(1, 2)      # (B, freq, frames)
 
-    def forward(self, x):
+    def forward(self, x, nograd_head=0):
         if precision.is_bf16():
             n_fft, hop, win = self.resolution
             spec = spectral.stft_magnitude(x, n_fft, hop, None, None)              # (B, frames, bins), channels-last
@@ -115,6 +121,10 @@ class DiscriminatorR(nn.Module):
             for conv in list(self.convs) + [self.conv_post]:
                 # reference weight (Cout, Cin, k_freq, k_time) is packed to native (Cout, KH = k_time, KW = k_freq, Cin)
                 args += [conv.weight_v, conv.weight_g, conv.bias]
+            if nograd_head:
+                o = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, (self.lrelu_slope, nograd_head), *args)
+                r, y = o[:6], o[6:]
+                return (r[5].reshape(nograd_head, -1), list(r)), (y[5].reshape(y[5].shape[0], -1), list(y))
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
             return s.reshape(s.shape[0], -1), [y1, y2, y3, y4, y5, s]
         fmap = []
@@ -157,6 +167,10 @@ class _Multi(nn.Module):
                 o, fm = d(torch.cat([y, y_hat], 0))
                 r, g = o[:B], o[B:]
                 fr, fg = [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm]
+            elif precision.is_bf16():
+                # generator phase: real (no gradient) and generated waves share every forward launch; the backward of the
+                # stack only covers the generated half
+                (r, fr), (g, fg) = d(torch.cat([y, y_hat], 0), nograd_head=B)
             else:
                 with torch.no_grad():
                     r, fr = d(y)
