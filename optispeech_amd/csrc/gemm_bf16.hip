@@ -1174,7 +1174,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
 // T = 64 (the 64-channel DiscriminatorR layers): 4 waves of 32x32, 128-byte rows (two rows per 64 banks), the 4 frame
 // rows of a transposed read alternate bank halves and slot ^= 4 * ((row >> 1) & 1) separates the pairs.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-template <int T>
+// F32 = true: f32 operands in HBM (the generator's activations); the slab goes global -> registers -> bf16 -> LDS (same
+// LDS image as the DMA path, so the transposed reads are shared), with the optional per-frame scale `arow` applied to dY.
+template <int T, bool F32 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     constexpr int SK = 64;                                   // frames per slab
     constexpr int S = T / 8, RPI = 64 / S, NI = SK / RPI / 4, TI = T / 64;   // slots/row, rows/instruction, instr/wave/operand
@@ -1226,6 +1228,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) issue_pair(mk, buf, i);
     };
+    // f32 operands: the same (row, slot) assignment, through registers
+    const float* dYf = reinterpret_cast<const float*>(p.dY) + (int64_t)bz * p.sYb;
+    const float* Xf = reinterpret_cast<const float*>(p.X) + (int64_t)bz * p.sXb;
+    const float* arow = p.arow ? p.arow + (int64_t)bz * p.M : nullptr;
+    float4 ry[NI][2], rx[NI][2];
+    auto gload_f32 = [&](int mk) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row0 = RPI * (NI * wave + i), m = mk + row0 + srow;
+            const bool mv = m < mend;
+            const int mc = mv ? m : mbeg;                                         // index select: loads stay unconditional
+            const float4* ys4 = reinterpret_cast<const float4*>(dYf + (int64_t)mc * ldy + n0 + lslot * 8);
+            const float sc = mv ? (arow ? arow[mc] : 1.f) : 0.f;
+            float4 a = ys4[0], b = ys4[1];
+            ry[i][0] = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+            ry[i][1] = make_float4(b.x * sc, b.y * sc, b.z * sc, b.w * sc);
+            const int u = fd_div(mc, p.fd_trows), t = mc - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+            const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+            const bool xv = mv && tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin;
+            const int64_t xr = xv ? (((int64_t)u * p.Hin + hh) * p.Tin + tt) : 0;
+            const float4* xs4 = reinterpret_cast<const float4*>(Xf + xr * ldx + c0 + lslot * 8);
+            const float xsel = xv ? 1.f : 0.f;
+            a = xs4[0]; b = xs4[1];
+            rx[i][0] = make_float4(a.x * xsel, a.y * xsel, a.z * xsel, a.w * xsel);
+            rx[i][1] = make_float4(b.x * xsel, b.y * xsel, b.z * xsel, b.w * xsel);
+        }
+    };
+    auto sstore_f32 = [&](int buf) {
+        unsigned short* ys = smem + buf * (2 * SK * T);
+        unsigned short* xs = ys + SK * T;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int off = (RPI * (NI * wave + i) + srow) * T + (lane % S) * 8;
+            *reinterpret_cast<uint4*>(ys + off) = make_uint4(pk2(ry[i][0].x, ry[i][0].y), pk2(ry[i][0].z, ry[i][0].w),
+                                                             pk2(ry[i][1].x, ry[i][1].y), pk2(ry[i][1].z, ry[i][1].w));
+            *reinterpret_cast<uint4*>(xs + off) = make_uint4(pk2(rx[i][0].x, rx[i][0].y), pk2(rx[i][0].z, rx[i][0].w),
+                                                             pk2(rx[i][1].x, rx[i][1].y), pk2(rx[i][1].z, rx[i][1].w));
+        }
+    };
     // fragment of operand tile `base` ([SK][T]) for the 32 channels starting at `col0`, k-step ks: 8 consecutive frames
     const int r16 = lane & 15, g16 = (lane >> 4) & 1, kg = lane >> 5;
     auto frag = [&](const unsigned short* base, int col0, int ks) -> bf16x8 {
@@ -1264,7 +1305,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
         }
     };
     const int niter = (mend - mbeg + SK - 1) / SK;
-    if (niter > 0) {
+    if constexpr (F32) {
+        if (niter > 0) {
+            gload_f32(mbeg);
+            sstore_f32(0);
+            __syncthreads();
+            for (int it = 0; it < niter; ++it) {
+                const int buf = it & 1;
+                if (it + 1 < niter) gload_f32(mbeg + (it + 1) * SK);
+                mma(buf, -1);
+                if (it + 1 < niter) sstore_f32(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    } else if (niter > 0) {
         issue(mbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1342,6 +1396,18 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         const dim3 g((unsigned)(N / T_), (unsigned)(taps * (Cin / T_)), (unsigned)(sp * batch));
         if (T_ == 128) hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<64>, g, dim3(256), 0, stream, p);
+    }
+    else if (use_tr && !y_bf16 && !x_bf16 && N % 64 == 0 && Cin % 64 == 0 && (ldy % 4 == 0) && (ldx % 4 == 0) &&
+             ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0 && (sYb % 4 == 0) && (sXb % 4 == 0)) {
+        // f32 operands (generator): 64-channel tiles through registers; small problems -> many splits
+        const int64_t tl = (N / 64) * taps * (Cin / 64) * batch;
+        int64_t sp = tl >= 960 ? 1 : (2048 + tl / 2) / tl;
+        int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
+        if (ch < 2 * TBK) ch = 2 * TBK;
+        sp = cdiv(M, ch);
+        p.chunk = (int)ch; p.splits = (int)sp;
+        const dim3 g((unsigned)(N / 64), (unsigned)(taps * (Cin / 64)), (unsigned)(sp * batch));
+        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<64, true>), g, dim3(256), 0, stream, p);
     }
     else if (fast) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p);
