@@ -52,7 +52,7 @@ struct GemmB {
     const void* B; int b_bf16; int64_t sBn, sBtap, sBk; int N;
     void* C; int c_bf16; int64_t ldc; int Tc, c_step, c_off;
     int epi; const float *bias, *gamma, *res; int64_t ldr; const float *rowmask, *rowscale;
-    float* aux_out; const void* aux_in; int aux_bf16; int64_t ld_aux; float slope;
+    void* aux_out; const void* aux_in; int aux_bf16; int64_t ld_aux; float slope;   // aux_bf16 describes whichever aux is used
     const void* res_any; int res_bf16;   // LRELU_BWD extra addend (f32 or bf16)
     // 2-D (conv2d over channels-last (U,H,W,C)) extension; the 1-D case has Hin = 1, Wrows = Trows, KW = taps
     int Wrows, Hin, KW, a_step_h, a_tapstep_h, a_off_h, Wc, c_step_h, c_off_h; int64_t sBtap_h;
@@ -114,18 +114,23 @@ __device__ __forceinline__ float dpp_swap1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
 }
 
+__device__ __forceinline__ void st_aux(void* p, int is_bf16, int64_t idx, float v) {
+    if (is_bf16) reinterpret_cast<__bf16*>(p)[idx] = (__bf16)v;
+    else reinterpret_cast<float*>(p)[idx] = v;
+}
+
 template <int EPI>
 __device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, int64_t mr, int64_t crow, int n, float gam,
-                                                     const float* res, const char* aux_in, float* aux_out) {
+                                                     const float* res, const char* aux_in, char* aux_out) {
     float out = v;
     if constexpr (EPI == BEPI_RELU) out = fmaxf(v, 0.f);
     if constexpr (EPI == BEPI_LRELU) out = v > 0.f ? v : v * pp.slope;
     if constexpr (EPI == BEPI_GELU) {
-        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+        if (aux_out) st_aux(aux_out, pp.aux_bf16, crow * pp.ld_aux + n, v);
         out = gelu_f(v);
     }
     if constexpr (EPI == BEPI_SCALE_RES_MASK) {
-        if (aux_out) aux_out[crow * pp.ld_aux + n] = v;
+        if (aux_out) st_aux(aux_out, pp.aux_bf16, crow * pp.ld_aux + n, v);
         const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
         out = (res[crow * pp.ldr + n] + rs * gam * v) * mk;
     }
@@ -152,7 +157,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * esC;
     const float* res = pp.res ? pp.res + bz * pp.sXb : nullptr;
     const char* aux_in = pp.aux_in ? reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
-    float* aux_out = pp.aux_out ? pp.aux_out + bz * pp.sXb : nullptr;
+    char* aux_out = pp.aux_out ? reinterpret_cast<char*>(pp.aux_out) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
     const int l31 = lane & 31, lh = lane >> 5;
     const bool c_bf16 = pp.c_bf16 != 0, accumulate = pp.accumulate != 0;
     const int Trows = pp.Trows, Wrows = pp.Wrows, Tc = pp.Tc, Wc = pp.Wc, c_step = pp.c_step, c_off = pp.c_off,
@@ -660,11 +665,11 @@ __device__ __forceinline__ void gemm_bf16_epi_elem(const GemmB& pp, float acc, i
         case BEPI_RELU: out = fmaxf(v, 0.f); break;
         case BEPI_LRELU: out = v > 0.f ? v : v * pp.slope; break;
         case BEPI_GELU:
-            if (pp.aux_out) (pp.aux_out + bz * pp.sXb)[crow * pp.ld_aux + n] = v;
+            if (pp.aux_out) st_aux(reinterpret_cast<char*>(pp.aux_out) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4), pp.aux_bf16, crow * pp.ld_aux + n, v);
             out = gelu_f(v);
             break;
         case BEPI_SCALE_RES_MASK: {
-            if (pp.aux_out) (pp.aux_out + bz * pp.sXb)[crow * pp.ld_aux + n] = v;
+            if (pp.aux_out) st_aux(reinterpret_cast<char*>(pp.aux_out) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4), pp.aux_bf16, crow * pp.ld_aux + n, v);
             const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
             out = ((pp.res + bz * pp.sXb)[crow * pp.ldr + n] + rs * (pp.gamma ? pp.gamma[n] : 1.f) * v) * mk;
             break;
@@ -811,7 +816,7 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
                                   int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
                                   int64_t c_step, int64_t c_off, int64_t epi, const float* bias, const float* gamma,
                                   const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
-                                  float* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
+                                  void* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
                                   int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
                                   hipStream_t stream) {
     OSP_CHECK_ARG(A && B && C, "null operand");
@@ -930,7 +935,7 @@ extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, in
                                   int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
                                   int64_t c_step, int64_t c_off, int64_t epi, const float* bias, const float* gamma,
                                   const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
-                                  float* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
+                                  void* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
                                   int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
                                   hipStream_t stream) {
     const int64_t d2[10] = {Trows, 1, taps, 0, 0, 0, Tc, 0, 0, 0};

@@ -302,6 +302,29 @@ def _isbf(t):
     return int(t is not None and t.dtype == torch.bfloat16)
 
 
+def pack_bf16(w, n_out, taps, cin, w_strides):
+    """(n_out, taps, cin) k-contiguous bf16 copy of a weight addressed through element strides (osp_pack_bf16)."""
+    wp = torch.empty((n_out, taps, cin), device=w.device, dtype=torch.bfloat16)
+    call("osp_pack_bf16", w, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
+    return wp
+
+
+def param_bf16(p, transposed=False):
+    """bf16 copy of a 2-D f32 parameter (N, K) -- or of its transpose -- cached on the Parameter object for the current
+    optimizer epoch (same invalidation rule as disc_ops.wnorm_packed)."""
+    from . import values
+    stamp = (values.param_epoch(), p._version, p.data_ptr())
+    cache = getattr(p, "_osp_bf16", None)
+    if cache is None or cache[0] != stamp:
+        cache = (stamp, {})
+        p._osp_bf16 = cache
+    if transposed not in cache[1]:
+        N, Kd = p.shape
+        cache[1][transposed] = (pack_bf16(p.detach(), Kd, 1, N, (1, 0, Kd)) if transposed
+                                else pack_bf16(p.detach(), N, 1, Kd, (Kd, 0, 1))).view(-1, N if transposed else Kd)
+    return cache[1][transposed]
+
+
 def cast_bf16(x):
     y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
     call("osp_cast_bf16", x.contiguous(), y, x.numel())
@@ -328,7 +351,8 @@ def conv_gemm_bf16(a, w, n_out, *, M, Trows, Tin, cin, taps=1, a_step=1, a_tapst
     ldr = res.stride(-2) if res is not None else 0
     call("osp_conv_gemm_bf16", a, _isbf(a), lda, M, Trows, Tin, cin, taps, a_step, a_tapstep, a_off, a_rowscale, w,
          _isbf(w), w_strides[0], w_strides[1], w_strides[2], n_out, out, _isbf(out), ldc, Tc, c_step, c_off, epi, bias,
-         gamma, res, _isbf(res), ldr, rowmask, rowscale, aux_out, aux_in, _isbf(aux_in), ld_aux, float(slope), batch,
+         gamma, res, _isbf(res), ldr, rowmask, rowscale, aux_out, aux_in, _isbf(aux_in if aux_in is not None else aux_out),
+         ld_aux, float(slope), batch,
          batch_strides[0], batch_strides[1], batch_strides[2], batch_strides[3], bool(accumulate))
     return out
 

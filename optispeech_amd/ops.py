@@ -7,6 +7,7 @@ parameter inputs.  Only activations flow through autograd.
 import torch
 
 from . import kernels as K
+from . import precision as _precision
 
 
 def gsink(p):
@@ -36,11 +37,23 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         x = x.contiguous()
         h, xhat, rstd = K.dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, 1e-6, save)
         h2 = h.view(M, C)
-        u = torch.empty((M, I), device=x.device, dtype=torch.float32) if save else None
-        g = K.conv_gemm(h2, W1, I, epi=K.EPI_GELU, bias=b1, aux_out=u)
         z = torch.empty((M, C), device=x.device, dtype=torch.float32) if save else None
-        y = K.conv_gemm(g, W2, C, epi=K.EPI_SCALE_RES_MASK, bias=b2, gamma=gamma, res=x.view(M, C),
-                        rowmask=rowmask, rowscale=rowscale, aux_out=z)
+        ctx.lowp = _precision.is_bf16() and I % 64 == 0 and C % 64 == 0
+        if ctx.lowp:
+            # performance mode: the I-wide intermediates (pre-activation u, gelu(u)) live in bf16 -- what autocast does
+            # to these matmul outputs in the reference's default `16-mixed` precision; the block's input / output /
+            # residual stream and the LayerNorm statistics stay f32.  Halves the dominant HBM traffic of the block and
+            # puts pwconv2 on the direct-to-LDS kernel (bf16 A operand).
+            u = torch.empty((M, I), device=x.device, dtype=torch.bfloat16) if save else None
+            g = K.conv_gemm_bf16(h2, K.param_bf16(W1), I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU, bias=b1, aux_out=u,
+                                 out_bf16=True)
+            y = K.conv_gemm_bf16(g, K.param_bf16(W2), C, M=M, Trows=M, Tin=M, cin=I, epi=K.EPI_SCALE_RES_MASK, bias=b2,
+                                 gamma=gamma, res=x.view(M, C), rowmask=rowmask, rowscale=rowscale, aux_out=z)
+        else:
+            u = torch.empty((M, I), device=x.device, dtype=torch.float32) if save else None
+            g = K.conv_gemm(h2, W1, I, epi=K.EPI_GELU, bias=b1, aux_out=u)
+            y = K.conv_gemm(g, W2, C, epi=K.EPI_SCALE_RES_MASK, bias=b2, gamma=gamma, res=x.view(M, C),
+                            rowmask=rowmask, rowscale=rowscale, aux_out=z)
         if save:
             if rowmask is not None and rowscale is not None:
                 rowf = rowmask * rowscale
@@ -65,12 +78,24 @@ class ConvNeXtBlockFn(torch.autograd.Function):
             gsink(gamma).add_(t.sum(0))
         W2g = W2 * gamma[:, None]
         # du[m,k] = rowf[m] * sum_n dy[m,n] * gamma[n] W2[n,k] * gelu'(u[m,k])
-        du = K.conv_gemm(dy2, W2g, I, cin=C, w_strides=(1, 0, I), epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u)
-        if _want(W2):
-            K.conv_wgrad(dy2, g, gsink(W2), gsink(b2) if _want(b2) else None, arow=rowf, oscale=gamma)
-        dh = K.conv_gemm(du, W1, C, cin=I, w_strides=(1, 0, C))
-        if _want(W1):
-            K.conv_wgrad(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None)
+        if ctx.lowp:
+            du = K.conv_gemm_bf16(dy2, K.pack_bf16(W2g, I, 1, C, (1, 0, I)), I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU_BWD,
+                                  rowscale=rowf, aux_in=u, out_bf16=True)
+            if _want(W2):
+                dys = K.cast_bf16(dy2 * rowf[:, None] if rowf is not None else dy2)
+                K.conv_wgrad_bf16(dys, g, gsink(W2), gsink(b2) if _want(b2) else None, M=M, Trows=M, Tin=M, n=C, cin=I,
+                                  oscale=gamma)
+            dh = K.conv_gemm_bf16(du, K.param_bf16(W1, transposed=True), C, M=M, Trows=M, Tin=M, cin=I)
+            if _want(W1):
+                K.conv_wgrad_bf16(du, K.cast_bf16(h.view(M, C)), gsink(W1), gsink(b1) if _want(b1) else None, M=M, Trows=M,
+                                  Tin=M, n=I, cin=C)
+        else:
+            du = K.conv_gemm(dy2, W2g, I, cin=C, w_strides=(1, 0, I), epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u)
+            if _want(W2):
+                K.conv_wgrad(dy2, g, gsink(W2), gsink(b2) if _want(b2) else None, arow=rowf, oscale=gamma)
+            dh = K.conv_gemm(du, W1, C, cin=I, w_strides=(1, 0, C))
+            if _want(W1):
+                K.conv_wgrad(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None)
         wl = _want(lnw)
         dc = K.layernorm_bwd(dh, xhat.view(M, C), None, rstd.view(M), lnw, gsink(lnw) if wl else None,
                              gsink(lnb) if wl else None)
