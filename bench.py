@@ -164,8 +164,25 @@ def main():
                 M_, N_ = args[3], args[23]
                 if N_ > 64 and -(-M_ // 128) * -(-N_ // 128) >= 160:
                     return 2.0 * M_ * args[9] * args[8] * N_                          # M, taps, Cin, N
+            # fused-phase dgrad (osp_conv2d_dgrad_bf16): the same kernel with blockIdx.z = output phase
+            if name == "osp_conv2d_dgrad_bf16" and args[1] == 1 and args[3] == 1:
+                U, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw = (args[6], args[7], args[8], args[11], args[12], args[13], args[14],
+                                                              args[15], args[16], args[17], args[18])
+                if Cout % 64 == 0 and Cin > 64 and Cout > 1:
+                    fl, mmax, nph = 0.0, 0, 0
+                    for rh in range(sh):
+                        for rw in range(sw):
+                            qh, qw = (H - rh + sh - 1) // sh, (W - rw + sw - 1) // sw
+                            if qh <= 0 or qw <= 0:
+                                continue
+                            n_h = (KH - (rh + ph) % sh + sh - 1) // sh
+                            n_w = (KW - (rw + pw) % sw + sw - 1) // sw
+                            fl += 2.0 * U * qh * qw * n_h * n_w * Cout * Cin
+                            mmax, nph = max(mmax, U * qh * qw), nph + 1
+                    if -(-mmax // 128) * -(-Cin // 128) * nph >= 160:
+                        return fl
             return None
-        roof_kernel, roof_peak = "conv_gemm_bf16_glds_kernel (MPD conv-GEMM forward + dgrad launches, N >= 128)", PEAK_BF16_MFMA_TFLOPS
+        roof_kernel, roof_peak = "conv_gemm_bf16_glds_kernel (MPD conv-GEMM forward + fused-phase dgrad launches, N >= 128)", PEAK_BF16_MFMA_TFLOPS
     else:
         M = B * T_MEL
 

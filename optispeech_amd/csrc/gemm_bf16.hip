@@ -56,9 +56,26 @@ struct GemmB {
     const void* res_any; int res_bf16;   // LRELU_BWD extra addend (f32 or bf16)
     // 2-D (conv2d over channels-last (U,H,W,C)) extension; the 1-D case has Hin = 1, Wrows = Trows, KW = taps
     int Wrows, Hin, KW, a_step_h, a_tapstep_h, a_off_h, Wc, c_step_h, c_off_h; int64_t sBtap_h;
-    int64_t sAb, sBb, sCb, sXb; int accumulate; int dbg;
+    int64_t sAb, sBb, sCb, sXb; int accumulate;
     FastDiv fd_trows, fd_wrows;
+    // output phases of a strided-conv dgrad fused into one launch (blockIdx.z = phase; batch must be 1): the fields a phase
+    // overrides -- its row count / geometry, tap subset (count, KW, first-tap offsets into dy and into the weights) and the
+    // output offsets.  M of the struct itself is the maximum over the phases (grid size).
+    int nphase;
+    struct Phase { int M, Trows, Wrows, taps, KW, a_off_h, a_off, c_off_h, c_off; int64_t b_off; FastDiv fd_trows, fd_wrows; } ph[4];
 };
+
+// effective parameters of this workgroup (wave-uniform: stays in SGPRs)
+__device__ __forceinline__ GemmB gemm_select_phase(const GemmB& pin) {
+    GemmB pp = pin;
+    if (pin.nphase > 0) {
+        const GemmB::Phase q = pin.ph[blockIdx.z];
+        pp.M = q.M; pp.Trows = q.Trows; pp.Wrows = q.Wrows; pp.taps = q.taps; pp.KW = q.KW; pp.a_off_h = q.a_off_h; pp.a_off = q.a_off;
+        pp.c_off_h = q.c_off_h; pp.c_off = q.c_off; pp.fd_trows = q.fd_trows; pp.fd_wrows = q.fd_wrows;
+        pp.B = reinterpret_cast<const char*>(pin.B) + q.b_off * (pin.b_bf16 ? 2 : 4);
+    }
+    return pp;
+}
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
     bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
@@ -286,7 +303,8 @@ __device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
 // FAST: every operand row is 16-byte addressable (Cin % 8 == 0, aligned strides, no per-row A scale) -- the generic
 // element-wise loaders are not even compiled into that instantiation (they bloat the loop past the I-cache).
 template <bool B_KCONTIG, int BKT, bool FAST, int BM_, int BN_>
-__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
+__global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pin) {
+    const GemmB pp = gemm_select_phase(pin);
     // hot-loop scalars in registers (the by-value struct must not be addressed inside the K loop)
     struct { int M, Trows, Wrows, Tin, Hin, Cin, taps, KW, a_step, a_step_h, a_off, a_off_h, a_tapstep, a_tapstep_h, N, a_bf16, b_bf16;
              int64_t lda, sBn, sBtap, sBtap_h, sBk; const float* a_rowscale; } p;
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pp) {
     int mb_, nb_;
     xcd_tile(mb_, nb_);
     const int m0 = mb_ * BM_, n0 = nb_ * BN_;
-    const int64_t bz = blockIdx.z;
+    const int64_t bz = pp.nphase > 0 ? 0 : blockIdx.z;
     const int esA = p.a_bf16 ? 2 : 4, esB = p.b_bf16 ? 2 : 4;
     const char* A = reinterpret_cast<const char*>(pp.A) + bz * pp.sAb * esA;
     const char* B = reinterpret_cast<const char*>(pp.B) + bz * pp.sBb * esB;
@@ -461,7 +479,8 @@ __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
 //   Per k-slab a CU then reads (128 + 64) * 64 * 2 B * 4 waves = 96 KB of fragments for 2 * 256*128*64 flop, i.e. LDS
 //   traffic per flop is 2/3 of the 128x128 tile's (which is LDS-bandwidth bound: 96 KB + 32 KB DMA per 512 MFMA clocks).
 template <int BM_, int NST, int BN_ = TBN>
-__device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsigned short* smem) {
+__device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem) {
+    const GemmB pp = gemm_select_phase(pin);
     constexpr int RA = BM_ / 32, RB = BN_ / 32, TM_ = BM_ / 64, TN_ = BN_ / 64;   // rows staged per thread (A, B); 32x32 tiles per wave along M
     unsigned short* As = smem;                       // [NST][BM_][64]
     unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][BN_][64]
@@ -470,7 +489,7 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pp, unsign
     int mb_, nb_;
     xcd_tile(mb_, nb_);
     const int m0 = mb_ * BM_, n0 = nb_ * BN_;
-    const int64_t bz = blockIdx.z;
+    const int64_t bz = pp.nphase > 0 ? 0 : blockIdx.z;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(pp.A) + bz * pp.sAb;
     const unsigned short* B = reinterpret_cast<const unsigned short*>(pp.B) + bz * pp.sBb;
     const int Cin = pp.Cin, Tin = pp.Tin, Hin = pp.Hin, KW = pp.KW, a_tapstep = pp.a_tapstep, a_tapstep_h = pp.a_tapstep_h;
@@ -810,48 +829,27 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
     }
 }
 
-static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
-                                  int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
-                                  const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
-                                  int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
-                                  int64_t c_step, int64_t c_off, int64_t epi, const float* bias, const float* gamma,
-                                  const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
-                                  void* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
-                                  int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
-                                  hipStream_t stream) {
-    OSP_CHECK_ARG(A && B && C, "null operand");
-    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && Tin > 0 && batch > 0, "bad shape");
-    OSP_CHECK_ARG(d2[0] > 0 && d2[1] > 0 && d2[2] > 0 && taps % d2[2] == 0 && Trows % d2[0] == 0, "bad 2-D geometry");
-    OSP_CHECK_ARG(M % Trows == 0, "M must be a whole number of utterances");
-    OSP_CHECK_ARG(sBk == 1 || sBn == 1, "B must be contiguous along k or along n");
-    OSP_CHECK_ARG(epi >= 0 && epi <= BEPI_LRELU_BWD, "unknown epilogue");
-    OSP_CHECK_ARG(epi != BEPI_SCALE_RES_MASK || (res && !res_bf16), "epilogue needs an f32 res");
-    OSP_CHECK_ARG((epi != BEPI_GELU_BWD && epi != BEPI_RELU_BWD && epi != BEPI_AXMY && epi != BEPI_LRELU_BWD) || aux_in, "epilogue needs aux_in");
-    OSP_CHECK_ARG(!(c_bf16 && accumulate), "accumulate needs an f32 destination");
-    GemmB p;
-    p.A = A; p.a_bf16 = (int)a_bf16; p.lda = lda; p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.Cin = (int)Cin;
-    p.taps = (int)taps; p.a_step = (int)a_step; p.a_tapstep = (int)a_tapstep; p.a_off = (int)a_off; p.a_rowscale = a_rowscale;
-    p.B = B; p.b_bf16 = (int)b_bf16; p.sBn = sBn; p.sBtap = sBtap; p.sBk = sBk; p.N = (int)N;
-    p.C = C; p.c_bf16 = (int)c_bf16; p.ldc = ldc; p.Tc = (int)Tc; p.c_step = (int)c_step; p.c_off = (int)c_off;
-    p.epi = (int)epi; p.bias = bias; p.gamma = gamma; p.res = res_bf16 ? nullptr : (const float*)res; p.ldr = ldr;
-    p.res_any = res; p.res_bf16 = (int)res_bf16; p.rowmask = rowmask; p.rowscale = rowscale;
-    p.aux_out = aux_out; p.aux_in = aux_in; p.aux_bf16 = (int)aux_bf16; p.ld_aux = ld_aux; p.slope = slope;
-    p.sAb = sAb; p.sBb = sBb; p.sCb = sCb; p.sXb = sXb; p.accumulate = (int)accumulate;
-    { const char* e = getenv("OSP_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
-    p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
-    p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
-    p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
+// Kernel selection + launch for a filled parameter block.  With p.nphase > 0 (fused dgrad phases) the grid's z dimension
+// enumerates the phases and p.M is the largest phase (see GemmB::Phase); batch must then be 1.
+static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
+    const int64_t M = p.M, N = p.N, Cin = p.Cin, taps = p.taps, lda = p.lda, sBn = p.sBn, sBtap = p.sBtap, sBk = p.sBk,
+                  sAb = p.sAb, sBb = p.sBb, a_bf16 = p.a_bf16, b_bf16 = p.b_bf16;
+    const int64_t d2_9 = p.sBtap_h;
+    const void *A = p.A, *B = p.B;
+    const float* a_rowscale = p.a_rowscale;
+    const int64_t batch = p.nphase > 0 ? p.nphase : batch_in;          // grid z
+    const bool single = p.nphase == 0 && batch_in == 1;                  // the degenerate-shape kernels take one problem
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int64_t ea = a_bf16 ? 2 : 4, eb = b_bf16 ? 2 : 4;
     const bool a_fast = (Cin % 8 == 0) && (lda % 8 == 0) && al16(A) && ((sAb * ea) % 16 == 0) && !a_rowscale;
     bool fast;
     if (sBk == 1)
-        fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && (d2[9] % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+        fast = a_fast && (sBn % 8 == 0) && (sBtap % 8 == 0) && (d2_9 % 8 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
     else
-        fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && (d2[9] % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
+        fast = a_fast && !b_bf16 && (sBk % 4 == 0) && (sBtap % 4 == 0) && (d2_9 % 4 == 0) && al16(B) && ((sBb * eb) % 16 == 0);
     static int use_degen = -1;
     if (use_degen < 0) { const char* e = getenv("OSP_GEMM_DEGEN"); use_degen = (e && atoi(e) == 0) ? 0 : 1; }
-    if (use_degen && N == 1 && batch == 1 && a_bf16 && a_fast && sBk == 1 && taps * Cin * 2 <= 65536) {
+    if (use_degen && N == 1 && single && a_bf16 && a_fast && sBk == 1 && taps * Cin * 2 <= 65536) {
         const int c8 = (int)(Cin / 8);
         const int L = c8 >= 64 ? 64 : (c8 >= 32 ? 32 : (c8 >= 16 ? 16 : (c8 >= 8 ? 8 : (c8 >= 4 ? 4 : (c8 >= 2 ? 2 : 1)))));
         const int64_t nb = cdiv(M, 256 / L);
@@ -864,7 +862,7 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
-    if (use_degen && Cin == 1 && batch == 1 && !a_rowscale && taps <= OUTER_MAXT && N % 8 == 0 && N >= 8 && N <= 2048) {
+    if (use_degen && Cin == 1 && single && !a_rowscale && taps <= OUTER_MAXT && N % 8 == 0 && N >= 8 && N <= 2048) {
         const int64_t rpb = 256 / (N / 8) > 0 ? 256 / (N / 8) : 1, nb = cdiv(M, rpb * 4);
         hipLaunchKernelGGL(conv_outer_bf16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, p);
         OSP_LAUNCH_CHECK();
@@ -929,6 +927,40 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     return OSP_OK;
 }
 
+static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
+                                  int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
+                                  const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
+                                  int64_t sBk, int64_t N, void* C, int64_t c_bf16, int64_t ldc, int64_t Tc,
+                                  int64_t c_step, int64_t c_off, int64_t epi, const float* bias, const float* gamma,
+                                  const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
+                                  void* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
+                                  int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
+                                  hipStream_t stream) {
+    OSP_CHECK_ARG(A && B && C, "null operand");
+    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && Tin > 0 && batch > 0, "bad shape");
+    OSP_CHECK_ARG(d2[0] > 0 && d2[1] > 0 && d2[2] > 0 && taps % d2[2] == 0 && Trows % d2[0] == 0, "bad 2-D geometry");
+    OSP_CHECK_ARG(M % Trows == 0, "M must be a whole number of utterances");
+    OSP_CHECK_ARG(sBk == 1 || sBn == 1, "B must be contiguous along k or along n");
+    OSP_CHECK_ARG(epi >= 0 && epi <= BEPI_LRELU_BWD, "unknown epilogue");
+    OSP_CHECK_ARG(epi != BEPI_SCALE_RES_MASK || (res && !res_bf16), "epilogue needs an f32 res");
+    OSP_CHECK_ARG((epi != BEPI_GELU_BWD && epi != BEPI_RELU_BWD && epi != BEPI_AXMY && epi != BEPI_LRELU_BWD) || aux_in, "epilogue needs aux_in");
+    OSP_CHECK_ARG(!(c_bf16 && accumulate), "accumulate needs an f32 destination");
+    GemmB p;
+    p.A = A; p.a_bf16 = (int)a_bf16; p.lda = lda; p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.Cin = (int)Cin;
+    p.taps = (int)taps; p.a_step = (int)a_step; p.a_tapstep = (int)a_tapstep; p.a_off = (int)a_off; p.a_rowscale = a_rowscale;
+    p.B = B; p.b_bf16 = (int)b_bf16; p.sBn = sBn; p.sBtap = sBtap; p.sBk = sBk; p.N = (int)N;
+    p.C = C; p.c_bf16 = (int)c_bf16; p.ldc = ldc; p.Tc = (int)Tc; p.c_step = (int)c_step; p.c_off = (int)c_off;
+    p.epi = (int)epi; p.bias = bias; p.gamma = gamma; p.res = res_bf16 ? nullptr : (const float*)res; p.ldr = ldr;
+    p.res_any = res; p.res_bf16 = (int)res_bf16; p.rowmask = rowmask; p.rowscale = rowscale;
+    p.aux_out = aux_out; p.aux_in = aux_in; p.aux_bf16 = (int)aux_bf16; p.ld_aux = ld_aux; p.slope = slope;
+    p.sAb = sAb; p.sBb = sBb; p.sCb = sCb; p.sXb = sXb; p.accumulate = (int)accumulate;
+    p.nphase = 0;
+    p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
+    p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
+    p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
+    return gemm_launch(p, batch, stream);
+}
+
 extern "C" int osp_conv_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
                                   int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
                                   const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
@@ -962,6 +994,67 @@ extern "C" int osp_conv2d_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, 
     return conv_gemm_bf16_impl(d2, A, a_bf16, lda, M, Trows, Win, Cin, taps, a_step, a_tapstep, a_off, nullptr, B, b_bf16, sBn,
                                sBtap, sBk, N, C, c_bf16, ldc, Tc, c_step, c_off, epi, bias, nullptr, res, res_bf16, ldr, nullptr,
                                nullptr, nullptr, aux_in, aux_bf16, ld_aux, slope, 1, 0, 0, 0, 0, 0, stream);
+}
+
+// dgrad of a strided channels-last conv2d, all output phases in ONE launch.
+//   dx[u, h, w, c] = epi( sum_{kh, kw, n} dy[u, (h + ph - kh) / sh, (w + pw - kw) / sw, n] * Wt[c, kh, kw, n] )   (exact divisions only)
+// Output phase (rh, rw) = (h % sh, w % sw) only sees the taps kh = kh0 + i*sh, kw = kw0 + j*sw (kh0 = (rh + ph) % sh, ...),
+// i.e. a dense convolution over dy with a sub-sampled kernel; phases differ in tap count, first-tap offsets and output offsets
+// (GemmB::Phase) and run as blockIdx.z of one grid instead of sh*sw small launches (DiscriminatorR: 4, DiscriminatorP: 3).
+// Wt: (Cin, KH, KW, Cout) = the weights transposed for dgrad.  epi: BEPI_NONE or BEPI_LRELU_BWD (aux_in = forward output y
+// of the previous layer, `res` an extra addend: the feature-matching gradient of that layer).
+extern "C" int osp_conv2d_dgrad_bf16(const void* dy, int64_t dy_bf16, const void* wt, int64_t w_bf16, void* dx, int64_t dx_bf16,
+                                     int64_t U, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int64_t KH,
+                                     int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t epi, const void* aux_in,
+                                     int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream) {
+    OSP_CHECK_ARG(dy && wt && dx, "null operand");
+    OSP_CHECK_ARG(U > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && sh > 0 && sw > 0, "bad shape");
+    OSP_CHECK_ARG(sh * sw <= 4 && KH >= sh && KW >= sw, "unsupported stride (at most 4 phases, kernel >= stride)");
+    OSP_CHECK_ARG(epi == BEPI_NONE || (epi == BEPI_LRELU_BWD && aux_in), "dgrad epilogue is NONE or LRELU_BWD");
+    GemmB p;
+    p.A = dy; p.a_bf16 = (int)dy_bf16; p.lda = Cout; p.Tin = (int)Wo; p.Hin = (int)Ho; p.Cin = (int)Cout;
+    p.a_step = 1; p.a_step_h = 1; p.a_tapstep = -1; p.a_tapstep_h = -1; p.a_rowscale = nullptr;
+    p.B = wt; p.b_bf16 = (int)w_bf16; p.sBn = KH * KW * Cout; p.sBtap_h = sh * KW * Cout; p.sBtap = sw * Cout; p.sBk = 1; p.N = (int)Cin;
+    p.C = dx; p.c_bf16 = (int)dx_bf16; p.ldc = Cin; p.Tc = (int)(H * W); p.Wc = (int)W; p.c_step_h = (int)sh; p.c_step = (int)sw;
+    p.epi = (int)epi; p.bias = nullptr; p.gamma = nullptr; p.res = res_bf16 ? nullptr : (const float*)res; p.ldr = Cin;
+    p.res_any = res; p.res_bf16 = (int)res_bf16; p.rowmask = nullptr; p.rowscale = nullptr;
+    p.aux_out = nullptr; p.aux_in = aux_in; p.aux_bf16 = (int)aux_bf16; p.ld_aux = Cin; p.slope = slope;
+    p.sAb = p.sBb = p.sCb = p.sXb = 0; p.accumulate = 0;
+    int np = 0;
+    for (int64_t rh = 0; rh < sh; ++rh)
+        for (int64_t rw = 0; rw < sw; ++rw) {
+            const int64_t qh = (H - rh + sh - 1) / sh, qw = (W - rw + sw - 1) / sw;
+            if (qh <= 0 || qw <= 0) continue;
+            const int64_t kh0 = (rh + ph) % sh, kw0 = (rw + pw) % sw;
+            const int64_t n_h = (KH - kh0 + sh - 1) / sh, n_w = (KW - kw0 + sw - 1) / sw;
+            GemmB::Phase& q = p.ph[np++];
+            q.M = (int)(U * qh * qw); q.Trows = (int)(qh * qw); q.Wrows = (int)qw; q.taps = (int)(n_h * n_w); q.KW = (int)n_w;
+            q.a_off_h = (int)((rh + ph - kh0) / sh); q.a_off = (int)((rw + pw - kw0) / sw); q.c_off_h = (int)rh; q.c_off = (int)rw;
+            q.b_off = (kh0 * KW + kw0) * Cout;
+            q.fd_trows = make_fastdiv((unsigned)q.Trows); q.fd_wrows = make_fastdiv((unsigned)q.Wrows);
+        }
+    OSP_CHECK_ARG(np > 0, "empty output");
+    // degenerate channel counts (first / last layers) go to the single-problem kernels: one launch per phase
+    const bool degenerate = (Cin == 1) || (Cout == 1);
+    int rc = OSP_OK;
+    for (int i = 0; i < (degenerate ? np : 1) && rc == OSP_OK; ++i) {
+        GemmB r = p;
+        const GemmB::Phase& q = p.ph[i];
+        if (degenerate) {
+            r.nphase = 0;
+            r.M = q.M; r.Trows = q.Trows; r.Wrows = q.Wrows; r.taps = q.taps; r.KW = q.KW; r.a_off_h = q.a_off_h; r.a_off = q.a_off;
+            r.c_off_h = q.c_off_h; r.c_off = q.c_off; r.fd_trows = q.fd_trows; r.fd_wrows = q.fd_wrows;
+            r.B = reinterpret_cast<const char*>(wt) + q.b_off * (w_bf16 ? 2 : 4);
+        } else {
+            r.nphase = np;
+            int mmax = 0, tmax = 0;
+            for (int k = 0; k < np; ++k) { mmax = p.ph[k].M > mmax ? p.ph[k].M : mmax; tmax = p.ph[k].taps > tmax ? p.ph[k].taps : tmax; }
+            r.M = mmax; r.Trows = p.ph[0].Trows; r.Wrows = p.ph[0].Wrows; r.taps = tmax; r.KW = p.ph[0].KW;
+            r.a_off_h = r.a_off = r.c_off_h = r.c_off = 0; r.fd_trows = p.ph[0].fd_trows; r.fd_wrows = p.ph[0].fd_wrows;
+        }
+        rc = gemm_launch(r, 1, stream);
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad

@@ -174,31 +174,15 @@ def transpose_weight2d(w):
 
 
 def conv2d_dgrad(dy, wt, H, W, KH, KW, sh, sw, ph, pw, *, lrelu_y=None, extra=None, slope=0.1, out_bf16=False):
-    """dx (U,H,W,Cin) of a strided conv2d: one GEMM per output phase (rh, rw) so only contributing taps are visited."""
+    """dx (U,H,W,Cin) of a strided conv2d.  Each output phase (h % sh, w % sw) only sees a sub-sampled kernel; all phases
+    run in ONE launch (osp_conv2d_dgrad_bf16, csrc/gemm_bf16.hip), with the LeakyReLU backward of the previous layer and
+    its feature-matching gradient (``extra``) fused into the epilogue."""
     U, Ho, Wo, Cout = dy.shape
     Cin = wt.shape[0]
     dx = torch.empty((U, H, W, Cin), device=dy.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    dy2 = dy.view(U * Ho * Wo, Cout)
-    epi = K.EPI_LRELU_BWD if lrelu_y is not None else K.EPI_NONE
-    for rh in range(sh):
-        qh = (H - rh + sh - 1) // sh
-        kh0 = (rh + ph) % sh
-        n_h = (KH - kh0 + sh - 1) // sh if kh0 < KH else 0
-        for rw in range(sw):
-            qw = (W - rw + sw - 1) // sw
-            kw0 = (rw + pw) % sw
-            n_w = (KW - kw0 + sw - 1) // sw if kw0 < KW else 0
-            if qh <= 0 or qw <= 0:
-                continue
-            assert n_h > 0 and n_w > 0, "kernel smaller than stride is not supported"
-            base = wt.view(Cin, KH, KW, Cout)[:, kh0:, kw0:, :]
-            K.conv2d_gemm_bf16(dy2, base, Cin, M=U * qh * qw, Trows=qh * qw, Wrows=qw, Hin=Ho, Win=Wo, cin=Cout,
-                               taps=n_h * n_w, KW=n_w, a_step_h=1, a_tapstep_h=-1, a_off_h=(rh + ph - kh0) // sh, a_step=1,
-                               a_tapstep=-1, a_off=(rw + pw - kw0) // sw,
-                               w_strides=(KH * KW * Cout, sh * KW * Cout, sw * Cout, 1), out=dx.view(U * H * W, Cin),
-                               ldc=Cin, Tc=H * W, Wc=W, c_step_h=sh, c_off_h=rh, c_step=sw, c_off=rw, epi=epi,
-                               aux_in=None if lrelu_y is None else lrelu_y.view(U * H * W, Cin),
-                               res=None if extra is None else extra.view(U * H * W, Cin), slope=slope)
+    isbf = lambda t: int(t is not None and t.dtype == torch.bfloat16)                 # noqa: E731
+    K.call("osp_conv2d_dgrad_bf16", dy, isbf(dy), wt, isbf(wt), dx, isbf(dx), U, H, W, Ho, Wo, Cin, Cout, KH, KW, sh, sw, ph, pw,
+           K.EPI_LRELU_BWD if lrelu_y is not None else K.EPI_NONE, lrelu_y, isbf(lrelu_y), extra, isbf(extra), float(slope))
     return dx
 
 
