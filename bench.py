@@ -214,6 +214,23 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     logs = model.fetch_logs()
+    # Second, untimed look at the same kernel with the sub-discriminator streams switched off: inside the timed region the
+    # eight discriminators run concurrently (optispeech_amd/model/discriminator.py), so a launch's event-to-event duration
+    # there includes whatever shared the GPU with it; serialised launches give the kernel's own efficiency.
+    iso = None
+    if a.precision == "bf16":
+        from optispeech_amd.model import discriminator as _disc
+        if _disc._DISC_STREAMS:
+            timed_events, timer.events = timer.events, []
+            _disc._DISC_STREAMS = False
+            timer.enabled = True
+            for i in range(3):
+                model.training_step(batch, a.warmup + a.steps + i)
+            sync()
+            timer.enabled = False
+            _disc._DISC_STREAMS = True
+            iso = timer.summary()
+            timer.events = timed_events
     ms_per_step = dt / a.steps * 1e3
     value = world * B * T_MEL / (dt / a.steps)
 
@@ -224,6 +241,11 @@ def main():
                 "unit": "TFLOP/s", "traffic": None, "launches_timed": nlaunch,
                 "avg_launch_us": (kms / nlaunch * 1e3) if nlaunch else None}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
+        if iso and iso[1]:
+            roof["concurrency"] = "timed region: sub-discriminators on 8 HIP streams (launch durations include co-scheduled kernels)"
+            roof["isolated"] = {"achieved": iso[0] / (iso[1] * 1e-3) / 1e12, "frac": iso[0] / (iso[1] * 1e-3) / 1e12 / roof_peak,
+                                "avg_launch_us": iso[1] / iso[2] * 1e3, "launches_timed": iso[2],
+                                "note": "same kernel, 3 extra untimed steps with the launches serialised on one stream"}
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read inside the timed
         # run); the committed summary of that pass is reported here when it matches the measured configuration
         pmc = os.path.join(ROOT, "profiles", "r01d_pmc_glds.json")

@@ -285,6 +285,11 @@ def wnorm_packed(v, g, want_f32, want_t):
     return pack
 
 
+def g_stream_is_side():
+    """True when the current stream is not the device's default stream (a sub-discriminator stream)."""
+    return torch.cuda.current_stream() != torch.cuda.default_stream()
+
+
 class ConvStackFn(torch.autograd.Function):
     """A whole DiscriminatorP / DiscriminatorR conv stack with weight norm folded in.
 
@@ -385,6 +390,11 @@ class ConvStackFn(torch.autograd.Function):
             else:
                 g = None
                 break
+        if any(need_w) and g_stream_is_side():
+            # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
+            # engine does not know that the stream backward() was called from must wait for this node's stream: say so.
+            side = torch.cuda.current_stream()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
         if need_x and ctx.u0:                                    # gradient of the whole input: zeros for the no-grad head
             full = torch.zeros((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
             full[ctx.u0:] = g

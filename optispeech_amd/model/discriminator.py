@@ -8,6 +8,8 @@ schema (`weight_g` / `weight_v`).
 """
 from types import SimpleNamespace
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -162,6 +164,8 @@ class _Multi(nn.Module):
             return rs, gs, frs, fgs
         real_needs_grad = any(p.requires_grad for p in self.parameters())
         B = y.shape[0]
+        if precision.is_bf16() and _DISC_STREAMS and y.is_cuda:
+            return self._forward_concurrent(torch.cat([y, y_hat], 0), B, real_needs_grad)
         for d in self.discriminators:
             if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
                 o, fm = d(torch.cat([y, y_hat], 0))
@@ -177,6 +181,46 @@ class _Multi(nn.Module):
                 g, fg = d(y_hat)
             rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
         return rs, gs, frs, fgs
+
+
+    def _forward_concurrent(self, x, B, with_param_grads):
+        """The sub-discriminators are independent (own weights, own spectrogram / period folding): each one runs on its own
+        HIP stream, so the many small launches of one (first / last layers, weight-norm packing, the narrow MRD layers)
+        overlap the large GEMMs of another.  autograd replays every node's backward on the stream its forward ran on and
+        joins the streams at the end of backward(), so the backward overlaps the same way."""
+        main = torch.cuda.current_stream()
+        streams = _disc_streams(id(self), len(self.discriminators), x.device)
+        ready = main.record_event()
+        outs = []
+        for d, st in zip(self.discriminators, streams):
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                if with_param_grads:                         # discriminator phase: one batch of 2B waves per launch
+                    o, fm = d(x)
+                    out = (o[:B], o[B:], [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm])
+                else:                                        # generator phase: no-grad head = the real waves
+                    (r, fr), (g, fg) = d(x, nograd_head=B)
+                    out = (r, g, fr, fg)
+            x.record_stream(st)
+            outs.append(out)
+        rs, gs, frs, fgs = [], [], [], []
+        for (r, g, fr, fg), st in zip(outs, streams):
+            main.wait_stream(st)
+            for t in [r, g] + list(fr) + list(fg):
+                t.record_stream(main)                        # consumed by the loss kernels on the main stream
+            rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
+        return rs, gs, frs, fgs
+
+
+_DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
+_STREAMS = {}
+
+
+def _disc_streams(key, n, device):
+    k = (key, torch.device(device).index)
+    if k not in _STREAMS:
+        _STREAMS[k] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _STREAMS[k]
 
 
 class MultiPeriodDiscriminator(_Multi):
