@@ -151,7 +151,7 @@ class _Multi(nn.Module):
             rs.append(r); frs.append(fr)
         return rs, frs
 
-    def forward(self, y, y_hat, real=None):
+    def forward(self, y, y_hat, real=None, defer_join=False):
         """Real and generated waves go through separately: in the generator phase the real branch needs no
         backward at all (it only feeds the feature-matching targets), so it runs under no_grad -- unless ``real``
         (a forward_real result) is supplied, in which case only the generated branch runs."""
@@ -165,7 +165,7 @@ class _Multi(nn.Module):
         real_needs_grad = any(p.requires_grad for p in self.parameters())
         B = y.shape[0]
         if precision.is_bf16() and _DISC_STREAMS and y.is_cuda:
-            return self._forward_concurrent(torch.cat([y, y_hat], 0), B, real_needs_grad)
+            return self._forward_concurrent(torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join)
         for d in self.discriminators:
             if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
                 o, fm = d(torch.cat([y, y_hat], 0))
@@ -183,7 +183,7 @@ class _Multi(nn.Module):
         return rs, gs, frs, fgs
 
 
-    def _forward_concurrent(self, x, B, with_param_grads):
+    def _forward_concurrent(self, x, B, with_param_grads, defer_join=False):
         """The sub-discriminators are independent (own weights, own spectrogram / period folding): each one runs on its own
         HIP stream, so the many small launches of one (first / last layers, weight-norm packing, the narrow MRD layers)
         overlap the large GEMMs of another.  autograd replays every node's backward on the stream its forward ran on and
@@ -205,15 +205,40 @@ class _Multi(nn.Module):
             outs.append(out)
         rs, gs, frs, fgs = [], [], [], []
         for (r, g, fr, fg), st in zip(outs, streams):
-            main.wait_stream(st)
-            for t in [r, g] + list(fr) + list(fg):
-                t.record_stream(main)                        # consumed by the loss kernels on the main stream
+            _PENDING.append((st, [r, g] + list(fr) + list(fg)))
             rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
+        if not defer_join:
+            join_streams()
         return rs, gs, frs, fgs
 
 
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
 _STREAMS = {}
+_PENDING = []
+
+
+def join_streams():
+    """The current stream waits for every side stream with work queued since the last join; the tensors produced there are
+    marked as used on the current stream (caching-allocator lifetime).  No host synchronisation."""
+    main = torch.cuda.current_stream()
+    while _PENDING:
+        st, tensors = _PENDING.pop()
+        main.wait_stream(st)
+        for t in tensors:
+            t.record_stream(main)
+
+
+def on_side_stream(key, fn, inputs):
+    """Run ``fn()`` on a persistent side stream (ordered after the current stream's work so far); joined by join_streams()."""
+    dev = inputs[0].device
+    st = _disc_streams(key, 1, dev)[0]
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out = fn()
+    for t in inputs:
+        t.record_stream(st)
+    _PENDING.append((st, [t for t in (out if isinstance(out, (tuple, list)) else [out]) if isinstance(t, torch.Tensor)]))
+    return out
 
 
 def _disc_streams(key, n, device):
@@ -280,19 +305,27 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         return self.multiperioddisc.forward_real(wav), self.multiresddisc.forward_real(wav)
 
     def forward_disc(self, wav, wav_hat, real=None):
-        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None)
-        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None)
+        # both families are launched before either is joined: the eight stacks overlap across the family boundary too
+        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True)
+        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True)
+        join_streams()
         loss_mp, loss_mrd = _hinge_d(r_mp, g_mp), _hinge_d(r_mr, g_mr)
         loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd
         return loss, dict(loss_mp=loss_mp.detach(), loss_mrd=loss_mrd.detach())
 
     def forward_gen(self, wav, wav_hat, real=None):
-        _, g_mp, fr_mp, fg_mp = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None)
-        _, g_mr, fr_mr, fg_mr = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None)
+        _, g_mp, fr_mp, fg_mp = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True)
+        _, g_mr, fr_mr, fg_mr = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True)
+        if precision.is_bf16() and _DISC_STREAMS and wav.is_cuda:
+            # the spectral reconstruction losses do not depend on the discriminators: a ninth stream
+            mel_loss, mr_stft_loss = on_side_stream(("spectral", id(self)), lambda: (self._get_mel_loss(wav, wav_hat),
+                                                                                   self._get_mr_stft_loss(wav, wav_hat)), [wav, wav_hat])
+        else:
+            mel_loss = self._get_mel_loss(wav, wav_hat)
+            mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
+        join_streams()
         loss_gen_mp, loss_gen_mrd = _hinge_g(g_mp), _hinge_g(g_mr)
         loss_fm_mp, loss_fm_mrd = _feature_matching(fr_mp, fg_mp), _feature_matching(fr_mr, fg_mr)
-        mel_loss = self._get_mel_loss(wav, wav_hat)
-        mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
         lam = self.loss_coeffs.lambda_mrd
         loss = loss_gen_mp + loss_gen_mrd * lam + loss_fm_mp + loss_fm_mrd * lam + mel_loss + mr_stft_loss
         logs = dict(loss_gen_mp=loss_gen_mp, loss_gen_mrd=loss_gen_mrd, loss_fm_mp=loss_fm_mp, loss_fm_mrd=loss_fm_mrd,
