@@ -151,7 +151,7 @@ class _Multi(nn.Module):
             rs.append(r); frs.append(fr)
         return rs, frs
 
-    def forward(self, y, y_hat, real=None, defer_join=False):
+    def forward(self, y, y_hat, real=None, defer_join=False, pre=None):
         """Real and generated waves go through separately: in the generator phase the real branch needs no
         backward at all (it only feeds the feature-matching targets), so it runs under no_grad -- unless ``real``
         (a forward_real result) is supplied, in which case only the generated branch runs."""
@@ -165,7 +165,8 @@ class _Multi(nn.Module):
         real_needs_grad = any(p.requires_grad for p in self.parameters())
         B = y.shape[0]
         if precision.is_bf16() and _DISC_STREAMS and y.is_cuda:
-            return self._forward_concurrent(torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join)
+            return self._forward_concurrent(pre[0] if pre is not None else torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join,
+                                            pre[1] if pre is not None else None)
         for d in self.discriminators:
             if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
                 o, fm = d(torch.cat([y, y_hat], 0))
@@ -183,14 +184,15 @@ class _Multi(nn.Module):
         return rs, gs, frs, fgs
 
 
-    def _forward_concurrent(self, x, B, with_param_grads, defer_join=False):
+    def _forward_concurrent(self, x, B, with_param_grads, defer_join=False, ready=None):
         """The sub-discriminators are independent (own weights, own spectrogram / period folding): each one runs on its own
         HIP stream, so the many small launches of one (first / last layers, weight-norm packing, the narrow MRD layers)
         overlap the large GEMMs of another.  autograd replays every node's backward on the stream its forward ran on and
         joins the streams at the end of backward(), so the backward overlaps the same way."""
         main = torch.cuda.current_stream()
         streams = _disc_streams(id(self), len(self.discriminators), x.device)
-        ready = main.record_event()
+        if ready is None:
+            ready = main.record_event()
         outs = []
         for d, st in zip(self.discriminators, streams):
             st.wait_event(ready)
@@ -304,10 +306,19 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
     def forward_real(self, wav):
         return self.multiperioddisc.forward_real(wav), self.multiresddisc.forward_real(wav)
 
-    def forward_disc(self, wav, wav_hat, real=None):
+    def prepare_disc_inputs(self, wav, wav_hat):
+        """(concatenated waves, 'ready' event) for a later forward_disc: taken right after the generator forward so that the
+        discriminator-phase forward does not have to wait for whatever the calling stream does in between (the generator's
+        backward), only for the waves themselves."""
+        if not (precision.is_bf16() and _DISC_STREAMS and wav.is_cuda):
+            return None
+        x = torch.cat([wav, wav_hat], 0)
+        return x, torch.cuda.current_stream().record_event()
+
+    def forward_disc(self, wav, wav_hat, real=None, pre=None):
         # both families are launched before either is joined: the eight stacks overlap across the family boundary too
-        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True)
-        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True)
+        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True, pre=pre)
+        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True, pre=pre)
         join_streams()
         loss_mp, loss_mrd = _hinge_d(r_mp, g_mp), _hinge_d(r_mr, g_mr)
         loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd

@@ -150,13 +150,16 @@ class OptiSpeech(nn.Module):
                                                        share_real=train_discriminator and self.share_real_pass)
         if apply:
             opt_g.zero_grad()
+        # the discriminator-phase inputs are fixed from here on: stage them before the generator's backward is queued, so
+        # that the discriminator-phase forward (side streams) overlaps that backward (this stream)
+        pre = self.discriminator.prepare_disc_inputs(wav, wav_hat.detach()) if train_discriminator and self._real_pass is None else None
         (loss_g / scale).backward()
         red_g.start(opt_g.arena.grad)
         for p in self.discriminator.parameters():
             p.requires_grad_(True)
         # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce)
         if train_discriminator:
-            loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs)
+            loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs, pre=pre)
             if apply:
                 opt_d.zero_grad()
             (loss_d / scale).backward()
@@ -203,11 +206,11 @@ class OptiSpeech(nn.Module):
         self._last_gen_outputs = gen_outputs
         return loss, (wav.detach(), wav_hat)
 
-    def training_step_d(self, batch, wav_outputs, logs):
+    def training_step_d(self, batch, wav_outputs, logs, pre=None):
         """base_lightning_module.py:163-186; D sees wav_hat.detach()."""
         wav, wav_hat = wav_outputs
         real, self._real_pass = getattr(self, "_real_pass", None), None
-        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real)
+        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real, pre=pre)
         logs["total_loss/discriminator"] = loss.detach()
         logs.update({f"discriminator/{k}": v for k, v in log_dict.items()})
         return loss
