@@ -7,6 +7,7 @@ module owns its optimisers (``configure_optimizers()`` is called lazily), the st
 (``global_step`` = number of optimiser steps taken, both optimisers counted -- which is what
 ``self.global_step >= pretraining_steps`` compares against upstream) and the data-parallel gradient reducer.
 """
+import contextlib
 import io
 import pickle
 from functools import partial
@@ -78,6 +79,10 @@ class OptiSpeech(nn.Module):
         self.max_steps = 2_000_000
         self._opts = None
         self.share_real_pass = os.environ.get("OSP_SHARE_REAL", "0") == "1"
+        #: issue the discriminator phase from its own stream so that consecutive steps overlap (see training_step); off by
+        #: default because code that reads discriminator parameters from another stream must then call join() first
+        self.pipeline_steps = os.environ.get("OSP_PIPELINE_STEPS", "0") == "1"
+        self._dstream = None
         self._reducers = None
         self.last_logs = {}
 
@@ -157,25 +162,49 @@ class OptiSpeech(nn.Module):
         red_g.start(opt_g.arena.grad)
         for p in self.discriminator.parameters():
             p.requires_grad_(True)
-        # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce)
+        # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce).
+        # With ``pipeline_steps`` its loss / backward / optimizer step are issued from a second "calling" stream: the
+        # calling stream proper only carries the generator work, so the NEXT step's generator forward (which needs the
+        # updated generator weights, not the discriminator's) overlaps this step's discriminator backward.  The
+        # discriminator stream is joined before anything reads discriminator state again (training_step_g, fetch_logs,
+        # state_dict, join()).
+        dctx = self._disc_phase_stream() if (train_discriminator and self.pipeline_steps) else contextlib.nullcontext()
         if train_discriminator:
-            loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs, pre=pre)
-            if apply:
-                opt_d.zero_grad()
-            (loss_d / scale).backward()
-            red_d.start(opt_d.arena.grad)
+            with dctx:
+                loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs, pre=pre)
+                if apply:
+                    opt_d.zero_grad()
+                (loss_d / scale).backward()
+                red_d.start(opt_d.arena.grad)
         red_g.wait()
         if apply:
             opt_g.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_g.world)
             sched_g.step()
             self.global_step += 1
         if train_discriminator:
-            red_d.wait()
-            if apply:
-                opt_d.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_d.world)
-                sched_d.step()
-                self.global_step += 1
+            with dctx:
+                red_d.wait()
+                if apply:
+                    opt_d.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_d.world)
+                    sched_d.step()
+                    self.global_step += 1
         self.last_logs = logs
+
+    def _disc_phase_stream(self):
+        """Context manager: make the discriminator-phase stream current, ordered after the calling stream's work so far."""
+        if self._dstream is None:
+            self._dstream = torch.cuda.Stream(device=self.device)
+        self._dstream.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._dstream)
+
+    def join(self):
+        """The current stream waits for a discriminator phase still in flight (``pipeline_steps``); no host sync."""
+        if self._dstream is not None:
+            torch.cuda.current_stream().wait_stream(self._dstream)
+
+    def state_dict(self, *args, **kwargs):
+        self.join()
+        return super().state_dict(*args, **kwargs)
 
     def training_step_g(self, batch, train_discriminator, logs, share_real=False):
         """base_lightning_module.py:128-161 (log values stay on the device; see fetch_logs).
@@ -192,6 +221,7 @@ class OptiSpeech(nn.Module):
         wav, wav_hat = gen_outputs["wav"], gen_outputs["wav_hat"]
         self._real_pass = None
         if train_discriminator:
+            self.join()                          # a pipelined discriminator update of the previous step must have landed
             if share_real:
                 self._real_pass = self.discriminator.forward_real(wav)
             for p in self.discriminator.parameters():
@@ -219,6 +249,7 @@ class OptiSpeech(nn.Module):
         """All logged scalars with ONE device->host copy (and one packed all-reduce under data parallelism)."""
         if not self.last_logs:
             return {}
+        self.join()
         keys = list(self.last_logs)
         packed = torch.stack([self.last_logs[k].float().reshape(()) for k in keys])
         if self._reducers is not None:

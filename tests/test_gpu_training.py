@@ -171,3 +171,47 @@ def test_training_step_runs_and_updates():
     # touches it, and at warm-up learning rates (<= 4e-7) that is below f32 resolution
     dec = m.generator.decoder.convnext[0].pwconv1_weight
     assert float(dec.grad.abs().max()) == 0.0 and relerr(dec, dec0) < 1e-6
+
+
+def test_pipelined_steps_match_serial_steps():
+    """``pipeline_steps`` (discriminator phase issued from its own stream, joined lazily) changes the schedule, not the
+    result.  One step from identical weights must agree tightly (both phases, both optimizer updates); later steps are only
+    checked for sanity, because the MAS alignment is discrete and amplifies atomics-order noise between ANY two runs."""
+    from optispeech_amd import precision, rng
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    precision.set_precision("bf16")
+    try:
+        cfg = ModelConfig()
+        batch = synthetic_batch(2, 24, 96, cfg, seed=5, device="cuda")
+        r01 = torch.rand(2, generator=torch.Generator().manual_seed(1))
+        out = []
+        for pipe in (False, True):
+            torch.manual_seed(3)
+            rng.manual_seed(3, 0)
+            rng._state["next_stream"] = 1                       # same dropout-site stream ids for both models
+            m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to("cuda").train()
+            m.pipeline_steps = pipe
+            m.generator.segment_rand01 = r01
+            m.optimizers()
+            for sch in m.lr_schedulers():                       # no warm-up: the first update is a full-size AdamW step
+                sch.warmup = 0
+                sch.opt.lr = sch.base_lr
+            m.training_step(batch, 0)
+            logs = m.fetch_logs()                               # joins the discriminator stream
+            sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            m.training_step(batch, 1)
+            m.training_step(batch, 2)
+            logs3 = m.fetch_logs()
+            assert all(np.isfinite(v) for v in logs3.values())
+            out.append((sd, logs))
+        (a, la), (b, lb) = out
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-3 * abs(la[k]) + 1e-5, (k, la[k], lb[k])
+        moved = 0
+        for k in a:
+            # a first AdamW step moves every weight by +-lr (2e-4): a gradient whose sign is noise-level may flip -> 2 lr
+            assert torch.allclose(a[k], b[k], rtol=1e-3, atol=5e-4), (k, (a[k] - b[k]).abs().max().item())
+            moved += int("discriminator" in k and a[k].is_floating_point())
+        assert moved > 0
+    finally:
+        precision.set_precision("f32")
