@@ -64,26 +64,32 @@ class _Lib:
         return f
 
     def call(self, name, *args):
-        f = self.fn(name)
-        cargs = []
-        for a in args:
-            if isinstance(a, torch.Tensor):
-                if not a.is_cuda:
-                    raise OspError(f"{name}: tensor argument is not on the GPU")
-                cargs.append(a.data_ptr())
-            elif a is None or isinstance(a, (int, float)):
-                cargs.append(a)
-            else:
-                raise TypeError(f"{name}: unsupported argument type {type(a)}")
-        # torch's current HIP stream of the current device (raw handle; torch.cuda.current_stream() costs ~9 us per call)
-        cargs.append(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
-        if f.argtypes is None:
-            raise OspError(f"{name} is not declared in include/osp.h (regenerate it with tools/gen_header.py)")
-        if len(cargs) != len(f.argtypes):
-            raise TypeError(f"{name}: {len(cargs) - 1} arguments given, include/osp.h declares {len(f.argtypes) - 1}")
-        rc = f(*cargs)
+        # hot path (~850 calls per training step): keep the per-argument work minimal.  ctypes converts ints / floats /
+        # None through the header-derived argtypes; tensors are passed as their device address.
+        f = self._fn.get(name) or self.fn(name)
+        T = torch.Tensor
+        cargs = [a.data_ptr() if isinstance(a, T) else a for a in args]
+        if _GUARD and any(isinstance(a, T) and not a.is_cuda for a in args):
+            raise OspError(f"{name}: tensor argument is not on the GPU")
+        cargs.append(_raw_stream(_cur_device()))      # torch's current HIP stream (raw handle)
+        try:
+            rc = f(*cargs)
+        except ctypes.ArgumentError as e:
+            raise TypeError(f"{name}: {e} (argument types must match include/osp.h)") from None
+        except TypeError:
+            if f.argtypes is None:
+                raise OspError(f"{name} is not declared in include/osp.h (regenerate it with tools/gen_header.py)") from None
+            raise TypeError(f"{name}: {len(cargs) - 1} arguments given, include/osp.h declares {len(f.argtypes) - 1}") from None
         if rc != 0:
+            if any(isinstance(a, T) and not a.is_cuda for a in args):
+                raise OspError(f"{name}: tensor argument is not on the GPU")
             raise OspError(f"{name} failed ({rc}): {self.cdll.osp_last_error().decode()}")
+
+
+#: reject host tensors before launching (a host pointer would fault on the device); OSP_FAST_CALL=1 drops the check
+_GUARD = os.environ.get("OSP_FAST_CALL", "0") != "1"
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
 
 
 _LIB = None
