@@ -32,6 +32,11 @@ class ModelConfig:
     dec_layers: int = 4                                   # decoder/convnext.yaml
     dec_inter: int = 1024
     dec_drop_path: float = 0.2
+    backbone: str = "convnext"                            # "transformer" = BASELINE config 4 (encoder/decoder/transformer.yaml)
+    tf_heads: int = 2
+    tf_units: int = 1024
+    tf_blocks: int = 4
+    tf_dropout: float = 0.2
     dur: tuple = (2, 384, 3, 0.1)                         # layers, channels, kernel, dropout
     pitch: tuple = (5, 256, 5, 0.5)
     energy: tuple = (2, 384, 3, 0.5)
@@ -62,6 +67,19 @@ class ModelConfig:
         return c
 
 
+
+def _backbones(c):
+    """(encoder, decoder) partials: ConvNeXt (configs[1]) or the Transformer variant (configs[4])."""
+    if c.backbone == "transformer":
+        from .model.transformer import Transformer
+        tf = partial(Transformer, attention_heads=c.tf_heads, linear_units=c.tf_units, num_blocks=c.tf_blocks,
+                     dropout_rate=c.tf_dropout, positional_dropout_rate=c.tf_dropout, attention_dropout_rate=c.tf_dropout)
+        return tf, tf
+    from .model.modules import ConvNeXtBackbone
+    return (partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers, drop_path=c.enc_drop_path),
+            partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers, drop_path=c.dec_drop_path))
+
+
 def make_generator(c: ModelConfig):
     from .model.generator import OptiSpeechGenerator
     from .model.modules import (ConvNeXtBackbone, DurationPredictor, EnergyPredictor, PitchPredictor, TextEmbedding)
@@ -77,15 +95,13 @@ def make_generator(c: ModelConfig):
         dim=c.dim, segment_size=c.segment_size,
         text_embedding=partial(TextEmbedding, n_vocab=c.n_vocab, dropout=c.text_dropout, padding_idx=0,
                                max_source_positions=c.max_source_positions),
-        encoder=partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers,
-                        drop_path=c.enc_drop_path),
+        encoder=_backbones(c)[0],
         duration_predictor=pred(DurationPredictor, c.dur),
         pitch_predictor=pred(PitchPredictor, c.pitch, embed_kernel_size=c.embed_kernel,
                              embed_dropout=c.pitch_embed_dropout),
         energy_predictor=pred(EnergyPredictor, c.energy, embed_kernel_size=c.embed_kernel,
                               embed_dropout=c.energy_embed_dropout),
-        decoder=partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers,
-                        drop_path=c.dec_drop_path),
+        decoder=_backbones(c)[1],
         vocoder=partial(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers,
                         drop_path=c.voc_drop_path),
         loss_coeffs=loss_coeffs, feature_extractor=c.fe, num_speakers=1, num_languages=1, data_statistics=None)
@@ -109,15 +125,13 @@ def make_optispeech(c: ModelConfig = None, batch_size=32, pretraining_steps=1000
         OptiSpeechGenerator, segment_size=c.segment_size,
         text_embedding=partial(TextEmbedding, n_vocab=c.n_vocab, dropout=c.text_dropout, padding_idx=0,
                                max_source_positions=c.max_source_positions),
-        encoder=partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers,
-                        drop_path=c.enc_drop_path),
+        encoder=_backbones(c)[0],
         duration_predictor=pred(DurationPredictor, c.dur),
         pitch_predictor=pred(PitchPredictor, c.pitch, embed_kernel_size=c.embed_kernel,
                              embed_dropout=c.pitch_embed_dropout),
         energy_predictor=pred(EnergyPredictor, c.energy, embed_kernel_size=c.embed_kernel,
                               embed_dropout=c.energy_embed_dropout),
-        decoder=partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers,
-                        drop_path=c.dec_drop_path),
+        decoder=_backbones(c)[1],
         loss_coeffs=SimpleNamespace(lambda_align=c.lambda_align, lambda_duration=c.lambda_duration,
                                     lambda_pitch=c.lambda_pitch, lambda_energy=c.lambda_energy))
     voc = partial(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers,

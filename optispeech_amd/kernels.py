@@ -421,3 +421,18 @@ def l1_sign(a, b, scale, gscale):
     gb = torch.empty_like(b)
     call("osp_l1_sign", a, b, _isbf(a), a.numel(), float(scale), gscale, gb)
     return gb
+
+
+# ------------------------------------------------------------------------------------------------ attention (A19)
+def attn_softmax_fwd(S, klen, B, H, T1, T2, scale, drop_p=0.0, seed=0, stream_id=0):
+    """in place: S (B*H, T1, T2) scores -> probabilities over the valid keys; returns (P, Pd) with Pd = dropout(P) (or P)."""
+    Pd = torch.empty_like(S) if drop_p > 0.0 else None
+    call("osp_attn_softmax_fwd", S, Pd, klen, B, H, T1, T2, float(scale), float(drop_p), int(seed), int(stream_id))
+    return S, (Pd if Pd is not None else S)
+
+
+def attn_softmax_bwd(P, dPd, scale, drop_p=0.0, seed=0, stream_id=0):
+    """in place: dPd (gradient w.r.t. the dropped probabilities) -> gradient w.r.t. the raw scores."""
+    T2 = P.shape[-1]
+    call("osp_attn_softmax_bwd", P, dPd, P.numel() // T2, T2, float(scale), float(drop_p), int(seed), int(stream_id))
+    return dPd

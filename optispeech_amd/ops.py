@@ -417,3 +417,43 @@ class GaussianUpsampleFn(torch.autograd.Function):
         dhs = torch.zeros((B, N, C), device=dy.device, dtype=torch.float32)
         K.conv_wgrad(P, dy.contiguous(), dhs, None, batch=B)
         return dhs, None, None, None, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(d_k) over the valid keys) V per head: MultiHeadedAttention.forward without the four linear layers
+    (generator/modules/_transformer/attention.py:50-125).  q, k, v: (B, T, H * d_k) f32; klen (B,) int64 valid key counts.
+    The batched GEMMs (batch = B * H) run on the conv-GEMM / wgrad kernels, the masked softmax + dropout on
+    osp_attn_softmax_fwd/bwd; the (B, H, T, T) probabilities are kept for the backward (164 MB per decoder layer at B = 32,
+    T = 800 -- a flash-style fused kernel is the round-2 item for this variant)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, klen, H, drop_p, seed, stream_id):
+        B, T, C = q.shape
+        dk = C // H
+        Z = B * H
+        heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)      # noqa: E731
+        qh, kh, vh = heads(q), heads(k), heads(v)
+        scale = 1.0 / float(dk) ** 0.5
+        S = K.conv_gemm(qh, kh, T, cin=dk, w_strides=(dk, 0, 1), batch=Z, batch_strides=(T * dk, T * dk, T * T, 0))
+        P, Pd = K.attn_softmax_fwd(S, klen, B, H, T, T, scale, drop_p, seed, stream_id)
+        O = K.conv_gemm(Pd, vh, dk, cin=T, w_strides=(1, 0, dk), batch=Z, batch_strides=(T * T, T * dk, T * dk, 0))
+        if any(ctx.needs_input_grad[:3]):
+            ctx.save_for_backward(qh, kh, vh, P, Pd)
+            ctx.cfg = (B, T, H, dk, scale, drop_p, seed, stream_id)
+        return O.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qh, kh, vh, P, Pd = ctx.saved_tensors
+        B, T, H, dk, scale, drop_p, seed, stream_id = ctx.cfg
+        Z = B * H
+        dO = dout.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)
+        dPd = K.conv_gemm(dO, vh, T, cin=dk, w_strides=(dk, 0, 1), batch=Z, batch_strides=(T * dk, T * dk, T * T, 0))
+        dV = torch.zeros((Z, T, dk), device=dout.device, dtype=torch.float32)
+        K.conv_wgrad(Pd, dO, dV, None, batch=Z)                          # dV[t2, d] = sum_t1 Pd[t1, t2] dO[t1, d]
+        dS = K.attn_softmax_bwd(P, dPd, scale, drop_p, seed, stream_id)
+        dQ = K.conv_gemm(dS, kh, dk, cin=T, w_strides=(1, 0, dk), batch=Z, batch_strides=(T * T, T * dk, T * dk, 0))
+        dKh = torch.zeros((Z, T, dk), device=dout.device, dtype=torch.float32)
+        K.conv_wgrad(dS, qh, dKh, None, batch=Z)                         # dK[t2, d] = sum_t1 dS[t1, t2] q[t1, d]
+        back = lambda t: t.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, H * dk)              # noqa: E731
+        return back(dQ), back(dKh), back(dV), None, None, None, None, None

@@ -1,0 +1,93 @@
+"""A19: Transformer backbone variant on the HIP kernels vs the reference golden / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_transformer_vs_reference_golden(golden):
+    """forward + every gradient of the 2-block reference run (ragged batch, eval mode), f32 mode, 1e-3 of the tensor scale"""
+    from optispeech_amd import precision
+    from optispeech_amd.model.transformer import Transformer
+    precision.set_precision("f32")
+    g = golden("transformer")
+    m = Transformer(dim=64, linear_units=96, num_blocks=2).to(DEV).eval()
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(g["w_" + k]) for k in g["keys"].tolist()}, strict=True)
+    assert not missing and not unexpected
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    lens = torch.from_numpy(g["lens"]).to(DEV)
+    pad = torch.arange(x.shape[1], device=DEV)[None] >= lens[:, None]
+    y = m(x, pad)
+    assert relerr(y, torch.from_numpy(g["y"])) < 1e-3
+    (y * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+    assert relerr(x.grad, torch.from_numpy(g["dx"])) < 1e-3
+    sd_grads = {}
+    for mprefix, mod in m.named_modules():                       # gradients in the reference layout
+        for name, prm in mod._parameters.items():
+            if prm is None:
+                continue
+            key, _, to_ref = mod._ref(name) if hasattr(mod, "_ref") else (name, None, None)
+            sd_grads[(mprefix + "." if mprefix else "") + key] = to_ref(prm.grad) if to_ref else prm.grad
+    for k in g["keys"].tolist():
+        want = torch.from_numpy(g["g_" + k])
+        # linear_k.bias has a mathematically zero gradient (a constant added to every key's score cancels in the softmax):
+        # both sides hold ~1e-7 round-off there, hence the absolute floor
+        err = (sd_grads[k].detach().cpu().double() - want.double()).abs().max().item()
+        assert err <= 2e-3 * want.abs().max().item() + 5e-6, (k, err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 3e-2)])
+def test_transformer_decoder_size_vs_oracle(mode, tol):
+    """BASELINE config 4 decoder shape (dim 256, 2 heads, 4 blocks, T = 800), ragged batch of 4, vs the CPU oracle"""
+    from optispeech_amd import precision
+    from optispeech_amd.model.transformer import Transformer
+    from oracle import transformer as OT
+    precision.set_precision(mode)
+    try:
+        torch.manual_seed(0)
+        m = Transformer(dim=256).to(DEV).eval()
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.dim() == 1 and p.numel() > 1:
+                    p.add_(torch.randn_like(p) * 0.05)
+        B, T = 4, 800
+        lens = torch.tensor([800, 643, 311, 17])
+        x = torch.randn(B, T, 256, generator=torch.Generator().manual_seed(1))
+        pad = torch.arange(T)[None] >= lens[:, None]
+        y = m(x.to(DEV), pad.to(DEV))
+        P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        want = OT.forward(P, x, pad, heads=2)
+        valid = (~pad)[:, :, None]
+        assert relerr(y.cpu() * valid, want * valid) < tol
+    finally:
+        precision.set_precision("f32")
+
+
+def test_transformer_generator_train_step_runs():
+    """the Transformer variant wired into the full model: one training step, finite losses, gradients reach the attention"""
+    from optispeech_amd import precision, rng
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    precision.set_precision("bf16")
+    try:
+        torch.manual_seed(2)
+        rng.manual_seed(2, 0)
+        cfg = ModelConfig(backbone="transformer")
+        m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
+        batch = synthetic_batch(2, 24, 96, cfg, seed=5, device=DEV)
+        og, od = m.optimizers()
+        m.training_step(batch, 0)
+        logs = m.fetch_logs()
+        assert all(np.isfinite(v) for v in logs.values()), logs
+        names = [k for k, _ in m.generator.named_parameters()]
+        assert any("encoder.transformer.encoders.0.self_attn.linear_q" in k for k in names)
+        gq = m.generator.encoder.transformer.encoders[0].self_attn.linear_q.weight.grad
+        assert gq is not None and torch.isfinite(gq).all() and gq.abs().sum().item() > 0
+    finally:
+        precision.set_precision("f32")

@@ -179,3 +179,19 @@ def test_mel_filterbank_shape_and_partition():
     assert fb.shape == (513, 100) and bool((fb >= 0).all())
     peak = fb.argmax(0)
     assert bool((peak[1:] >= peak[:-1]).all())
+
+
+def test_transformer_oracle_vs_reference_golden(golden):
+    """A19: the restated Transformer backbone vs the reference module's output and gradients (ragged batch, 2 blocks)."""
+    from oracle import transformer as OT
+    g = golden("transformer")
+    P = {k: torch.from_numpy(g["w_" + k]).requires_grad_(True) for k in g["keys"].tolist()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    lens = torch.from_numpy(g["lens"])
+    pad = torch.arange(x.shape[1])[None] >= lens[:, None]
+    y = OT.forward(P, x, pad, heads=2)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-5)
+    (y * torch.from_numpy(g["G"])).sum().backward()
+    assert torch.allclose(x.grad, torch.from_numpy(g["dx"]), rtol=1e-4, atol=1e-5)
+    for k in g["keys"].tolist():
+        assert torch.allclose(P[k].grad, torch.from_numpy(g["g_" + k]), rtol=1e-4, atol=2e-5), k
