@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the bounded CPU-baseline sample")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
+    ap.add_argument("--backbone", choices=["convnext", "transformer"], default="convnext",
+                    help="transformer = BASELINE configs[4] encoder/decoder (secondary datapoint; the headline is convnext)")
     ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("OSP_PRECISION", "bf16"),
                     help="bf16 = BASELINE config[1] (bf16 MFMA operands, f32 accumulate, f32 master weights); "
                          "f32 = exact-f32 parity mode")
@@ -147,7 +149,7 @@ def main():
 
     torch.manual_seed(1234)                                   # configs/train.yaml:53; same init on every rank
     rng.manual_seed(1234, rank)
-    cfg = ModelConfig()
+    cfg = ModelConfig(backbone=a.backbone)
     model = make_optispeech(cfg, batch_size=B, pretraining_steps=0).to(dev).train()
     batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
     model.optimizers()
@@ -263,7 +265,7 @@ def main():
                "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.precision, "data": "synthetic",
-               "config": {"workload": "configs[1]: ConvNeXt backbone, synthetic LJSpeech-shaped batch=32 per GPU "
+               "config": {"workload": ("configs[4]: Transformer backbone" if a.backbone == "transformer" else "configs[1]: ConvNeXt backbone") + ", synthetic LJSpeech-shaped batch=32 per GPU "
                                       "(T_text=128, T_mel=800, 22.05 kHz), full GAN training step "
                                       "(G phase + D phase + 2x AdamW), train mode",
                           "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}",
