@@ -402,6 +402,114 @@ class ConvStackFn(torch.autograd.Function):
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)
 
 
+# =================================================================================================== f32 parity mode
+# The exact-parity mode keeps f32 activations and weights.  The MFMA conv kernels take bf16 operands, so every f32 operand
+# is split into hi + lo bf16 halves (x = hi + lo with |lo| <= 2^-9 |x|) and a product becomes hi*hi + lo*hi + hi*lo
+# (the dropped lo*lo term is 2^-18 relative): three launches of the same kernels with f32 accumulation give ~2e-5 relative
+# accuracy -- two orders inside the 1e-3 parity tolerance -- without a separate f32 conv2d code path (and without MIOpen).
+def _split_bf16(x32):
+    hi = K.cast_bf16(x32)
+    return hi, K.cast_bf16(x32 - hi.float())
+
+
+def precise_conv2d_fwd(x32, w32, KH, KW, sh, sw, ph, pw):
+    xh, xl = _split_bf16(x32.contiguous())
+    wh, wl = _split_bf16(w32.contiguous())
+    y = conv2d_fwd(xh, wh, None, KH, KW, sh, sw, ph, pw, None, False)
+    y += conv2d_fwd(xl, wh, None, KH, KW, sh, sw, ph, pw, None, False)
+    y += conv2d_fwd(xh, wl, None, KH, KW, sh, sw, ph, pw, None, False)
+    return y
+
+
+def precise_conv2d_dgrad(dy32, wt32, H, W, KH, KW, sh, sw, ph, pw):
+    dh, dl = _split_bf16(dy32.contiguous())
+    th, tl = _split_bf16(wt32.contiguous())
+    dx = conv2d_dgrad(dh, th, H, W, KH, KW, sh, sw, ph, pw)
+    dx += conv2d_dgrad(dl, th, H, W, KH, KW, sh, sw, ph, pw)
+    dx += conv2d_dgrad(dh, tl, H, W, KH, KW, sh, sw, ph, pw)
+    return dx
+
+
+def precise_conv2d_wgrad(dy32, x32, KH, KW, sh, sw, ph, pw):
+    dh, dl = _split_bf16(dy32.contiguous())
+    xh, xl = _split_bf16(x32.contiguous())
+    dw, db = conv2d_wgrad(dh, xh, KH, KW, sh, sw, ph, pw)
+    dw2, db2 = conv2d_wgrad(dl, xh, KH, KW, sh, sw, ph, pw)
+    dw3, _ = conv2d_wgrad(dh, xl, KH, KW, sh, sw, ph, pw)
+    return dw + dw2 + dw3, db + db2
+
+
+class ConvStackPreciseFn(torch.autograd.Function):
+    """ConvStackFn for the f32 parity mode: same stack, f32 activations, split-bf16 products (see above); the Cin = 1 first
+    layer runs on the exact-f32 VALU kernels of csrc/smallcin.hip.  Outputs y1..y5 (f32, LeakyReLU applied) and the score map."""
+
+    @staticmethod
+    def forward(ctx, x, spec, slope, *params):
+        ctx.set_materialize_grads(False)
+        vs, gs, bs = params[0::3], params[1::3], params[2::3]
+        need_w = [bool(ctx.needs_input_grad[3 + 3 * i]) for i in range(6)]
+        need_x = bool(ctx.needs_input_grad[0])
+        packs, acts, h = [], [], x.contiguous()
+        for i in range(6):
+            KH, KW, sh, sw, ph, pw = spec[i]
+            cout, cin = vs[i].shape[0], vs[i].shape[1]
+            _, wn32, _, inv = wnorm_packed(vs[i], gs[i], True, True)
+            packs.append((wn32, inv))
+            if cin == 1:
+                U, H, W = h.shape[0], h.shape[1], h.shape[2]
+                Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+                h = K.smallcin_fwd(h, wn32.view(cout, -1), bs[i].detach(), U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo, cout=cout, KH=KH,
+                                   KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=slope if i < 5 else None,
+                                   out_bf16=False).view(U, Ho, Wo, cout)
+            else:
+                h = precise_conv2d_fwd(h, wn32, KH, KW, sh, sw, ph, pw) + bs[i].detach()
+                if i < 5:
+                    h = torch.where(h > 0, h, h * slope)
+            acts.append(h)
+        if need_x or any(need_w):
+            ctx.save_for_backward(x, *acts[:5], *[t for pk in packs for t in pk])
+            ctx.params = params
+            ctx.cfg = (spec, slope, need_x, need_w)
+        return tuple(acts)
+
+    @staticmethod
+    def backward(ctx, d1, d2, d3, d4, d5, ds):
+        from .ops import gsink
+        spec, slope, need_x, need_w = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        x, acts, rest = saved[0], saved[1:6], saved[6:]
+        packs = [(rest[2 * i], rest[2 * i + 1]) for i in range(6)]
+        vs, gs, bs = ctx.params[0::3], ctx.params[1::3], ctx.params[2::3]
+        extras = (d1, d2, d3, d4, d5)
+        if ds is None:
+            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
+        g = ds.contiguous().float()
+        for i in range(5, -1, -1):
+            inp = acts[i - 1] if i > 0 else x
+            KH, KW, sh, sw, ph, pw = spec[i]
+            wn32, inv = packs[i]
+            cout, cin = vs[i].shape[0], vs[i].shape[1]
+            if need_w[i]:
+                if cin == 1:
+                    dw = torch.zeros((cout, KH, KW, cin), device=g.device, dtype=torch.float32)
+                    K.smallcin_wgrad(inp, g, dw, gsink(bs[i]), U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
+                                     Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+                else:
+                    dw, db = precise_conv2d_wgrad(g, inp, KH, KW, sh, sw, ph, pw)
+                    gsink(bs[i]).add_(db)
+                K.wnorm_bwd(dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i]))
+            if (i > 0 and (need_x or any(need_w[:i]))) or (i == 0 and need_x):
+                g = precise_conv2d_dgrad(g, wn32.permute(3, 1, 2, 0).contiguous(), inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw)
+                if i > 0:                                        # LeakyReLU backward of the layer below (+ its fmap gradient)
+                    if extras[i - 1] is not None:
+                        g = g + extras[i - 1]
+                    g = torch.where(inp > 0, g, g * slope)
+            else:
+                g = None
+                break
+        return (g if need_x else None, None, None) + (None,) * len(ctx.params)
+
+
 MPD_SPEC = ((1, 5, 1, 3, 0, 2),) * 4 + ((1, 5, 1, 1, 0, 2), (1, 3, 1, 1, 0, 1))
 MRD_SPEC = MRDStackFn.SPEC
 

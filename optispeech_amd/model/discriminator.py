@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import precision, spectral
-from ..disc_ops import MPD_SPEC, MRD_SPEC, ConvStackFn, L1MeanFn
+from ..disc_ops import MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, L1MeanFn
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -88,6 +88,15 @@ class DiscriminatorP(nn.Module):
                 return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
             return s.view(b, -1), [y2, y3, y4, y5, s]
+        if _F32_HIP and x.is_cuda:
+            # f32 parity mode on the same kernels (split-bf16 products, disc_ops.ConvStackPreciseFn); feature maps come out
+            # channels-last, which the (layout-agnostic) mean losses do not care about
+            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)
+            args = []
+            for conv in list(self.convs) + [self.conv_post]:
+                args += [conv.weight_v, conv.weight_g, conv.bias]
+            y1, y2, y3, y4, y5, s = ConvStackPreciseFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
+            return s.view(b, -1), [y2, y3, y4, y5, s]
         x = x.view(b, c, t // self.period, self.period)
         fmap = []
         for i, conv in enumerate(self.convs):
@@ -129,6 +138,14 @@ class DiscriminatorR(nn.Module):
                 return (r[5].reshape(nograd_head, -1), list(r)), (y[5].reshape(y[5].shape[0], -1), list(y))
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
             return s.reshape(s.shape[0], -1), [y1, y2, y3, y4, y5, s]
+        if _F32_HIP and x.is_cuda:
+            n_fft, hop, win = self.resolution
+            spec = spectral.stft_magnitude(x, n_fft, hop, None, None)
+            args = []
+            for conv in list(self.convs) + [self.conv_post]:
+                args += [conv.weight_v, conv.weight_g, conv.bias]
+            ys = ConvStackPreciseFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
+            return ys[5].reshape(ys[5].shape[0], -1), list(ys)
         fmap = []
         x = self.spectrogram(x).unsqueeze(1)
         for conv in self.convs:
@@ -214,6 +231,8 @@ class _Multi(nn.Module):
         return rs, gs, frs, fgs
 
 
+#: f32 parity mode: discriminators on the hand-written kernels (split-bf16 products); "0" = torch conv2d (MIOpen)
+_F32_HIP = os.environ.get("OSP_F32_DISC_HIP", "1") != "0"
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
 _STREAMS = {}
 _PENDING = []

