@@ -89,5 +89,14 @@ def test_transformer_generator_train_step_runs():
         assert any("encoder.transformer.encoders.0.self_attn.linear_q" in k for k in names)
         gq = m.generator.encoder.transformer.encoders[0].self_attn.linear_q.weight.grad
         assert gq is not None and torch.isfinite(gq).all() and gq.abs().sum().item() > 0
+        # inference path of the same variant
+        from optispeech_amd.values import InferenceInputs
+        x = torch.randint(1, 150, (2, 16))
+        xl = torch.tensor([16, 9])
+        out = m.eval().synthesise(InferenceInputs(clean_text="", x=x * (torch.arange(16)[None] < xl[:, None]), x_lengths=xl,
+                                                  d_factor=1.0, p_factor=1.0, e_factor=1.0),
+                                  durations_override=torch.full((2, 16), 3))
+        wav = torch.as_tensor(out.wav)
+        assert wav.shape[0] == 2 and torch.isfinite(wav).all()
     finally:
         precision.set_precision("f32")
