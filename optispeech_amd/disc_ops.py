@@ -306,9 +306,10 @@ class ConvStackFn(torch.autograd.Function):
         # ``slope`` may be (slope, u0): the first u0 sequences are a no-grad branch (the real waves in the generator
         # phase) that shares the forward launches with the rest; the outputs then come as 6 no-grad tensors followed by
         # 6 differentiable ones (views of the same buffers) and the backward runs over the sequences from u0 on only.
-        u0 = 0
+        u0, holder = 0, None
         if isinstance(slope, tuple):
-            slope, u0 = slope
+            holder = slope[2] if len(slope) > 2 else None
+            slope, u0 = slope[0], slope[1]
         ctx.set_materialize_grads(False)
         vs, gs, bs = params[0::3], params[1::3], params[2::3]
         need_w = [bool(ctx.needs_input_grad[3 + 3 * i]) for i in range(6)]
@@ -339,6 +340,11 @@ class ConvStackFn(torch.autograd.Function):
             ctx.params = params
             ctx.cfg = (spec, slope, need_x, need_w)
             ctx.u0, ctx.U = u0, x.shape[0]
+        if holder is not None:
+            # everything a later backward over the WHOLE batch needs (ConvStackReplayFn): the discriminator phase of the
+            # same step sees the same waves and the same weights, so it replays this forward instead of repeating it
+            from . import values
+            holder["rec"] = (values.param_epoch(), x, list(acts), [(pk[0], pk[2], pk[3]) for pk in packs], spec, slope)
         if u0:
             head = tuple(a[:u0] for a in acts)
             ctx.mark_non_differentiable(*head)
@@ -347,7 +353,6 @@ class ConvStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        from .ops import gsink
         d1, d2, d3, d4, d5, ds = douts[-6:]                      # (with a no-grad head the first 6 gradients are None)
         spec, slope, need_x, need_w = ctx.cfg
         saved = list(ctx.saved_tensors)
@@ -359,47 +364,74 @@ class ConvStackFn(torch.autograd.Function):
             for flag in has:
                 item.append(rest.pop(0) if flag else None)
             packs.append(item)                                  # (wn, wt, inv)
-        vs, gs, bs = ctx.params[0::3], ctx.params[1::3], ctx.params[2::3]
-        extras = [d.contiguous() if d is not None else None for d in (d1, d2, d3, d4, d5)]
-        if ds is None:
-            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
-        g = ds.contiguous()
-        for i in range(5, -1, -1):
-            inp = acts[i - 1] if i > 0 else x
-            KH, KW, sh, sw, ph, pw = spec[i]
-            wn, wt, inv = packs[i]
-            cout, cin = vs[i].shape[0], vs[i].shape[1]
-            if need_w[i]:
-                dw = torch.zeros((cout, KH, KW, cin), device=g.device, dtype=torch.float32)
-                db = gsink(bs[i])
-                if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
-                    K.smallcin_wgrad(inp, g, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
-                                     Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
-                else:
-                    U, Ho, Wo = g.shape[0], g.shape[1], g.shape[2]
-                    H, W = inp.shape[1], inp.shape[2]
-                    K.conv2d_wgrad_bf16(g.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
-                                        Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
-                                        pad_w=pw, step_h=sh, step_w=sw)
-                K.wnorm_bwd(dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i]))
-            if i > 0 and (need_x or any(need_w[:i])):
-                g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp, extra=extras[i - 1],
-                                 slope=slope, out_bf16=True)
-            elif i == 0 and need_x:
-                g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, out_bf16=False)
-            else:
-                g = None
-                break
-        if any(need_w) and g_stream_is_side():
-            # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
-            # engine does not know that the stream backward() was called from must wait for this node's stream: say so.
-            side = torch.cuda.current_stream()
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
+        g = _stack_backward(x, acts, packs, ctx.params, spec, slope, need_x, need_w, (d1, d2, d3, d4, d5), ds)
         if need_x and ctx.u0:                                    # gradient of the whole input: zeros for the no-grad head
             full = torch.zeros((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
             full[ctx.u0:] = g
             g = full
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)
+
+
+def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds):
+    """Backward of a conv stack over (x, activations y1..y5): weight gradients into the arena (gsink), returns d x or None.
+    ``dfm`` = gradients w.r.t. the feature maps y1..y5 (or None), ``ds`` = gradient w.r.t. the score map."""
+    from .ops import gsink
+    vs, gs, bs = params[0::3], params[1::3], params[2::3]
+    extras = [d.contiguous() if d is not None else None for d in dfm]
+    if ds is None:
+        ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
+    g = ds.contiguous()
+    for i in range(5, -1, -1):
+        inp = acts[i - 1] if i > 0 else x
+        KH, KW, sh, sw, ph, pw = spec[i]
+        wn, wt, inv = packs[i]
+        cout, cin = vs[i].shape[0], vs[i].shape[1]
+        if need_w[i]:
+            dw = torch.zeros((cout, KH, KW, cin), device=g.device, dtype=torch.float32)
+            db = gsink(bs[i])
+            if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
+                K.smallcin_wgrad(inp, g, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
+                                 Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+            else:
+                U, Ho, Wo = g.shape[0], g.shape[1], g.shape[2]
+                H, W = inp.shape[1], inp.shape[2]
+                K.conv2d_wgrad_bf16(g.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
+                                    Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
+                                    pad_w=pw, step_h=sh, step_w=sw)
+            K.wnorm_bwd(dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i]))
+        if i > 0 and (need_x or any(need_w[:i])):
+            g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp, extra=extras[i - 1],
+                             slope=slope, out_bf16=True)
+        elif i == 0 and need_x:
+            g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, out_bf16=False)
+        else:
+            g = None
+            break
+    if any(need_w) and g_stream_is_side():
+        # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
+        # engine does not know that the stream backward() was called from must wait for this node's stream: say so.
+        side = torch.cuda.current_stream()
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
+    return g
+
+
+class ConvStackReplayFn(torch.autograd.Function):
+    """Discriminator-phase view of a stack whose forward already ran in the generator phase of the same step (same waves,
+    same weights -> the same activations): forward returns the recorded score map, backward is the stack's full backward
+    (weight gradients for every layer) over the whole 2B batch.  ``rec`` comes from ConvStackFn.forward(holder=...)."""
+
+    @staticmethod
+    def forward(ctx, rec, *params):
+        _, x, acts, packs, spec, slope = rec
+        ctx.rec, ctx.params = rec, params
+        ctx.need_w = [bool(ctx.needs_input_grad[1 + 3 * i]) for i in range(6)]
+        return acts[5].detach().clone()
+
+    @staticmethod
+    def backward(ctx, ds):
+        _, x, acts, packs, spec, slope = ctx.rec
+        _stack_backward(x, acts[:5], packs, ctx.params, spec, slope, False, ctx.need_w, (None,) * 5, ds)
+        return (None,) + (None,) * len(ctx.params)
 
 
 # =================================================================================================== f32 parity mode

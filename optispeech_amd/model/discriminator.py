@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import precision, spectral
-from ..disc_ops import MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, L1MeanFn
+from ..disc_ops import MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, L1MeanFn
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -83,7 +83,8 @@ class DiscriminatorP(nn.Module):
             for conv in list(self.convs) + [self.conv_post]:
                 args += [conv.weight_v, conv.weight_g, conv.bias]
             if nograd_head:
-                o = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, (self.lrelu_slope, nograd_head * self.period), *args)
+                self._holder = {}
+                o = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, (self.lrelu_slope, nograd_head * self.period, self._holder), *args)
                 (_, r2, r3, r4, r5, rs), (_, y2, y3, y4, y5, s) = o[:6], o[6:]
                 return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
@@ -133,7 +134,8 @@ class DiscriminatorR(nn.Module):
                 # reference weight (Cout, Cin, k_freq, k_time) is packed to native (Cout, KH = k_time, KW = k_freq, Cin)
                 args += [conv.weight_v, conv.weight_g, conv.bias]
             if nograd_head:
-                o = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, (self.lrelu_slope, nograd_head), *args)
+                self._holder = {}
+                o = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, (self.lrelu_slope, nograd_head, self._holder), *args)
                 r, y = o[:6], o[6:]
                 return (r[5].reshape(nograd_head, -1), list(r)), (y[5].reshape(y[5].shape[0], -1), list(y))
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
@@ -156,6 +158,21 @@ class DiscriminatorR(nn.Module):
         return torch.flatten(x, 1, -1), fmap
 
 
+def _replay_scores(d, B):
+    """(real scores, generated scores) of sub-discriminator ``d`` from the forward its generator-phase call recorded, as a
+    graph node whose backward yields the weight gradients (disc_ops.ConvStackReplayFn); None if nothing valid is recorded."""
+    from .. import values
+    rec = getattr(d, "_holder", {}).pop("rec", None)
+    if rec is None or rec[0] != values.param_epoch():
+        return None
+    args = []
+    for conv in list(d.convs) + [d.conv_post]:
+        args += [conv.weight_v, conv.weight_g, conv.bias]
+    s = ConvStackReplayFn.apply(rec, *args)
+    o = s.reshape(2 * B, -1)
+    return o[:B], o[B:]
+
+
 class _Multi(nn.Module):
     def forward_real(self, y):
         """Real-wave branch only -> (scores, feature maps) per sub-discriminator, under the caller's grad mode.  Inside
@@ -168,7 +185,7 @@ class _Multi(nn.Module):
             rs.append(r); frs.append(fr)
         return rs, frs
 
-    def forward(self, y, y_hat, real=None, defer_join=False, pre=None):
+    def forward(self, y, y_hat, real=None, defer_join=False, pre=None, replay=False):
         """Real and generated waves go through separately: in the generator phase the real branch needs no
         backward at all (it only feeds the feature-matching targets), so it runs under no_grad -- unless ``real``
         (a forward_real result) is supplied, in which case only the generated branch runs."""
@@ -183,7 +200,7 @@ class _Multi(nn.Module):
         B = y.shape[0]
         if precision.is_bf16() and _DISC_STREAMS and y.is_cuda:
             return self._forward_concurrent(pre[0] if pre is not None else torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join,
-                                            pre[1] if pre is not None else None)
+                                            pre[1] if pre is not None else None, replay)
         for d in self.discriminators:
             if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
                 o, fm = d(torch.cat([y, y_hat], 0))
@@ -201,7 +218,7 @@ class _Multi(nn.Module):
         return rs, gs, frs, fgs
 
 
-    def _forward_concurrent(self, x, B, with_param_grads, defer_join=False, ready=None):
+    def _forward_concurrent(self, x, B, with_param_grads, defer_join=False, ready=None, replay=False):
         """The sub-discriminators are independent (own weights, own spectrogram / period folding): each one runs on its own
         HIP stream, so the many small launches of one (first / last layers, weight-norm packing, the narrow MRD layers)
         overlap the large GEMMs of another.  autograd replays every node's backward on the stream its forward ran on and
@@ -214,7 +231,10 @@ class _Multi(nn.Module):
         for d, st in zip(self.discriminators, streams):
             st.wait_event(ready)
             with torch.cuda.stream(st):
-                if with_param_grads:                         # discriminator phase: one batch of 2B waves per launch
+                rep = _replay_scores(d, B) if (with_param_grads and replay) else None
+                if rep is not None:                          # discriminator phase on the generator phase's forward
+                    out = (rep[0], rep[1], [], [])
+                elif with_param_grads:                       # discriminator phase: one batch of 2B waves per launch
                     o, fm = d(x)
                     out = (o[:B], o[B:], [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm])
                 else:                                        # generator phase: no-grad head = the real waves
@@ -334,10 +354,12 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         x = torch.cat([wav, wav_hat], 0)
         return x, torch.cuda.current_stream().record_event()
 
-    def forward_disc(self, wav, wav_hat, real=None, pre=None):
+    def forward_disc(self, wav, wav_hat, real=None, pre=None, replay=False):
+        """replay=True: reuse the forward the generator phase of the SAME step ran on these waves (same weights -> same
+        activations) and only run the backward with weight gradients; falls back to a fresh forward when nothing valid is recorded."""
         # both families are launched before either is joined: the eight stacks overlap across the family boundary too
-        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True, pre=pre)
-        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True, pre=pre)
+        r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True, pre=pre, replay=replay)
+        r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True, pre=pre, replay=replay)
         join_streams()
         loss_mp, loss_mrd = _hinge_d(r_mp, g_mp), _hinge_d(r_mr, g_mr)
         loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd

@@ -82,6 +82,10 @@ class OptiSpeech(nn.Module):
         #: issue the discriminator phase from its own stream so that consecutive steps overlap (see training_step); off by
         #: default because code that reads discriminator parameters from another stream must then call join() first
         self.pipeline_steps = os.environ.get("OSP_PIPELINE_STEPS", "0") == "1"
+        #: opt-in: the discriminator phase replays the backward on the forward the generator phase already ran (same waves,
+        #: same weights inside one step -> identical activations) instead of evaluating the discriminators a second time.
+        #: Off by default: the benchmarked step does every forward the reference does.
+        self.replay_disc_forward = os.environ.get("OSP_DISC_REPLAY", "0") == "1"
         self._dstream = None
         self._reducers = None
         self.last_logs = {}
@@ -171,7 +175,7 @@ class OptiSpeech(nn.Module):
         dctx = self._disc_phase_stream() if (train_discriminator and self.pipeline_steps) else contextlib.nullcontext()
         if train_discriminator:
             with dctx:
-                loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs, pre=pre)
+                loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs, pre=pre, replay=self.replay_disc_forward)
                 if apply:
                     opt_d.zero_grad()
                 (loss_d / scale).backward()
@@ -236,11 +240,11 @@ class OptiSpeech(nn.Module):
         self._last_gen_outputs = gen_outputs
         return loss, (wav.detach(), wav_hat)
 
-    def training_step_d(self, batch, wav_outputs, logs, pre=None):
+    def training_step_d(self, batch, wav_outputs, logs, pre=None, replay=False):
         """base_lightning_module.py:163-186; D sees wav_hat.detach()."""
         wav, wav_hat = wav_outputs
         real, self._real_pass = getattr(self, "_real_pass", None), None
-        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real, pre=pre)
+        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real, pre=pre, replay=replay)
         logs["total_loss/discriminator"] = loss.detach()
         logs.update({f"discriminator/{k}": v for k, v in log_dict.items()})
         return loss

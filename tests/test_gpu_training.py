@@ -257,3 +257,35 @@ def test_f32_mode_split_bf16_stacks_match_torch_conv2d(which):
     for k in a[3]:
         if a[3][k].abs().max().item() > 1e-7:
             assert rel2(b[3][k], a[3][k]) < 5e-3, (k, rel2(b[3][k], a[3][k]))
+
+
+def test_discriminator_replay_matches_second_forward():
+    """``replay_disc_forward``: the discriminator phase on the generator phase's recorded forward gives the same loss and the
+    same discriminator gradients as evaluating the stacks again."""
+    from optispeech_amd import precision, rng
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    precision.set_precision("bf16")
+    try:
+        cfg = ModelConfig()
+        batch = synthetic_batch(2, 24, 96, cfg, seed=5, device="cuda")
+        r01 = torch.rand(2, generator=torch.Generator().manual_seed(1))
+        out = []
+        for rep in (False, True):
+            torch.manual_seed(3)
+            rng.manual_seed(3, 0)
+            rng._state["next_stream"] = 1
+            m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to("cuda").train()
+            m.replay_disc_forward = rep
+            m.generator.segment_rand01 = r01
+            _, od = m.optimizers()
+            od.step = lambda *a, **k: None                      # keep the gradient arena as the step left it
+            m.training_step(batch, 0)
+            logs = m.fetch_logs()
+            torch.cuda.synchronize()
+            out.append((logs["total_loss/discriminator"], od.arena.grad.clone()))
+        (la, ga), (lb, gb) = out
+        assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+        assert ga.abs().sum().item() > 0
+        assert ((ga - gb).norm() / ga.norm()).item() < 1e-3
+    finally:
+        precision.set_precision("f32")
