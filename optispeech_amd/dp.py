@@ -20,9 +20,11 @@ def env_world():
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun contract). Returns (world, rank, local)."""
     world, rank, local = env_world()
+    if os.environ.get("OSP_DP_SINGLE_DEVICE") == "1":        # test aid: all ranks on GPU 0 (gloo moves the buckets via the host)
+        local = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("OSP_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
