@@ -1,0 +1,536 @@
+// Weight gradients of the bf16 conv-GEMM family + weight packing / casting (split from gemm_bf16.hip to halve the build time
+// of the largest translation unit).  See gemm_bf16_common.h for the shared tile helpers.
+#include "gemm_bf16_common.h"
+
+// conv padding rows of the LDS-DMA staging read a zero page (one per translation unit)
+__device__ __attribute__((aligned(256))) unsigned osp_zero_page_w[64];
+#define osp_zero_page osp_zero_page_w
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW[n, j, c] += oscale[n] * sum_{u,t} arow * dY[u, t, n] * X[u, t*x_step + j - pad, c];  db[n] likewise.
+// Both operands are reduction-major -> transposing loader for both.  Split over the frame dimension, f32 atomics.
+struct WgradB {
+    const void* dY; int y_bf16; int64_t ldy; const void* X; int x_bf16; int64_t ldx;
+    int M, Trows, Tin, N, Cin, taps, pad, x_step;
+    int Wrows, Hin, KW, x_step_h, pad_h;              // 2-D extension (1-D: Wrows = Trows, Hin = 1, KW = taps)
+    FastDiv fd_trows, fd_wrows;
+    const float *arow, *oscale; float* dW; int64_t ldw; float* db; int chunk, splits;
+    int64_t sYb, sXb, sWb, sDb;
+};
+
+__device__ __forceinline__ float4 ld4_any(const void* p, int is_bf16, int64_t off, int lim, bool vec) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lim >= 4 && vec) {
+        if (is_bf16) {
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off);
+            x = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                            __uint_as_float(h.y & 0xffff0000u));
+        } else x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + off);
+    } else {
+        if (lim > 0) x.x = ld_elem(p, is_bf16, off);
+        if (lim > 1) x.y = ld_elem(p, is_bf16, off + 1);
+        if (lim > 2) x.z = ld_elem(p, is_bf16, off + 2);
+        if (lim > 3) x.w = ld_elem(p, is_bf16, off + 3);
+    }
+    return x;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (TBM + TBN) * LDK];
+    unsigned short* As = smem;
+    unsigned short* Bs = smem + 2 * TBM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int ctiles = (p.Cin + TBN - 1) / TBN;
+    const int j = blockIdx.y / ctiles, c0 = (blockIdx.y - j * ctiles) * TBN;
+    const int n0 = blockIdx.x * TBM;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z - bz * p.splits;
+    const char* dY = reinterpret_cast<const char*>(p.dY) + (int64_t)bz * p.sYb * (p.y_bf16 ? 2 : 4);
+    const char* X = reinterpret_cast<const char*>(p.X) + (int64_t)bz * p.sXb * (p.x_bf16 ? 2 : 4);
+    const float* arow = p.arow ? p.arow + (int64_t)bz * p.M : nullptr;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const bool y_vec = (p.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dY) & 15) == 0);
+    const bool x_vec = (p.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const int kg = tid >> 5, c4 = tid & 31;                   // k-group (8 frames) x 4 columns
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bias = (p.db != nullptr) && (blockIdx.y == 0);
+    const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int mk) {
+        float4 ya[8], xb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mk + kg * 8 + q;
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f), x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) {
+                const int n = n0 + 4 * c4;
+                if (n < p.N) {
+                    y = ld4_any(dY, p.y_bf16, (int64_t)m * p.ldy + n, p.N - n, y_vec);
+                    if (arow) { const float s = arow[m]; y.x *= s; y.y *= s; y.z *= s; y.w *= s; }
+                }
+                const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+                const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+                const int c = c0 + 4 * c4;
+                if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin && c < p.Cin)
+                    x = ld4_any(X, p.x_bf16, (((int64_t)u * p.Hin + hh) * p.Tin + tt) * p.ldx + c, p.Cin - c, x_vec);
+            }
+            ya[q] = y; xb[q] = x;
+            if (do_bias) { bsum.x += y.x; bsum.y += y.y; bsum.z += y.z; bsum.w += y.w; }
+        }
+        ra[0] = make_uint4(pk2(ya[0].x, ya[1].x), pk2(ya[2].x, ya[3].x), pk2(ya[4].x, ya[5].x), pk2(ya[6].x, ya[7].x));
+        ra[1] = make_uint4(pk2(ya[0].y, ya[1].y), pk2(ya[2].y, ya[3].y), pk2(ya[4].y, ya[5].y), pk2(ya[6].y, ya[7].y));
+        ra[2] = make_uint4(pk2(ya[0].z, ya[1].z), pk2(ya[2].z, ya[3].z), pk2(ya[4].z, ya[5].z), pk2(ya[6].z, ya[7].z));
+        ra[3] = make_uint4(pk2(ya[0].w, ya[1].w), pk2(ya[2].w, ya[3].w), pk2(ya[4].w, ya[5].w), pk2(ya[6].w, ya[7].w));
+        rb[0] = make_uint4(pk2(xb[0].x, xb[1].x), pk2(xb[2].x, xb[3].x), pk2(xb[4].x, xb[5].x), pk2(xb[6].x, xb[7].x));
+        rb[1] = make_uint4(pk2(xb[0].y, xb[1].y), pk2(xb[2].y, xb[3].y), pk2(xb[4].y, xb[5].y), pk2(xb[6].y, xb[7].y));
+        rb[2] = make_uint4(pk2(xb[0].z, xb[1].z), pk2(xb[2].z, xb[3].z), pk2(xb[4].z, xb[5].z), pk2(xb[6].z, xb[7].z));
+        rb[3] = make_uint4(pk2(xb[0].w, xb[1].w), pk2(xb[2].w, xb[3].w), pk2(xb[4].w, xb[5].w), pk2(xb[6].w, xb[7].w));
+    };
+    auto sstore = [&](int buf) {
+        unsigned short* as = As + buf * TBM * LDK;
+        unsigned short* bs = Bs + buf * TBN * LDK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<uint4*>(as + (4 * c4 + q) * LDK + kg * 8) = ra[q];
+            *reinterpret_cast<uint4*>(bs + (4 * c4 + q) * LDK + kg * 8) = rb[q];
+        }
+    };
+    // ---- fast path: both operands bf16 with 16-byte rows.  Threads 0-127 stage the dY tile, 128-255 the X tile:
+    // 8 frames x 8 channels per thread (eight 16-byte loads), 8x8 bf16 transpose in registers, eight ds_write_b128.
+    constexpr bool fast = FAST;
+    // lane -> (k-group, column-group): k-group fastest, so the 8 lanes of a ds_write_b128 group fill 128 contiguous
+    // bytes of ONE LDS row (column-group fastest put all 8 lanes on the same banks: 8-way conflict)
+    const int half = tid >> 7, ht = tid & 127, fkg = ht & 7, c8 = ht >> 3;
+    uint4 r8[8];
+    float bs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto gload_fast = [&](int mk) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = mk + fkg * 8 + q;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < mend) {
+                if (half == 0) {
+                    const int n = n0 + 8 * c8;
+                    if (n < p.N) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(dY) + (int64_t)m * p.ldy + n);
+                } else {
+                    const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+                    const int c = c0 + 8 * c8;
+                    const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+                    if (tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin && c < p.Cin)
+                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(X) + (((int64_t)u * p.Hin + hh) * p.Tin + tt) * p.ldx + c);
+                }
+            }
+            r8[q] = v;
+        }
+        if (do_bias && half == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bs8[0] += __uint_as_float(r8[q].x << 16); bs8[1] += __uint_as_float(r8[q].x & 0xffff0000u);
+                bs8[2] += __uint_as_float(r8[q].y << 16); bs8[3] += __uint_as_float(r8[q].y & 0xffff0000u);
+                bs8[4] += __uint_as_float(r8[q].z << 16); bs8[5] += __uint_as_float(r8[q].z & 0xffff0000u);
+                bs8[6] += __uint_as_float(r8[q].w << 16); bs8[7] += __uint_as_float(r8[q].w & 0xffff0000u);
+            }
+        }
+    };
+    auto sstore_fast = [&](int buf) {
+        unsigned short* dst = (half == 0 ? As + buf * TBM * LDK : Bs + buf * TBN * LDK) + (8 * c8) * LDK + fkg * 8;
+        const unsigned* w = reinterpret_cast<const unsigned*>(r8);      // w[q*4 + d]: frame q, channel pair d
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint4 lo, hi;                                                // channels 2d and 2d+1, frames 0..7
+            lo.x = (w[0 * 4 + d] & 0xffffu) | (w[1 * 4 + d] << 16);  hi.x = (w[0 * 4 + d] >> 16) | (w[1 * 4 + d] & 0xffff0000u);
+            lo.y = (w[2 * 4 + d] & 0xffffu) | (w[3 * 4 + d] << 16);  hi.y = (w[2 * 4 + d] >> 16) | (w[3 * 4 + d] & 0xffff0000u);
+            lo.z = (w[4 * 4 + d] & 0xffffu) | (w[5 * 4 + d] << 16);  hi.z = (w[4 * 4 + d] >> 16) | (w[5 * 4 + d] & 0xffff0000u);
+            lo.w = (w[6 * 4 + d] & 0xffffu) | (w[7 * 4 + d] << 16);  hi.w = (w[6 * 4 + d] >> 16) | (w[7 * 4 + d] & 0xffff0000u);
+            *reinterpret_cast<uint4*>(dst + (2 * d) * LDK) = lo;
+            *reinterpret_cast<uint4*>(dst + (2 * d + 1) * LDK) = hi;
+        }
+    };
+    const int niter = (mend - mbeg + TBK - 1) / TBK;
+    if (niter > 0) {
+        if constexpr (fast) { gload_fast(mbeg); sstore_fast(0); } else { gload(mbeg); sstore(0); }
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < niter) { if constexpr (fast) gload_fast(mbeg + (it + 1) * TBK); else gload(mbeg + (it + 1) * TBK); }
+            mma_tile_bf16<2, 2>(As + buf * TBM * LDK, Bs + buf * TBN * LDK, wm0, wn0, lane, acc);
+            if (it + 1 < niter) { if constexpr (fast) sstore_fast(buf ^ 1); else sstore(buf ^ 1); }
+            __syncthreads();
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int c = c0 + wn0 + 32 * jj + l31;
+            if (c >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n >= p.N) continue;
+                float* dst = dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c;
+                const float val = (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r];
+                if (p.splits == 1) *dst += val;            // this block owns the tile: no atomics
+                else atomicAdd(dst, val);
+            }
+        }
+    if (do_bias) {
+        // reduce the per-thread column sums over the 8 k-groups (threads with equal columns) through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [8][128]
+        if constexpr (fast) {
+            if (half == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[fkg * 128 + 8 * c8 + e] = bs8[e];
+            }
+        } else {
+            *reinterpret_cast<float4*>(red + kg * 128 + 4 * c4) = bsum;
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q * 128 + tid];
+            atomicAdd(p.db + (int64_t)bz * p.sDb + n0 + tid, (p.oscale ? p.oscale[n0 + tid] : 1.f) * s);
+        }
+    }
+}
+
+// ---- transposed-read variant (both operands bf16 with 16-byte rows, N % 128 == 0, Cin % 128 == 0, no row scale).
+// The reduction index (frames) is the SLOW index of both dY (M, N) and X (rows, Cin); the kernel above transposes 8x8
+// blocks in registers while staging, which makes it VALU-bound (~500 VALU instructions per k-slab and wave, PMC).  Here
+// the slabs are copied as they lie in HBM with global_load_lds (64 frames x 128 channels per operand, 256-byte rows), and
+// the MFMA fragments (8 consecutive frames of one channel per lane) are produced by ds_read_b64_tr_b16, which transposes
+// a 4 (frames) x 16 (channels) block per 16-lane group on the way out of LDS.
+// Bank mapping: a 256-byte row covers all 64 banks, so the 4 frame rows of one transposed read would collide 4-way; the
+// 16-byte slot index is XOR-ed with 4 * (row & 3) (applied to the global source address when staging and to the LDS
+// address when reading), which puts the 8 (row, 16-channel group) segments of a 32-lane pass on 8 distinct bank ranges.
+// T = 128: 4 waves of 64x64, 256-byte rows, slot ^= 4 * (row & 3).
+// T = 64 (the 64-channel DiscriminatorR layers): 4 waves of 32x32, 128-byte rows (two rows per 64 banks), the 4 frame
+// rows of a transposed read alternate bank halves and slot ^= 4 * ((row >> 1) & 1) separates the pairs.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// F32 = true: f32 operands in HBM (the generator's activations); the slab goes global -> registers -> bf16 -> LDS (same
+// LDS image as the DMA path, so the transposed reads are shared), with the optional per-frame scale `arow` applied to dY.
+template <int T, bool F32 = false>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
+    constexpr int SK = 64;                                   // frames per slab
+    constexpr int S = T / 8, RPI = 64 / S, NI = SK / RPI / 4, TI = T / 64;   // slots/row, rows/instruction, instr/wave/operand
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * 2 * SK * T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * (T / 2), wn0 = (wave & 1) * (T / 2);
+    const int ctiles = p.Cin / T;
+    const int j = blockIdx.y / ctiles, c0 = (blockIdx.y - j * ctiles) * T;
+    const int n0 = blockIdx.x * T;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z - bz * p.splits;
+    const unsigned short* dY = reinterpret_cast<const unsigned short*>(p.dY) + (int64_t)bz * p.sYb;
+    const unsigned short* X = reinterpret_cast<const unsigned short*>(p.X) + (int64_t)bz * p.sXb;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
+    const bool do_bias = (p.db != nullptr) && (blockIdx.y == 0);
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
+    const int64_t ldy = p.ldy, ldx = p.ldx;
+    auto swz = [](int row) { return T == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };
+
+    f32x16 acc[TI][TI], accb[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < TI; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    }
+    // staging: wave w, instruction i covers slab rows RPI * (NI * w + i) + (lane / S); physical 16-byte slot = lane % S
+    const int srow = lane / S, lslot = (lane % S) ^ swz(srow);
+    // one (dY row, X row) pair of loads; `i` = instruction index 0..NI-1
+    auto issue_pair = [&](int mk, int buf, int i) {
+        unsigned short* ys = smem + buf * (2 * SK * T);
+        unsigned short* xs = ys + SK * T;
+        const int row0 = RPI * (NI * wave + i), m = mk + row0 + srow;
+        const bool mv = m < mend;
+        const unsigned short* src = mv ? dY + (int64_t)m * ldy + n0 + lslot * 8 : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, 0, 0);
+        const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+        const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+        const bool xv = mv && tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin;
+        const unsigned short* xsrc = xv ? X + (((int64_t)u * p.Hin + hh) * p.Tin + tt) * ldx + c0 + lslot * 8 : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
+                                         (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, 0, 0);
+    };
+    auto issue = [&](int mk, int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_pair(mk, buf, i);
+    };
+    // f32 operands: the same (row, slot) assignment, through registers
+    const float* dYf = reinterpret_cast<const float*>(p.dY) + (int64_t)bz * p.sYb;
+    const float* Xf = reinterpret_cast<const float*>(p.X) + (int64_t)bz * p.sXb;
+    const float* arow = p.arow ? p.arow + (int64_t)bz * p.M : nullptr;
+    float4 ry[NI][2], rx[NI][2];
+    auto gload_f32 = [&](int mk) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row0 = RPI * (NI * wave + i), m = mk + row0 + srow;
+            const bool mv = m < mend;
+            const int mc = mv ? m : mbeg;                                         // index select: loads stay unconditional
+            const float4* ys4 = reinterpret_cast<const float4*>(dYf + (int64_t)mc * ldy + n0 + lslot * 8);
+            const float sc = mv ? (arow ? arow[mc] : 1.f) : 0.f;
+            float4 a = ys4[0], b = ys4[1];
+            ry[i][0] = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+            ry[i][1] = make_float4(b.x * sc, b.y * sc, b.z * sc, b.w * sc);
+            const int u = fd_div(mc, p.fd_trows), t = mc - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+            const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+            const bool xv = mv && tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin;
+            const int64_t xr = xv ? (((int64_t)u * p.Hin + hh) * p.Tin + tt) : 0;
+            const float4* xs4 = reinterpret_cast<const float4*>(Xf + xr * ldx + c0 + lslot * 8);
+            const float xsel = xv ? 1.f : 0.f;
+            a = xs4[0]; b = xs4[1];
+            rx[i][0] = make_float4(a.x * xsel, a.y * xsel, a.z * xsel, a.w * xsel);
+            rx[i][1] = make_float4(b.x * xsel, b.y * xsel, b.z * xsel, b.w * xsel);
+        }
+    };
+    auto sstore_f32 = [&](int buf) {
+        unsigned short* ys = smem + buf * (2 * SK * T);
+        unsigned short* xs = ys + SK * T;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int off = (RPI * (NI * wave + i) + srow) * T + (lane % S) * 8;
+            *reinterpret_cast<uint4*>(ys + off) = make_uint4(pk2(ry[i][0].x, ry[i][0].y), pk2(ry[i][0].z, ry[i][0].w),
+                                                             pk2(ry[i][1].x, ry[i][1].y), pk2(ry[i][1].z, ry[i][1].w));
+            *reinterpret_cast<uint4*>(xs + off) = make_uint4(pk2(rx[i][0].x, rx[i][0].y), pk2(rx[i][0].z, rx[i][0].w),
+                                                             pk2(rx[i][1].x, rx[i][1].y), pk2(rx[i][1].z, rx[i][1].w));
+        }
+    };
+    // fragment of operand tile `base` ([SK][T]) for the 32 channels starting at `col0`, k-step ks: 8 consecutive frames
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1, kg = lane >> 5;
+    auto frag = [&](const unsigned short* base, int col0, int ks) -> bf16x8 {
+        const int col = col0 + 16 * g16 + 4 * (r16 & 3);                          // first of this lane's 4 source channels
+        const int pslot = (col >> 3) ^ swz(r16 >> 2);
+        const unsigned short* a0 = base + (16 * ks + 8 * kg + (r16 >> 2)) * T + pslot * 8 + (col & 7);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * T));
+        union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+        u.s.l = lo; u.s.h = hi;
+        return u.v;
+    };
+    bf16x8 ones;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+    // MFMA phase over slab `buf`; the next slab (frames from `mk_next`, < 0 = none) is staged one row pair per k-step
+    auto mma = [&](int buf, int mk_next) {
+        const unsigned short* ys = smem + buf * (2 * SK * T);
+        const unsigned short* xs = ys + SK * T;
+#pragma unroll
+        for (int ks = 0; ks < SK / 16; ++ks) {
+            bf16x8 a[TI], b[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = frag(ys, wm0 + 32 * i, ks);
+#pragma unroll
+            for (int jj = 0; jj < TI; ++jj) b[jj] = frag(xs, wn0 + 32 * jj, ks);
+            if (mk_next >= 0 && ks < NI) issue_pair(mk_next, buf ^ 1, ks);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TI; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+            if (do_bias && wn0 == 0) {                                            // block-uniform x wave-uniform
+#pragma unroll
+                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    };
+    const int niter = (mend - mbeg + SK - 1) / SK;
+    if constexpr (F32) {
+        if (niter > 0) {
+            gload_f32(mbeg);
+            sstore_f32(0);
+            __syncthreads();
+            for (int it = 0; it < niter; ++it) {
+                const int buf = it & 1;
+                if (it + 1 < niter) gload_f32(mbeg + (it + 1) * SK);
+                mma(buf, -1);
+                if (it + 1 < niter) sstore_f32(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    } else if (niter > 0) {
+        issue(mbeg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const int buf = it & 1;
+            mma(buf, it + 1 < niter ? mbeg + (it + 1) * SK : -1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TI; ++jj) {
+            const int c = c0 + wn0 + 32 * jj + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* dst = dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c;
+                const float val = (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r];
+                if (p.splits == 1) *dst += val;            // this block owns the tile: no atomics
+                else atomicAdd(dst, val);
+            }
+        }
+    if (do_bias && wn0 == 0 && l31 == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                atomicAdd(p.db + (int64_t)bz * p.sDb + n, (p.oscale ? p.oscale[n] : 1.f) * accb[i][r]);
+            }
+    }
+}
+
+static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                   int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
+                                   int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
+                                   float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                   hipStream_t stream) {
+    OSP_CHECK_ARG(dY && X && dW, "null operand");
+    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && M % Trows == 0 && batch > 0, "bad shape");
+    WgradB p;
+    p.dY = dY; p.y_bf16 = (int)y_bf16; p.ldy = ldy; p.X = X; p.x_bf16 = (int)x_bf16; p.ldx = ldx;
+    p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.N = (int)N; p.Cin = (int)Cin; p.taps = (int)taps;
+    p.pad = (int)pad; p.x_step = (int)x_step; p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db;
+    p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb;
+    p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.x_step_h = (int)d2[3]; p.pad_h = (int)d2[4];
+    p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
+    const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
+    int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);
+    int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
+    if (chunk < 2 * TBK) chunk = 2 * TBK;
+    splits = cdiv(M, chunk);
+    p.chunk = (int)chunk; p.splits = (int)splits;
+    dim3 grid((unsigned)cdiv(N, TBM), (unsigned)(taps * cdiv(Cin, TBN)), (unsigned)(splits * batch));
+    const bool fast = y_bf16 && x_bf16 && !arow && (ldy % 8 == 0) && (ldx % 8 == 0) && (N % 8 == 0) && (Cin % 8 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dY) & 15) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                      (sYb % 8 == 0) && (sXb % 8 == 0);
+    static int use_tr = -1;
+    if (use_tr < 0) { const char* e = getenv("OSP_WGRAD_TR"); use_tr = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_tr && fast && N % 64 == 0 && Cin % 64 == 0) {
+        // 128-tiles when both channel counts allow it, 64-tiles otherwise (DiscriminatorR).  The frames are split so that
+        // the grid is close to a multiple of the resident workgroup count (2 / CU for T = 128, 4 / CU for T = 64);
+        // partial sums meet in f32 atomics
+        const int64_t T_ = (N % 128 == 0 && Cin % 128 == 0) ? 128 : 64;
+        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = T_ == 128 ? 1024 : 2048;
+        int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
+        int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
+        if (ch < 4 * TBK) ch = 4 * TBK;
+        sp = cdiv(M, ch);
+        p.chunk = (int)ch; p.splits = (int)sp;
+        const dim3 g((unsigned)(N / T_), (unsigned)(taps * (Cin / T_)), (unsigned)(sp * batch));
+        if (T_ == 128) hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<64>, g, dim3(256), 0, stream, p);
+    }
+    else if (use_tr && !y_bf16 && !x_bf16 && N % 64 == 0 && Cin % 64 == 0 && (ldy % 4 == 0) && (ldx % 4 == 0) &&
+             ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0 && (sYb % 4 == 0) && (sXb % 4 == 0)) {
+        // f32 operands (generator): 64-channel tiles through registers; small problems -> many splits
+        const int64_t tl = (N / 64) * taps * (Cin / 64) * batch;
+        int64_t sp = tl >= 960 ? 1 : (2048 + tl / 2) / tl;
+        int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
+        if (ch < 2 * TBK) ch = 2 * TBK;
+        sp = cdiv(M, ch);
+        p.chunk = (int)ch; p.splits = (int)sp;
+        const dim3 g((unsigned)(N / 64), (unsigned)(taps * (Cin / 64)), (unsigned)(sp * batch));
+        hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<64, true>), g, dim3(256), 0, stream, p);
+    }
+    else if (fast) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                   int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
+                                   int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
+                                   float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                   hipStream_t stream) {
+    const int64_t d2[5] = {Trows, 1, taps, 0, 0};
+    return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Tin, N, Cin, taps, pad, x_step, arow, oscale, dW, ldw,
+                                db, batch, sYb, sXb, sWb, sDb, stream);
+}
+
+// 2-D weight gradient: dW[n, kh, kw, c] += sum dY[u, th, tw, n] * X[u, th*x_step_h + kh - pad_h, tw*x_step + kw - pad, c]
+extern "C" int osp_conv2d_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                     int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin, int64_t Win, int64_t N, int64_t Cin,
+                                     int64_t taps, int64_t KW, int64_t pad_h, int64_t pad, int64_t x_step_h, int64_t x_step,
+                                     float* dW, float* db, hipStream_t stream) {
+    const int64_t d2[5] = {Wrows, Hin, KW, x_step_h, pad_h};
+    return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Win, N, Cin, taps, pad, x_step, nullptr, nullptr, dW,
+                                taps * Cin, db, 1, 0, 0, 0, 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ casts
+__global__ void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        reinterpret_cast<uint2*>(y)[i] = make_uint2(pk2(v.x, v.y), pk2(v.z, v.w));
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = __builtin_bit_cast(unsigned short, (__bf16)x[i]);
+}
+extern "C" int osp_cast_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
+    OSP_CHECK_ARG(x && y && n > 0, "bad args");
+    const int64_t blocks = cdiv(n, 1024);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, x, (unsigned short*)y, n);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// out[n][tap][k] (bf16, contiguous) = w[n*sN + tap*sT + k*sK] (f32; any strides, sT may be negative for a flipped kernel).
+// The dgrad GEMMs of the generator address the weights transposed (k-strided); packing them once per call into the
+// k-contiguous bf16 layout lets the GEMM use 16-byte operand loads instead of its transposing element loader, which is
+// ~2x slower than the GEMM itself on these small shapes.  32x32 tiles through LDS, reads along the unit-stride axis.
+// Algorithmic bytes: 4 read + 2 written per weight.
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int N, int taps,
+                                                        int K, int64_t sN, int64_t sT, int64_t sK) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + (int64_t)tap * sT;
+    const bool along_n = (sN < 0 ? -sN : sN) < (sK < 0 ? -sK : sK);
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = along_n ? n0 + tx : n0 + r, k = along_n ? k0 + r : k0 + tx;
+        const float v = (n < N && k < K) ? src[(int64_t)n * sN + (int64_t)k * sK] : 0.f;
+        if (along_n) tile[r][tx] = v; else tile[tx][r] = v;      // tile[k_local][n_local]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) out[((int64_t)n * taps + tap) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][r]);
+    }
+}
+extern "C" int osp_pack_bf16(const float* w, void* out, int64_t N, int64_t taps, int64_t K, int64_t sN, int64_t sT, int64_t sK,
+                             hipStream_t stream) {
+    OSP_CHECK_ARG(w && out && N > 0 && taps > 0 && K > 0, "bad args");
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32), (unsigned)taps), dim3(256), 0, stream, w,
+                       (unsigned short*)out, (int)N, (int)taps, (int)K, sN, sT, sK);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
