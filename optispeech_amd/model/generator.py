@@ -24,6 +24,9 @@ def sequence_mask(length, max_length=None):
     return x.unsqueeze(0) < length.unsqueeze(1)
 
 
+_VOC_STREAM = __import__("os").environ.get("OSP_VOC_STREAM", "1") != "0"
+
+
 class OptiSpeechGenerator(nn.Module):
     def __init__(self, dim: int, segment_size, text_embedding, encoder, duration_predictor, pitch_predictor,
                  energy_predictor, decoder, vocoder, loss_coeffs, feature_extractor, num_speakers, num_languages,
@@ -92,7 +95,12 @@ class OptiSpeechGenerator(nn.Module):
         r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=y.device)
         start_idx = (r.to(y.device) * max_start).to(torch.long)                             # utils/segments.py:32-34
         segment = K.gather_rows(y.detach(), start_idx, segment_size)                        # :149-153, detach :161
-        wav_hat = self.vocoder(segment, f0=None)                                            # :161 (f0 unused by WaveNeXt)
+        # :161 (f0 unused by WaveNeXt).  The vocoder's graph is disjoint from the acoustic model's (``segment`` is detached):
+        # built on its own stream, its backward overlaps the acoustic model's backward
+        if _VOC_STREAM and segment.is_cuda and torch.is_grad_enabled():
+            wav_hat = ops.run_on_side_stream("vocoder", lambda: self.vocoder(segment, f0=None), [segment])
+        else:
+            wav_hat = self.vocoder(segment, f0=None)
 
         c = self.loss_coeffs
         duration_loss, pitch_loss, energy_loss = ops.VarianceLossFn.apply(

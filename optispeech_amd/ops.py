@@ -457,3 +457,46 @@ class AttentionFn(torch.autograd.Function):
         K.conv_wgrad(dS, qh, dKh, None, batch=Z)                         # dK[t2, d] = sum_t1 dS[t1, t2] q[t1, d]
         back = lambda t: t.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, H * dk)              # noqa: E731
         return back(dQ), back(dKh), back(dV), None, None, None, None, None
+
+
+class JoinStreamAtBackwardEndFn(torch.autograd.Function):
+    """Identity.  Placed on the output of a sub-graph that ran on a side stream: autograd replays that sub-graph's backward on
+    the same side stream, and because parameter gradients are written straight into the gradient arena (no AccumulateGrad
+    node) the engine would not make the stream backward() was called from wait for it -- this node's backward (the first
+    node of the sub-graph's backward) queues that wait as an engine callback."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        side = torch.cuda.current_stream()
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
+        return g
+
+
+def run_on_side_stream(key, fn, inputs):
+    """fn() on a persistent side stream ordered after the current stream; the current stream waits for it right away (the
+    forward stays serial) -- the point is that autograd replays fn's backward on that stream, concurrently with whatever
+    backward work runs on the current stream."""
+    main = torch.cuda.current_stream()
+    st = _side_stream(inputs[0].device) if key is None else _named_stream(key, inputs[0].device)
+    st.wait_stream(main)
+    with torch.cuda.stream(st):
+        out = JoinStreamAtBackwardEndFn.apply(fn())
+    for t in inputs:
+        t.record_stream(st)
+    main.wait_stream(st)
+    out.record_stream(main)
+    return out
+
+
+_named = {}
+
+
+def _named_stream(key, device):
+    k = (key, torch.device(device).index)
+    if k not in _named:
+        _named[k] = torch.cuda.Stream(device=device)
+    return _named[k]
