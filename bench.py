@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the bounded CPU-baseline sample")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="serial schedule: do not issue the discriminator phase from its own stream (OptiSpeech.pipeline_steps)")
     ap.add_argument("--backbone", choices=["convnext", "transformer"], default="convnext",
                     help="transformer = BASELINE configs[4] encoder/decoder (secondary datapoint; the headline is convnext)")
     ap.add_argument("--precision", choices=["bf16", "f32"], default=os.environ.get("OSP_PRECISION", "bf16"),
@@ -153,6 +155,9 @@ def main():
     model = make_optispeech(cfg, batch_size=B, pretraining_steps=0).to(dev).train()
     batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
     model.optimizers()
+    # production schedule: the discriminator phase runs from a second calling stream, so step n+1's generator forward
+    # overlaps step n's discriminator backward (everything is drained by the synchronize() that closes the timed region)
+    model.pipeline_steps = not a.no_pipeline
 
     # dominant hand-written kernel by time: conv_gemm_bf16_glds_kernel (csrc/gemm_bf16.hip), i.e. every conv-GEMM launch
     # whose operands are bf16 in HBM with Cin % 64 == 0 (all large MPD / MRD forward and dgrad GEMMs).  Algorithmic
@@ -268,7 +273,7 @@ def main():
                "config": {"workload": ("configs[4]: Transformer backbone" if a.backbone == "transformer" else "configs[1]: ConvNeXt backbone") + ", synthetic LJSpeech-shaped batch=32 per GPU "
                                       "(T_text=128, T_mel=800, 22.05 kHz), full GAN training step "
                                       "(G phase + D phase + 2x AdamW), train mode",
-                          "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}",
+                          "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}", "schedule": "serial" if a.no_pipeline else "pipelined (pipeline_steps)",
                           "lengths": "ragged" if a.ragged else "fixed"},
                "per_gpu": value / world, "roofline": roof, "cpu_baseline": cpu,
                "synthesise": None if a.no_infer else synthesise_rtf(model, dev),
