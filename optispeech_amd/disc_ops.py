@@ -73,87 +73,6 @@ def conv1d_strided_bwd(dy, x, w, dw, db, taps, stride, pad, need_dx):
     return conv1d_strided_dgrad(dy, w, Tin, Cin, taps, stride, pad) if need_dx else None
 
 
-class MPDStackFn(torch.autograd.Function):
-    """The six convolutions of one DiscriminatorP on a batch of period-folded sequences.
-
-    inputs : x (U, T0, 1) f32; then (w_i native (Cout, taps, Cin) f32, b_i) for the 5 convs and conv_post
-    outputs: y1..y5 (bf16, LeakyReLU applied; y2..y5 are the reference's fmap entries) and the score s (U, T5, 1) f32
-    """
-    STRIDES = (3, 3, 3, 3, 1)
-    SLOPE = 0.1
-
-    @staticmethod
-    def forward(ctx, x, *wb):
-        ctx.set_materialize_grads(False)
-        ws, bs = wb[0::2], wb[1::2]
-        acts, h = [], x.contiguous()
-        wbf = [K.cast_bf16(w) for w in ws]
-        ctx.need_dgrad = any(ctx.needs_input_grad)
-        for i in range(5):
-            if i == 0 and ws[0].shape[0] in (16, 32, 64):           # Cin = 1: direct VALU kernel (csrc/smallcin.hip)
-                U, T0 = h.shape[0], h.shape[1]
-                T1 = _tout(T0, 5, 3, 2)
-                h = K.smallcin_fwd(h, ws[0].detach(), bs[0], U=U, Hin=1, Win=T0, Ho=1, Wo=T1, cout=ws[0].shape[0], KH=1, KW=5,
-                                   sh=1, sw=3, ph=0, pw=2, slope=MPDStackFn.SLOPE, out_bf16=True).view(U, T1, -1)
-            else:
-                h = conv1d_strided_fwd(h, wbf[i], bs[i], 5, MPDStackFn.STRIDES[i], 2, MPDStackFn.SLOPE, True)
-            acts.append(h)
-        s = conv1d_strided_fwd(h, wbf[5], bs[5], 3, 1, 1, None, False)
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, *acts, *wbf)
-            ctx.wneed = [w.requires_grad for w in ws]
-            ctx.bneed = [b.requires_grad for b in bs]
-        return (*acts, s)
-
-    @staticmethod
-    def backward(ctx, d1, d2, d3, d4, d5, ds):
-        saved = ctx.saved_tensors
-        x, acts, wbf = saved[0], saved[1:6], saved[6:12]
-        extras = [d.contiguous() if d is not None else None for d in (d1, d2, d3, d4, d5)]
-        if ds is None:
-            ds = torch.zeros((x.shape[0], acts[4].shape[1], 1), device=x.device, dtype=torch.float32)
-        U = x.shape[0]
-        grads_w, grads_b = [None] * 6, [None] * 6
-
-        def wgrad(i, g, inp, taps, pad, stride):
-            if not (ctx.wneed[i] or ctx.bneed[i]):
-                return
-            Cout, Cin = wbf[i].shape[0], wbf[i].shape[2]
-            dw = torch.zeros(wbf[i].shape, device=g.device, dtype=torch.float32)
-            db = torch.zeros(Cout, device=g.device, dtype=torch.float32)
-            Tin, Tout = inp.shape[1], g.shape[1]
-            if Cin == 1 and Cout in (16, 32, 64):
-                K.smallcin_wgrad(inp, g, dw, db, U=U, Hin=1, Win=Tin, Ho=1, Wo=Tout, cout=Cout, KH=1, KW=taps, sh=1,
-                                 sw=stride, ph=0, pw=pad)
-            else:
-                K.conv_wgrad_bf16(g.view(U * Tout, Cout), inp.reshape(U * Tin, Cin), dw, db, M=U * Tout, Trows=Tout,
-                                  Tin=Tin, n=Cout, cin=Cin, taps=taps, pad=pad, x_step=stride)
-            grads_w[i], grads_b[i] = dw, db
-
-        wts = [transpose_weight(w) for w in wbf]
-        # conv_post: s = conv(y5)
-        g = ds.contiguous()
-        wgrad(5, g, acts[4], 3, 1, 1)
-        g = conv1d_strided_dgrad(g, wbf[5], acts[4].shape[1], acts[4].shape[2], 3, 1, 1, lrelu_y=acts[4],
-                                 extra=extras[4], slope=MPDStackFn.SLOPE, out_bf16=True, wt=wts[5])
-        for i in range(4, -1, -1):
-            inp = acts[i - 1] if i > 0 else x
-            st = MPDStackFn.STRIDES[i]
-            wgrad(i, g, inp, 5, 2, st)
-            if i > 0:
-                g = conv1d_strided_dgrad(g, wbf[i], inp.shape[1], inp.shape[2], 5, st, 2, lrelu_y=inp,
-                                         extra=extras[i - 1], slope=MPDStackFn.SLOPE, out_bf16=True, wt=wts[i])
-            elif ctx.needs_input_grad[0]:
-                g = conv1d_strided_dgrad(g, wbf[0], inp.shape[1], 1, 5, st, 2, out_bf16=False, wt=wts[0])
-            else:
-                g = None
-        out = [g]
-        for i in range(6):
-            out += [grads_w[i], grads_b[i]]
-        return tuple(out)
-
-
-# =================================================================================================== 2-D (MRD)
 def conv2d_fwd(x, w, bias, KH, KW, sh, sw, ph, pw, slope, out_bf16):
     """x (U,H,W,C) channels-last; w native (Cout, KH, KW, Cin) -> (U,Ho,Wo,Cout), optional fused LeakyReLU."""
     U, H, W, C = x.shape
@@ -194,75 +113,6 @@ def conv2d_wgrad(dy, x, KH, KW, sh, sw, ph, pw):
     K.conv2d_wgrad_bf16(dy.view(U * Ho * Wo, Cout), x.view(U * H * W, Cin), dw, db, M=U * Ho * Wo, Trows=Ho * Wo, Wrows=Wo,
                         Hin=H, Win=W, n=Cout, cin=Cin, taps=KH * KW, KW=KW, pad_h=ph, pad_w=pw, step_h=sh, step_w=sw)
     return dw, db
-
-
-class MRDStackFn(torch.autograd.Function):
-    """The six Conv2d of one DiscriminatorR (vocoder/wavenext/disc/_discriminators.py:154-194) on the channels-last
-    magnitude spectrogram (U, H = frames, W = freq bins, 1) -- i.e. the STFT kernel's output as is.
-
-    spec rows: (KH, KW, sh, sw, ph, pw) in (frames, freq) order.  inputs: x, then (w_i native (Cout,KH,KW,Cin), b_i) x 6.
-    outputs: y1..y5 (bf16, LeakyReLU applied) and the score map s (U,H5,W5,1) f32 -- all six are the reference's fmap.
-    """
-    SPEC = ((5, 7, 2, 2, 2, 3), (3, 5, 1, 2, 1, 2), (3, 5, 2, 2, 1, 2), (3, 3, 1, 2, 1, 1), (3, 3, 2, 2, 1, 1),
-            (3, 3, 1, 1, 1, 1))
-    SLOPE = 0.1
-
-    @staticmethod
-    def forward(ctx, x, *wb):
-        ctx.set_materialize_grads(False)
-        ws, bs = wb[0::2], wb[1::2]
-        wbf = [K.cast_bf16(w) for w in ws]
-        acts, h = [], x.contiguous()
-        for i in range(5):
-            if i == 0 and ws[0].shape[0] in (16, 32, 64) and h.shape[-1] == 1:   # Cin = 1: direct VALU kernel
-                KH, KW, sh, sw, ph, pw = MRDStackFn.SPEC[0]
-                U, H, W = h.shape[0], h.shape[1], h.shape[2]
-                Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
-                h = K.smallcin_fwd(h, ws[0].detach().reshape(ws[0].shape[0], -1), bs[0], U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo,
-                                   cout=ws[0].shape[0], KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=MRDStackFn.SLOPE,
-                                   out_bf16=True).view(U, Ho, Wo, -1)
-            else:
-                h = conv2d_fwd(h, wbf[i], bs[i], *MRDStackFn.SPEC[i], MRDStackFn.SLOPE, True)
-            acts.append(h)
-        s = conv2d_fwd(h, wbf[5], bs[5], *MRDStackFn.SPEC[5], None, False)
-        if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, *acts, *wbf)
-            ctx.wneed = [w.requires_grad or b.requires_grad for w, b in zip(ws, bs)]
-        return (*acts, s)
-
-    @staticmethod
-    def backward(ctx, d1, d2, d3, d4, d5, ds):
-        saved = ctx.saved_tensors
-        x, acts, wbf = saved[0], saved[1:6], saved[6:12]
-        extras = [d.contiguous() if d is not None else None for d in (d1, d2, d3, d4, d5)]
-        if ds is None:
-            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
-        gw, gb = [None] * 6, [None] * 6
-        g = ds.contiguous()
-        for i in range(5, -1, -1):
-            inp = acts[i - 1] if i > 0 else x
-            sp = MRDStackFn.SPEC[i]
-            if ctx.wneed[i]:
-                if i == 0 and inp.shape[-1] == 1 and g.shape[-1] in (16, 32, 64):
-                    KH, KW, sh, sw, ph, pw = sp
-                    cout = g.shape[-1]
-                    gw[i] = torch.zeros((cout, KH, KW, 1), device=g.device, dtype=torch.float32)
-                    gb[i] = torch.zeros((cout,), device=g.device, dtype=torch.float32)
-                    K.smallcin_wgrad(inp, g, gw[i], gb[i], U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
-                                     Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
-                else:
-                    gw[i], gb[i] = conv2d_wgrad(g, inp, *sp)
-            if i > 0:
-                g = conv2d_dgrad(g, transpose_weight2d(wbf[i]), inp.shape[1], inp.shape[2], *sp, lrelu_y=inp,
-                                 extra=extras[i - 1], slope=MRDStackFn.SLOPE, out_bf16=True)
-            elif ctx.needs_input_grad[0]:
-                g = conv2d_dgrad(g, transpose_weight2d(wbf[0]), inp.shape[1], inp.shape[2], *sp, out_bf16=False)
-            else:
-                g = None
-        out = [g]
-        for i in range(6):
-            out += [gw[i], gb[i]]
-        return tuple(out)
 
 
 # =================================================================================================== generic stack
@@ -543,7 +393,8 @@ class ConvStackPreciseFn(torch.autograd.Function):
 
 
 MPD_SPEC = ((1, 5, 1, 3, 0, 2),) * 4 + ((1, 5, 1, 1, 0, 2), (1, 3, 1, 1, 0, 1))
-MRD_SPEC = MRDStackFn.SPEC
+# DiscriminatorR: (KH = k_time, KW = k_freq, sh, sw, ph, pw) per layer in native (frames, bins) orientation
+MRD_SPEC = ((5, 7, 2, 2, 2, 3), (3, 5, 1, 2, 1, 2), (3, 5, 2, 2, 1, 2), (3, 3, 1, 2, 1, 1), (3, 3, 2, 2, 1, 1), (3, 3, 1, 1, 1, 1))
 
 
 class L1MeanFn(torch.autograd.Function):

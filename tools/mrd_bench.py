@@ -18,7 +18,7 @@ for (n_fft, hop) in ((1024, 256), (2048, 512), (512, 128)):
     x = torch.rand(B, H, W, 1, device=dev)
     print(f"res {n_fft}: H={H} W={W}")
     cin = 1
-    for i, sp in enumerate(D.MRDStackFn.SPEC):
+    for i, sp in enumerate(D.MRD_SPEC):
         KH, KW, sh, sw, ph, pw = sp
         cout = 64 if i < 5 else 1
         w = K.cast_bf16(torch.randn(cout, KH, KW, cin, device=dev) * 0.05)
