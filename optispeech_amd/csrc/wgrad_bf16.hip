@@ -434,7 +434,9 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         // the grid is close to a multiple of the resident workgroup count (2 / CU for T = 128, 4 / CU for T = 64);
         // partial sums meet in f32 atomics
         const int64_t T_ = (N % 128 == 0 && Cin % 128 == 0) ? 128 : 64;
-        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = T_ == 128 ? 1024 : 2048;
+        static int64_t tgt_env = -1;
+        if (tgt_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET"); tgt_env = e ? atoll(e) : 0; }
+        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = tgt_env > 0 ? (T_ == 128 ? tgt_env : 2 * tgt_env) : (T_ == 128 ? 1024 : 2048);
         int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
         if (ch < 4 * TBK) ch = 4 * TBK;
