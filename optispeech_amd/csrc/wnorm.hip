@@ -121,3 +121,35 @@ extern "C" int osp_l1_sign(const void* a, const void* b, int64_t is_bf16, int64_
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ fused hinge means
+// GeneratorLoss / DiscriminatorLoss terms (disc/loss.py:16-65): out += scale * sum max(0, 1 + sgn * x)  (sgn = -1 for the
+// "real" / generator terms mean(clamp(1 - x, 0)), +1 for mean(clamp(1 + x, 0))); backward dx = gscale * scale * sgn * [1 + sgn x > 0].
+__global__ __launch_bounds__(256) void hinge_sum_kernel(const float* __restrict__ x, int64_t n, float sgn, float scale,
+                                                        float* __restrict__ out) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += fmaxf(0.f, 1.f + sgn * x[i]);
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+extern "C" int osp_hinge_sum(const float* x, int64_t n, float sgn, float scale, float* out, hipStream_t stream) {
+    OSP_CHECK_ARG(x && out && n > 0, "bad args");
+    const int64_t blocks = cdiv(n, 256 * 8);
+    hipLaunchKernelGGL(hinge_sum_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, stream, x, n, sgn, scale, out);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+__global__ __launch_bounds__(256) void hinge_grad_kernel(const float* __restrict__ x, int64_t n, float sgn, float scale,
+                                                         const float* __restrict__ gscale, float* __restrict__ dx) {
+    const float g = gscale[0] * scale * sgn;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = (1.f + sgn * x[i] > 0.f) ? g : 0.f;
+}
+extern "C" int osp_hinge_grad(const float* x, int64_t n, float sgn, float scale, const float* gscale, float* dx, hipStream_t stream) {
+    OSP_CHECK_ARG(x && gscale && dx && n > 0, "bad args");
+    const int64_t blocks = cdiv(n, 256 * 8);
+    hipLaunchKernelGGL(hinge_grad_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, stream, x, n, sgn, scale, gscale, dx);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

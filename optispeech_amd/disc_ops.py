@@ -412,3 +412,54 @@ class L1MeanFn(torch.autograd.Function):
     def backward(ctx, gout):
         target, y = ctx.saved_tensors
         return None, K.l1_sign(target, y, 1.0 / y.numel(), gout.reshape(1).float().contiguous())
+
+
+class FeatureMatchSumFn(torch.autograd.Function):
+    """sum_i mean |target_i - y_i| over a whole list of feature-map pairs in ONE autograd node (FeatureMatchingLoss,
+    disc/loss.py:71-85): n fused |a-b| reductions accumulate into one scalar; the backward writes sign(y - target) / numel
+    per pair.  Inputs: n targets followed by n generated maps."""
+
+    @staticmethod
+    def forward(ctx, n, *maps):
+        tg, ys = [t.contiguous() for t in maps[:n]], [t.contiguous() for t in maps[n:]]
+        out = torch.zeros((), device=ys[0].device, dtype=torch.float32)
+        for a, b in zip(tg, ys):
+            K.l1_sum(a, b, 1.0 / b.numel(), out)
+        ctx.save_for_backward(*tg, *ys)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        n, saved = ctx.n, ctx.saved_tensors
+        g = gout.reshape(1).float().contiguous()
+        grads = [K.l1_sign(a, b, 1.0 / b.numel(), g) for a, b in zip(saved[:n], saved[n:])]
+        return (None,) + (None,) * n + tuple(grads)
+
+
+class HingeSumFn(torch.autograd.Function):
+    """sum_i mean(clamp(1 + sgn_i * x_i, min=0)) over a list of score maps in one node (GeneratorLoss / DiscriminatorLoss,
+    disc/loss.py:16-65).  ``sgns``: tuple of +-1 per tensor."""
+
+    @staticmethod
+    def forward(ctx, sgns, *xs):
+        xs = [x.contiguous().float() for x in xs]
+        out = torch.zeros((), device=xs[0].device, dtype=torch.float32)
+        for s, x in zip(sgns, xs):
+            K.call("osp_hinge_sum", x, x.numel(), float(s), 1.0 / x.numel(), out)
+        ctx.save_for_backward(*xs)
+        ctx.sgns = sgns
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = gout.reshape(1).float().contiguous()
+        grads = []
+        for s, x, need in zip(ctx.sgns, ctx.saved_tensors, ctx.needs_input_grad[1:]):
+            if not need:
+                grads.append(None)
+                continue
+            dx = torch.empty_like(x)
+            K.call("osp_hinge_grad", x, x.numel(), float(s), 1.0 / x.numel(), g, dx)
+            grads.append(dx)
+        return (None,) + tuple(grads)

@@ -15,7 +15,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import precision, spectral
-from ..disc_ops import MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, L1MeanFn
+from ..disc_ops import (MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, FeatureMatchSumFn, HingeSumFn,
+                        L1MeanFn)
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -254,6 +255,8 @@ class _Multi(nn.Module):
 #: f32 parity mode: discriminators on the hand-written kernels (split-bf16 products); "0" = torch conv2d (MIOpen)
 _F32_HIP = os.environ.get("OSP_F32_DISC_HIP", "1") != "0"
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
+#: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
+_FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"
 _STREAMS = {}
 _PENDING = []
 
@@ -305,16 +308,28 @@ class MultiResolutionDiscriminator(_Multi):
         self.discriminators = nn.ModuleList([DiscriminatorR(resolution=r) for r in resolutions])
 
 
+def _fused_losses(t):
+    return precision.is_bf16() and t.is_cuda and _FUSED_LOSSES
+
+
 def _hinge_g(outs):                                            # GeneratorLoss, disc/loss.py:16-32
+    if _fused_losses(outs[0]):
+        return HingeSumFn.apply((-1.0,) * len(outs), *outs) / len(outs)
     return sum(torch.mean(torch.clamp(1 - o, min=0)) for o in outs) / len(outs)
 
 
 def _hinge_d(real, fake):                                      # DiscriminatorLoss, disc/loss.py:40-65
+    if _fused_losses(real[0]):
+        return HingeSumFn.apply((-1.0,) * len(real) + (1.0,) * len(fake), *real, *fake) / len(real)
     return sum(torch.mean(torch.clamp(1 - r, min=0)) + torch.mean(torch.clamp(1 + g, min=0))
                for r, g in zip(real, fake)) / len(real)
 
 
 def _feature_matching(fr, fg):                                 # FeatureMatchingLoss, disc/loss.py:71-85
+    if _fused_losses(fg[0][0]):
+        tg = [a.detach() for dr in fr for a in dr]
+        ys = [b for dg in fg for b in dg]
+        return FeatureMatchSumFn.apply(len(ys), *tg, *ys) / len(fr)
     tot = 0
     for dr, dg in zip(fr, fg):
         for a, b in zip(dr, dg):
