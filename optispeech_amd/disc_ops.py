@@ -231,13 +231,17 @@ def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds
     if ds is None:
         ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
     g = ds.contiguous()
+    # one zero-filled buffer for the native-layout weight gradients of all layers (one fill instead of six)
+    sizes = [vs[i].numel() if need_w[i] else 0 for i in range(6)]
+    flat = torch.zeros((sum(sizes),), device=g.device, dtype=torch.float32) if sum(sizes) else None
+    offs = [sum(sizes[:i]) for i in range(6)]
     for i in range(5, -1, -1):
         inp = acts[i - 1] if i > 0 else x
         KH, KW, sh, sw, ph, pw = spec[i]
         wn, wt, inv = packs[i]
         cout, cin = vs[i].shape[0], vs[i].shape[1]
         if need_w[i]:
-            dw = torch.zeros((cout, KH, KW, cin), device=g.device, dtype=torch.float32)
+            dw = flat[offs[i]:offs[i] + sizes[i]].view(cout, KH, KW, cin)
             db = gsink(bs[i])
             if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
                 K.smallcin_wgrad(inp, g, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
