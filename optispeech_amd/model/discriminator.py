@@ -258,6 +258,7 @@ _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
 #: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
 _FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"
 _STREAMS = {}
+_MAX_STREAMS = int(os.environ.get("OSP_DISC_MAX_STREAMS", "8"))     # streams per discriminator family
 _PENDING = []
 
 
@@ -288,7 +289,8 @@ def on_side_stream(key, fn, inputs):
 def _disc_streams(key, n, device):
     k = (key, torch.device(device).index)
     if k not in _STREAMS:
-        _STREAMS[k] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        pool = [torch.cuda.Stream(device=device) for _ in range(min(n, _MAX_STREAMS))]
+        _STREAMS[k] = [pool[i % len(pool)] for i in range(n)]
     return _STREAMS[k]
 
 
