@@ -148,3 +148,57 @@ class TextWavBatchCollate:
         return dict(x=x, wav=wav, mel=mel, x_lengths=ln("x"), wav_lengths=ln("wav"), mel_lengths=ln("mel"), energies=energies,
                     pitches=pitches, sids=sids, lids=lids, x_texts=[it.get("text", "") for it in batch],
                     filepaths=[it.get("filepath", "") for it in batch])
+
+
+# ------------------------------------------------------------------------------------------------ on-disk dataset
+def parse_filelist(filelist_path):
+    """dataset/text_wav_datamodule.py:46-49: one datapoint stem per non-empty line."""
+    import pathlib
+    return [f for f in pathlib.Path(filelist_path).read_text(encoding="utf-8").splitlines() if f.strip()]
+
+
+def write_datapoint(stem, phoneme_ids, text, wav, mel, energy, pitch, sid=None, lid=None):
+    """The on-disk format of tools/preprocess_dataset.py:57-79: ``<stem>.json`` (phoneme_ids, text[, sid, lid]) +
+    ``<stem>.npz`` (wav, mel, energy, pitch; no pickles)."""
+    import json
+    import pathlib
+    stem = pathlib.Path(stem)
+    meta = {"phoneme_ids": [int(i) for i in phoneme_ids], "text": text}
+    if sid is not None:
+        meta["sid"] = sid
+    if lid is not None:
+        meta["lid"] = lid
+    with open(stem.with_suffix(".json"), "w", encoding="utf-8") as fh:
+        json.dump(meta, fh, ensure_ascii=False)
+    np.savez(stem.with_suffix(".npz"), allow_pickle=False, wav=wav, mel=mel, energy=energy, pitch=pitch)
+
+
+class TextWavDataset(torch.utils.data.Dataset):
+    """dataset/text_wav_datamodule.py:133-193 (the reader half): a shuffled file list of ``.json`` + ``.npz`` datapoints;
+    pitch values at or below ``f_min // 3.5`` are unvoiced and set to 0 (:163-165)."""
+
+    def __init__(self, num_speakers, filelist_path, text_processor, feature_extractor, seed=None):
+        import random
+        self.num_speakers, self.text_processor, self.feature_extractor = num_speakers, text_processor, feature_extractor
+        self.file_paths = parse_filelist(filelist_path)
+        self.uv_threshold = feature_extractor.f_min // 3.5
+        random.Random(seed).shuffle(self.file_paths) if seed is not None else random.shuffle(self.file_paths)
+
+    def get_datapoint(self, filepath):
+        import json
+        import pathlib
+        f = pathlib.Path(filepath)
+        with open(f.with_suffix(".json"), encoding="utf-8") as fh:
+            meta = json.load(fh)
+        arrays = np.load(f.with_suffix(".npz"), allow_pickle=False)
+        pitch = torch.from_numpy(arrays["pitch"]).clone()
+        pitch[pitch <= self.uv_threshold] = 0.0
+        return dict(x=torch.LongTensor(meta["phoneme_ids"]), wav=torch.from_numpy(arrays["wav"]), mel=torch.from_numpy(arrays["mel"]),
+                    energy=torch.from_numpy(arrays["energy"]), pitch=pitch, sid=meta.get("sid"), lid=meta.get("lid"),
+                    text=meta["text"], filepath=str(filepath))
+
+    def __getitem__(self, index):
+        return self.get_datapoint(self.file_paths[index])
+
+    def __len__(self):
+        return len(self.file_paths)

@@ -70,3 +70,33 @@ def test_hip_features_batched_full_size():
     m1, e1 = fe.mel_energy_device(wav[5])
     assert torch.equal(m1[0], mel[5]) and torch.equal(e1[0], energy[5])
     assert torch.isfinite(mel).all() and (mel >= np.log(1e-5) - 1e-6).all()
+
+
+def test_dataset_reader_and_collate_round_trip(tmp_path, golden):
+    """on-disk format (.json + .npz) -> TextWavDataset -> TextWavBatchCollate (CPU device): same batch as the reference's
+    collate produced from the same datapoints; unvoiced pitch threshold applied on read"""
+    import os
+    from types import SimpleNamespace
+    from optispeech_amd import features as FE
+    g = golden("features")
+    stems = []
+    for i, it in enumerate(_items(g)):
+        stem = os.path.join(tmp_path, f"utt{i}")
+        pitch = it["pitch"].copy()
+        FE.write_datapoint(stem, it["x"], f"utt {i}", it["wav"], it["mel"], it["energy"], pitch)
+        stems.append(stem)
+    fl = os.path.join(tmp_path, "train.txt")
+    open(fl, "w").write("\n".join(stems) + "\n\n")
+    ds = FE.TextWavDataset(1, fl, None, SimpleNamespace(f_min=80), seed=1234)
+    assert len(ds) == 4 and ds.uv_threshold == 80 // 3.5 and sorted(ds.file_paths) == sorted(stems)
+    ds.file_paths = stems                                        # undo the shuffle for the comparison
+    items = [ds[i] for i in range(4)]
+    assert items[1]["text"] == "utt 1" and items[2]["x"].dtype == torch.long
+    stats = dict(zip(STAT_KEYS, g["stats"].tolist()))
+    b = FE.TextWavBatchCollate(100, stats, device="cpu")(items)
+    for k in ("x", "wav", "mel", "x_lengths", "wav_lengths", "mel_lengths", "energies", "pitches"):
+        assert np.allclose(b[k].numpy(), g["collate_" + k], rtol=1e-6, atol=1e-6), k
+    # unvoiced rule
+    low = dict(items[0]); stem = os.path.join(tmp_path, "low")
+    FE.write_datapoint(stem, [1, 2], "low", g["wav0"], g["mel0"], g["energy0"], np.full_like(g["pitch0"], 10.0))
+    assert float(ds.get_datapoint(stem)["pitch"].abs().max()) == 0.0
