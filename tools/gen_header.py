@@ -41,6 +41,25 @@ REPLACES = {
     "osp_stft_mag_bwd": "autograd of the same",
     "osp_sumsq": "clip_grad_norm_ total norm (LightningModule.clip_gradients, base_lightning_module.py:100-102,120-122)",
     "osp_adamw_clip": "torch.optim.AdamW.step + clip_gradients: base_lightning_module.py:96-105,116-125; configs/model/optimizer/adamw.yaml",
+    "osp_attn_softmax_fwd": "MultiHeadedAttention.forward_attention masked softmax + dropout: generator/modules/_transformer/attention.py:75-97",
+    "osp_attn_softmax_bwd": "autograd of the same (softmax' and the dropout mask regenerated from the Philox counter)",
+    "osp_conv2d_gemm_bf16": "weight-normed Conv2d forward of DiscriminatorP / DiscriminatorR + F.leaky_relu: "
+                            "vocoder/wavenext/disc/_discriminators.py:51-60,63-97 and :154-163,165-194",
+    "osp_conv2d_dgrad_bf16": "autograd input gradients of the same strided Conv2d stacks (all stride phases in one launch)",
+    "osp_conv2d_wgrad_bf16": "autograd weight gradients of the same Conv2d stacks",
+    "osp_smallcin_conv_fwd": "first layers Conv2d(1, 32, (k,1)) / Conv2d(1, 32, (7,5)) and the 32-channel DiscriminatorR layers: "
+                             "disc/_discriminators.py:53,156-160",
+    "osp_smallcin_conv_wgrad": "autograd weight/bias gradients of the same narrow-channel layers",
+    "osp_logmel_energy": "CommonFeatureExtractor.get_mel mel_basis @ magnitudes + spectral_normalize_torch, and get_energy's torch.norm: "
+                         "dataset/feature_extractors/__init__.py:143-146,197-199; utils/audio.py:23-24",
+    "osp_cast_bf16": "no reference counterpart: f32 -> bf16 operand copy for the MFMA kernels (the reference's autocast does this implicitly)",
+    "osp_pack_bf16": "no reference counterpart: (Cout, Cin, K) -> tap-major bf16 weight layout for the conv-GEMM kernels",
+    "osp_wnorm_fwd": "torch.nn.utils.weight_norm forward w = g * v / ||v|| at every DiscriminatorP/R conv: disc/_discriminators.py:7,53-60,156-163",
+    "osp_wnorm_bwd": "autograd of weight_norm: gradients of weight_g / weight_v from the effective-weight gradient",
+    "osp_l1_sum": "FeatureMatchingLoss.forward torch.mean(torch.abs(rl - gl)): disc/loss.py:68-85",
+    "osp_l1_sign": "autograd of the same",
+    "osp_hinge_sum": "GeneratorLoss / DiscriminatorLoss hinge terms mean(clamp(1 -/+ d, min=0)): disc/loss.py:11-65",
+    "osp_hinge_grad": "autograd of the same",
     "osp_last_error": "error text of the last failing call on this thread",
     "osp_abi_version": "ABI version of this library",
 }
@@ -92,7 +111,7 @@ def main():
         if f != cur:
             out.append(f"/* ---- {f} ---- */\n")
             cur = f
-        out.append(f"/* replaces: {REPLACES.get(name, 'n/a (support routine)')} */\n{sig};\n\n")
+        out.append(f"/* replaces: {REPLACES[name]} */\n{sig};\n\n")
     out.append("#ifdef __cplusplus\n}\n#endif\n#endif /* OSP_H */\n")
     os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
     with open(os.path.join(ROOT, "include", "osp.h"), "w") as fh:
