@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-am-only", action="store_true", help="skip the acoustic-model-only (pre-training regime) step timing")
     ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the bounded CPU-baseline sample")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
@@ -242,6 +243,23 @@ def main():
             _disc._DISC_STREAMS = True
             iso = timer.summary()
             timer.events = timed_events
+    # secondary figure: the acoustic-model-only step of the first `pretraining_steps` steps (no adversarial
+    # losses, no discriminator phase: base_lightning_module.py:88,108-110,149-150); same batch, 3 warm-up + 10 timed steps
+    am_only = None
+    if not a.no_am_only:
+        keep, model.train_args.pretraining_steps = model.train_args.pretraining_steps, 1 << 60
+        n0 = a.warmup + a.steps + 3
+        for i in range(3):
+            model.training_step(batch, n0 + i)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(10):
+            model.training_step(batch, n0 + 3 + i)
+        sync()
+        am_dt = (time.perf_counter() - t1) / 10
+        model.train_args.pretraining_steps = keep
+        am_only = {"ms_per_step": am_dt * 1e3, "mel_frames_per_s": world * B * T_MEL / am_dt, "steps": 10,
+                   "note": "pre-training regime (global_step < pretraining_steps): acoustic-model losses only, per-rank wall time of rank 0"}
     ms_per_step = dt / a.steps * 1e3
     value = world * B * T_MEL / (dt / a.steps)
 
@@ -280,6 +298,7 @@ def main():
                           "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}", "schedule": "serial" if a.no_pipeline else "pipelined (pipeline_steps)",
                           "lengths": "ragged" if a.ragged else "fixed"},
                "per_gpu": value / world, "roofline": roof, "cpu_baseline": cpu,
+               "am_only_step": am_only,
                "synthesise": None if a.no_infer else synthesise_rtf(model, dev),
                "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")}}
         print(json.dumps(out))
