@@ -57,6 +57,8 @@ def build(force=False, verbose=True):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
         if verbose:
             print(f"[osp build] linked {LIB}")
+    from . import fastcall
+    fastcall.build(verbose=verbose)
     return LIB
 
 

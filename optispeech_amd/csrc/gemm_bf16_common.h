@@ -154,6 +154,98 @@ __device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, i
     return out;
 }
 
+// ---- row-domain epilogue for the kinds that READ a tensor of the output's shape (LeakyReLU' needs y, plus the optional
+// feature-matching gradient; GELU' needs u).  In the MFMA layout a lane owns one column, so those reads were 2-byte loads
+// (64 per operand and wave tile) touching 64-byte fragments of 4 lines each: on the DiscriminatorP dgrad launches they
+// doubled the kernel time (67 -> 139 us at 1024 -> 512, stride 3).  Here the f32 accumulators of one 32-row block go
+// through the wave-private LDS tile first; afterwards a lane owns 8 consecutive channels of a row, reads y / extra / u with
+// one 16-byte load each (8 full lines per wave instruction), applies the epilogue and stores 16 bytes.
+__device__ __forceinline__ void unpack8_bf16(const uint4 q, float (&f)[8]) {
+    f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+    f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+    f[4] = __uint_as_float(q.z << 16); f[5] = __uint_as_float(q.z & 0xffff0000u);
+    f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+__device__ __forceinline__ void ld8_f32(const void* p, int is_bf16, int64_t off, float (&f)[8]) {
+    if (is_bf16) unpack8_bf16(*reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + off), f);
+    else {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + off);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + off + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+}
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int EPI>
+__device__ __forceinline__ bool gemm_bf16_rows_ok(const GemmB& pp) {
+    if constexpr (EPI == BEPI_LRELU_BWD)
+        return pp.aux_in && aligned16(pp.aux_in) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0 &&
+               (!pp.res_any || (aligned16(pp.res_any) && (pp.ldr & 7) == 0));
+    if constexpr (EPI == BEPI_GELU_BWD || EPI == BEPI_RELU_BWD)
+        return pp.aux_in && aligned16(pp.aux_in) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0;
+    return false;
+}
+
+template <int EPI, int TM_, int TN_>
+__device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wm0, int wn0,
+                                                        int lane, int64_t bz, float* stage) {
+    constexpr int SPF = 32 * TN_ + 8;                          // f32 staging pitch: 4 rows apart = 32 banks apart
+    constexpr int CPR = 4 * TN_, RPI = 64 / CPR;               // 8-channel chunks per row, rows per wave instruction
+    __bf16* Cb = reinterpret_cast<__bf16*>(pp.C) + bz * pp.sCb;
+    const char* aux_in = reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4);
+    const int l31 = lane & 31, lh = lane >> 5, cc = lane % CPR, rr = lane / CPR;
+    const int Trows = pp.Trows, Wrows = pp.Wrows, Tc = pp.Tc, Wc = pp.Wc, c_step = pp.c_step, c_off = pp.c_off,
+              c_step_h = pp.c_step_h, c_off_h = pp.c_off_h, M = pp.M, N = pp.N;
+    const FastDiv fd_trows = pp.fd_trows, fd_wrows = pp.fd_wrows;
+    const int n = n0 + wn0 + cc * 8;
+    const bool n_ok = n < N;                                   // N % 8 == 0: a chunk is inside or outside as a whole
+    float bias[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias[k] = (pp.bias && n_ok) ? pp.bias[n + k] : 0.f;
+    const float slope = pp.slope;
+#pragma unroll
+    for (int i = 0; i < TM_; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN_; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SPF + 32 * j + l31] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int lrow = it * RPI + rr, m = m0 + wm0 + 32 * i + lrow;
+            if (m < M && n_ok) {
+                const int u = fd_div(m, fd_trows), t = m - u * Trows, th = fd_div(t, fd_wrows), tw = t - th * Wrows;
+                const int64_t crow = (int64_t)u * Tc + (int64_t)(th * c_step_h + c_off_h) * Wc + (int64_t)tw * c_step + c_off;
+                const float4 v0 = *reinterpret_cast<const float4*>(stage + lrow * SPF + cc * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(stage + lrow * SPF + cc * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, y[8], o[8];
+                ld8_f32(aux_in, pp.aux_bf16, crow * pp.ld_aux + n, y);
+                if constexpr (EPI == BEPI_LRELU_BWD) {
+                    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (pp.res_any) ld8_f32(pp.res_any, pp.res_bf16, crow * pp.ldr + n, e);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float s = v[k] + bias[k] + e[k]; o[k] = y[k] > 0.f ? s : s * slope; }
+                }
+                if constexpr (EPI == BEPI_RELU_BWD) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = y[k] > 0.f ? v[k] + bias[k] : 0.f;
+                }
+                if constexpr (EPI == BEPI_GELU_BWD) {
+                    const float rs = pp.rowscale ? pp.rowscale[bz * M + m] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_f(y[k]);
+                }
+                *reinterpret_cast<uint4*>(Cb + crow * pp.ldc + n) =
+                    make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Row geometry (two divisions per row, done with the multiply-high dividers) is computed once per accumulator row and
 // shared by the TN_ column tiles.  bf16 destinations are written as 4-byte pairs: lanes n / n+1 swap the values of two
 // consecutive rows (DPP), the even lane stores (row r, cols n..n+1), the odd lane (row r+1, cols n-1..n).
@@ -177,6 +269,13 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     // 128-byte lines instead of 64-byte fragments of 4 different lines.
     constexpr int SP = 32 * TN_ + 8;                                              // staging pitch (elements)
     const bool staged = stage != nullptr && pair_ok && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
+    // (callers reserve max(32 * TM_, 64) bf16 rows per wave: one 32-row block of f32)
+    if constexpr (EPI == BEPI_LRELU_BWD || EPI == BEPI_GELU_BWD || EPI == BEPI_RELU_BWD) {
+        if (staged && gemm_bf16_rows_ok<EPI>(pp)) {                                   // kernel-uniform
+            gemm_bf16_epilogue_rows<EPI, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
+            return;
+        }
+    }
     float bias[TN_], gam[TN_];
     int ncol[TN_];
 #pragma unroll

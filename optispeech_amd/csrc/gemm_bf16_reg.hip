@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pin) {
     }
 
     __syncthreads();                                  // operand tiles are dead: reuse them as the epilogue staging tiles
-    gemm_bf16_epilogue<TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * (32 * TN_ + 8));
+    gemm_bf16_epilogue<TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, smem + wave * (TM_ >= 2 ? 32 * TM_ : 64) * (32 * TN_ + 8));
 }
 
 

@@ -87,6 +87,7 @@ class OptiSpeech(nn.Module):
         #: Off by default: the benchmarked step does every forward the reference does.
         self.replay_disc_forward = os.environ.get("OSP_DISC_REPLAY", "0") == "1"
         self._dstream = None
+        self._disc_param_list = None
         self._reducers = None
         self.last_logs = {}
 
@@ -164,7 +165,7 @@ class OptiSpeech(nn.Module):
         pre = self.discriminator.prepare_disc_inputs(wav, wav_hat.detach()) if train_discriminator and self._real_pass is None else None
         (loss_g / scale).backward()
         red_g.start(opt_g.arena.grad)
-        for p in self.discriminator.parameters():
+        for p in self._disc_params():
             p.requires_grad_(True)
         # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce).
         # With ``pipeline_steps`` its loss / backward / optimizer step are issued from a second "calling" stream: the
@@ -193,6 +194,12 @@ class OptiSpeech(nn.Module):
                     sched_d.step()
                     self.global_step += 1
         self.last_logs = logs
+
+    def _disc_params(self):
+        """The discriminator's parameter list, walked once (toggled twice per step: toggle_optimizer of the reference)."""
+        if self._disc_param_list is None:
+            self._disc_param_list = list(self.discriminator.parameters())
+        return self._disc_param_list
 
     def _disc_phase_stream(self):
         """Context manager: make the discriminator-phase stream current, ordered after the calling stream's work so far."""
@@ -228,7 +235,7 @@ class OptiSpeech(nn.Module):
             self.join()                          # a pipelined discriminator update of the previous step must have landed
             if share_real:
                 self._real_pass = self.discriminator.forward_real(wav)
-            for p in self.discriminator.parameters():
+            for p in self._disc_params():
                 p.requires_grad_(False)
             gen_adv_loss, log_dict = self.discriminator.forward_gen(wav, wav_hat, real=self._real_pass)
             logs["total_loss/train_gen_adv_loss"] = gen_adv_loss.detach()

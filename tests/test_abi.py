@@ -40,3 +40,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
+
+
+def test_native_marshalling_module_covers_the_header():
+    """_ospfast (generated from include/osp.h) has one typed call per stream-taking entry point and rejects malformed calls
+    before anything is launched (no GPU needed: every call below fails in argument conversion)."""
+    import pytest
+    from optispeech_amd import _lib, fastcall
+    from optispeech_amd.build import build
+    build(verbose=False)
+    fast = _lib._load_fast()
+    assert fast is not None, "optispeech_amd/lib/_ospfast*.so not built"
+    ents = fastcall.entries()
+    assert fast.N_ENTRIES == len(ents) >= 40
+    for i, (name, _) in enumerate(ents):
+        assert fast.index(name) == i
+    assert fast.index("osp_no_such_entry") is None
+    i = fast.index("osp_sumsq")
+    with pytest.raises(TypeError, match="arguments given"):
+        fast.call(i, 0, 1, 2)
+    nargs = len(dict(ents)["osp_sumsq"])
+    with pytest.raises(TypeError, match="must match include/osp.h"):
+        fast.call(i, 0, *(["not a tensor"] * nargs))
+    import torch
+    with pytest.raises(RuntimeError, match="not on the GPU"):
+        fast.call(i, 0, *([torch.zeros(4)] * nargs))

@@ -20,6 +20,8 @@ def sig(name, args):
     ints = [a for a in args if isinstance(a, int) and not isinstance(a, bool)]
     if name == "osp_conv_gemm_bf16": return (name, "M", args[3], "Tr", args[4], "Cin", args[6], "taps", args[7], "N", args[17], "astep", args[8])
     if name == "osp_conv2d_gemm_bf16": return (name, "M", args[3], "Cin", args[8], "taps", args[9], "N", args[23])
+    if name == "osp_conv2d_dgrad_bf16":
+        return (name, "U", args[6], "H", args[7], "W", args[8], "Cin", args[11], "Cout", args[12], "K", (args[13], args[14]), "s", (args[15], args[16]))
     if name == "osp_conv_gemm_f32": return (name, "M", args[2], "Cin", args[4], "taps", args[5], "N", args[12], "epi", args[15])
     if name == "osp_conv_wgrad_bf16": return (name, "M", args[6], "N", args[9], "Cin", args[10], "taps", args[11])
     if name == "osp_conv2d_wgrad_bf16": return (name, "M", args[6], "N", args[11], "Cin", args[12], "taps", args[13])
@@ -51,6 +53,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("T
     tf = ""
     if k[0] == "osp_conv2d_gemm_bf16":
         tf = f"{2.0*k[2]*k[4]*k[6]*k[8]/(v[0]/v[1]*1e-3)/1e12:6.0f} TF"
+    if k[0] == "osp_conv2d_dgrad_bf16":
+        U, H, W, Cin, Cout, (KH, KW), (sh, sw) = k[2], k[4], k[6], k[8], k[10], k[12], k[14]
+        tf = f"{2.0*U*H*W*Cin*Cout*KH*KW/(sh*sw)/(v[0]/v[1]*1e-3)/1e12:6.0f} TF"
     if k[0] == "osp_conv2d_wgrad_bf16":
         tf = f"{2.0*k[2]*k[4]*k[6]*k[8]/(v[0]/v[1]*1e-3)/1e12:6.0f} TF"
     print(f"{v[0]/N:8.3f} ms/step  x{v[1]/N:5.1f}  avg {v[0]/v[1]*1e3:8.1f} us {tf}  {k}")
