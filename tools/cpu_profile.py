@@ -17,9 +17,11 @@ for i in range(5):
     m.training_step(batch, i)
 torch.cuda.synchronize()
 import cProfile, pstats
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread, so that the profiler sees it
 pr = cProfile.Profile(); pr.enable()
 N = 10
 for i in range(N):
     m.training_step(batch, 30 + i)
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumulative").print_stats(60)
