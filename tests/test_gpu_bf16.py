@@ -279,3 +279,60 @@ def test_conv_gemm_bf16_large_tiles_256_variant():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "test_conv_gemm_bf16_large_tiles and not variant",
                         os.path.join(root, "tests", "test_gpu_bf16.py")], env=env, cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("U,H,W,cin,cout,spec,extra", [
+    (3, 1, 57, 72, 128, (1, 5, 1, 3, 0, 2), "bf16"),      # N = 72: a partial 128-wide tile whose last 16-byte chunks are outside
+    (5, 1, 41, 128, 192, (1, 5, 1, 1, 0, 2), "f32"),
+    (2, 17, 40, 64, 64, (3, 5, 1, 2, 1, 2), None),          # 128x64 tile variant (N <= 64)
+    (2, 9, 33, 136, 64, (3, 3, 2, 2, 1, 1), "bf16"),
+    (1, 1, 700, 256, 256, (1, 5, 1, 3, 0, 2), "bf16")])     # >= 160 tiles: the LDS-DMA kernel
+def test_conv2d_dgrad_fused_lrelu_epilogue(U, H, W, cin, cout, spec, extra):
+    """osp_conv2d_dgrad_bf16 with the previous layer's LeakyReLU' and the feature-matching gradient fused into the epilogue
+    (row-domain epilogue: 16-byte reads of y / extra after the LDS transpose) vs torch: dx = (conv_transpose(dy) + e) * lrelu'(y)."""
+    from optispeech_amd import disc_ops as D
+    KH, KW, sh, sw, ph, pw = spec
+    slope = 0.1
+    Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+    w = bfr(rnd(cout, cin, KH, KW, seed=2, scale=1.0 / np.sqrt(cout * KH * KW)))
+    dy = bfr(rnd(U, cout, Ho, Wo, seed=4))
+    y = bfr(rnd(U, cin, H, W, seed=5))                                              # the layer input = previous LeakyReLU output
+    e = rnd(U, cin, H, W, seed=6) if extra else None
+    if extra == "bf16":
+        e = bfr(e)
+    opad = (H - ((Ho - 1) * sh - 2 * ph + KH), W - ((Wo - 1) * sw - 2 * pw + KW))
+    want = F.conv_transpose2d(dy, w, stride=(sh, sw), padding=(ph, pw), output_padding=opad)
+    if e is not None:
+        want = want + e
+    want = torch.where(y > 0, want, want * slope)
+    cl = lambda t, dt: t.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)           # noqa: E731
+    wt = D.transpose_weight2d(w.permute(0, 2, 3, 1).contiguous().to(DEV))
+    got = D.conv2d_dgrad(cl(dy, torch.bfloat16), wt, H, W, *spec, lrelu_y=cl(y, torch.bfloat16),
+                         extra=None if e is None else cl(e, torch.bfloat16 if extra == "bf16" else torch.float32),
+                         slope=slope, out_bf16=True)
+    assert got.dtype == torch.bfloat16 and got.shape == (U, H, W, cin)
+    assert relerr(got.float().permute(0, 3, 1, 2), want) < 1e-2
+
+
+@pytest.mark.parametrize("M,cin,n_out,aux_bf16", [(300, 64, 200, True), (4096, 256, 1024, True), (515, 128, 72, False)])
+def test_conv_gemm_bf16_gelu_relu_bwd_epilogues(M, cin, n_out, aux_bf16):
+    """du = rowscale * (dy W) * gelu'(u) and relu' gating with bf16 output: the row-domain epilogue vs torch, at tile-ragged
+    sizes (M % 32 != 0, N % 128 != 0) and with bf16 / f32 pre-activations."""
+    from optispeech_amd import kernels as K
+    dy = bfr(rnd(M, cin, seed=1))
+    w = bfr(rnd(n_out, cin, seed=2, scale=1.0 / np.sqrt(cin)))
+    u = rnd(M, n_out, seed=3)
+    if aux_bf16:
+        u = bfr(u)
+    rs = rnd(M, seed=4).abs() + 0.5
+    acc = dy @ w.t()
+    ud = u.clone().requires_grad_(True)
+    F.gelu(ud).sum().backward()
+    want_gelu = rs[:, None] * acc * ud.grad
+    want_relu = torch.where(u > 0, acc, torch.zeros_like(acc))
+    dyg, wg = dy.to(DEV).to(torch.bfloat16), w.to(DEV).to(torch.bfloat16)
+    ug = u.to(DEV).to(torch.bfloat16 if aux_bf16 else torch.float32)
+    got = K.conv_gemm_bf16(dyg, wg, n_out, M=M, Trows=M, Tin=M, cin=cin, epi=K.EPI_GELU_BWD, rowscale=rs.to(DEV), aux_in=ug, out_bf16=True)
+    assert relerr(got.float(), want_gelu) < 1e-2
+    got = K.conv_gemm_bf16(dyg, wg, n_out, M=M, Trows=M, Tin=M, cin=cin, epi=K.EPI_RELU_BWD, aux_in=ug, out_bf16=True)
+    assert relerr(got.float(), want_relu) < 1e-2
