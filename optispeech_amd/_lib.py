@@ -56,6 +56,11 @@ class _Lib:
         self._fcall, self._fidx = None, {}
         if os.environ.get("OSP_CTYPES_CALL", "0") != "1":
             fast = _load_fast()
+            if fast is not None and fast.HEADER_SHA1 != _header_sha1():
+                import warnings
+                warnings.warn("optispeech_amd/lib/_ospfast*.so was generated from a different include/osp.h: ignoring it "
+                              "(ctypes marshalling); rebuild with `python -m optispeech_amd.build`")
+                fast = None
             if fast is not None:
                 fast.set_guard(os.environ.get("OSP_FAST_CALL", "0") != "1")
                 self._fcall = fast.call
@@ -104,6 +109,12 @@ class _Lib:
 _GUARD = os.environ.get("OSP_FAST_CALL", "0") != "1"
 _raw_stream = torch._C._cuda_getCurrentRawStream
 _cur_device = torch._C._cuda_getDevice
+
+
+def _header_sha1():
+    import hashlib
+    path = os.path.join(os.path.dirname(_HERE), "include", "osp.h")
+    return hashlib.sha1(open(path, "rb").read()).hexdigest() if os.path.exists(path) else ""
 
 
 def _load_fast():
