@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
     const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
     const bool do_bias = (p.db != nullptr) && (blockIdx.y == 0);
+    const bool bias_wave = __builtin_amdgcn_readfirstlane((int)(do_bias && wn0 == 0)) != 0;
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
     const int64_t ldy = p.ldy, ldx = p.ldx;
     auto swz = [](int row) { return T == 128 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };
@@ -256,18 +257,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     // staging: wave w, instruction i covers slab rows RPI * (NI * w + i) + (lane / S); physical 16-byte slot = lane % S
     const int srow = lane / S, lslot = (lane % S) ^ swz(srow);
     // one (dY row, X row) pair of loads; `i` = instruction index 0..NI-1
+    const unsigned short* dY_lane = dY + n0 + lslot * 8;
+    const unsigned short* X_lane = X + c0 + lslot * 8;
     auto issue_pair = [&](int mk, int buf, int i) {
         unsigned short* ys = smem + buf * (2 * SK * T);
         unsigned short* xs = ys + SK * T;
         const int row0 = RPI * (NI * wave + i), m = mk + row0 + srow;
         const bool mv = m < mend;
-        const unsigned short* src = mv ? dY + (int64_t)m * ldy + n0 + lslot * 8 : zero;
+        // row indices stay 32-bit (a tensor has < 2^31 rows); one 64-bit multiply-add per pointer, selects instead of branches
+        const unsigned short* ysel = mv ? dY_lane : zero;
+        const unsigned short* src = ysel + (int64_t)(mv ? m : 0) * ldy;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, 0, 0);
         const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
         const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
         const bool xv = mv && tt >= 0 && tt < p.Tin && hh >= 0 && hh < p.Hin;
-        const unsigned short* xsrc = xv ? X + (((int64_t)u * p.Hin + hh) * p.Tin + tt) * ldx + c0 + lslot * 8 : zero;
+        const int xrow = xv ? (u * p.Hin + hh) * p.Tin + tt : 0;
+        const unsigned short* xsel = xv ? X_lane : zero;
+        const unsigned short* xsrc = xsel + (int64_t)xrow * ldx;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
                                          (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, 0, 0);
     };
@@ -320,11 +327,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
         const int col = col0 + 16 * g16 + 4 * (r16 & 3);                          // first of this lane's 4 source channels
         const int pslot = (col >> 3) ^ swz(r16 >> 2);
         const unsigned short* a0 = base + (16 * ks + 8 * kg + (r16 >> 2)) * T + pslot * 8 + (col & 7);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * T));
+        // Issued through inline asm: for the builtin the compiler cannot tell that the LDS-DMA loads in flight (next slab,
+        // other buffer) do not alias these reads and put `s_waitcnt vmcnt(0)` in front of every k-step's reads, i.e. each
+        // k-step waited for the global loads issued one k-step earlier (the slab pipeline was serialised: 350 TFLOP/s on
+        // the 1024x1024x5 layer vs 680 for the forward kernel).  The price: the compiler does not count these reads in
+        // lgkmcnt either, so mma() waits for them explicitly (frag_wait) before the MFMAs consume the registers.
+        const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)a0;
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * T * 2) : "memory");
         union { struct { s16x4 l, h; } s; bf16x8 v; } u;
         u.s.l = lo; u.s.h = hi;
         return u.v;
+    };
+    auto frag_wait = [](bf16x8 (&a)[TI], bf16x8 (&b)[TI]) {
+        if constexpr (TI == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]) : : "memory");
     };
     bf16x8 ones;
 #pragma unroll
@@ -341,11 +361,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
 #pragma unroll
             for (int jj = 0; jj < TI; ++jj) b[jj] = frag(xs, wn0 + 32 * jj, ks);
             if (mk_next >= 0 && ks < NI) issue_pair(mk_next, buf ^ 1, ks);
+            frag_wait(a, b);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int jj = 0; jj < TI; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
-            if (do_bias && wn0 == 0) {                                            // block-uniform x wave-uniform
+            if (bias_wave) {                                                      // scalar condition: no exec masking around the MFMAs
 #pragma unroll
                 for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
             }
