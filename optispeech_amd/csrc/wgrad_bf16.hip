@@ -16,6 +16,7 @@ struct WgradB {
     FastDiv fd_trows, fd_wrows;
     const float *arow, *oscale; float* dW; int64_t ldw; float* db; int chunk, splits;
     int64_t sYb, sXb, sWb, sDb;
+    unsigned y_bytes, x_bytes;                        // extent of one batch slice of dY / X (buffer-resource variant)
 };
 
 __device__ __forceinline__ float4 ld4_any(const void* p, int is_bf16, int64_t off, int lim, bool vec) {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradB p) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // F32 = true: f32 operands in HBM (the generator's activations); the slab goes global -> registers -> bf16 -> LDS (same
 // LDS image as the DMA path, so the transposed reads are shared), with the optional per-frame scale `arow` applied to dY.
-template <int T, bool F32 = false>
+template <int T, bool F32 = false, bool BUF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     constexpr int SK = 64;                                   // frames per slab
     constexpr int S = T / 8, RPI = 64 / S, NI = SK / RPI / 4, TI = T / 64;   // slots/row, rows/instruction, instr/wave/operand
@@ -257,6 +258,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     // staging: wave w, instruction i covers slab rows RPI * (NI * w + i) + (lane / S); physical 16-byte slot = lane % S
     const int srow = lane / S, lslot = (lane % S) ^ swz(srow);
     // one (dY row, X row) pair of loads; `i` = instruction index 0..NI-1
+    const int ldy32 = (int)ldy, ldx32 = (int)ldx;
+    const unsigned ycol2 = (unsigned)(n0 + lslot * 8) * 2u, xcol2 = (unsigned)(c0 + lslot * 8) * 2u;
+    __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dY), 0, BUF ? (int)p.y_bytes : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, BUF ? (int)p.x_bytes : 0, 0x00020000);
     const unsigned short* dY_lane = dY + n0 + lslot * 8;
     const unsigned short* X_lane = X + c0 + lslot * 8;
     auto issue_pair = [&](int mk, int buf, int i) {
@@ -264,6 +269,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
         unsigned short* xs = ys + SK * T;
         const int row0 = RPI * (NI * wave + i), m = mk + row0 + srow;
         const bool mv = m < mend;
+        if constexpr (BUF) {
+            // buffer-resource form: 32-bit byte offsets against an SGPR descriptor, out-of-range offsets read as zero (no
+            // zero page, no 64-bit pointer arithmetic or pointer selects: the address VALU work was what bound this loop)
+            const unsigned yo = mv ? (unsigned)(m * ldy32) * 2u + ycol2 : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, yo, 0, 0, 0);
+            const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+            const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+            const bool xv = mv && (unsigned)tt < (unsigned)p.Tin && (unsigned)hh < (unsigned)p.Hin;
+            const unsigned xo = xv ? (unsigned)(((u * p.Hin + hh) * p.Tin + tt) * ldx32) * 2u + xcol2 : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, xo, 0, 0, 0);
+            return;
+        }
         // row indices stay 32-bit (a tensor has < 2^31 rows); one 64-bit multiply-add per pointer, selects instead of branches
         const unsigned short* ysel = mv ? dY_lane : zero;
         const unsigned short* src = ysel + (int64_t)(mv ? m : 0) * ldy;
@@ -436,6 +453,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     p.M = (int)M; p.Trows = (int)Trows; p.Tin = (int)Tin; p.N = (int)N; p.Cin = (int)Cin; p.taps = (int)taps;
     p.pad = (int)pad; p.x_step = (int)x_step; p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db;
     p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb;
+    p.y_bytes = 0; p.x_bytes = 0;
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.x_step_h = (int)d2[3]; p.pad_h = (int)d2[4];
     p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
@@ -464,8 +482,20 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         sp = cdiv(M, ch);
         p.chunk = (int)ch; p.splits = (int)sp;
         const dim3 g((unsigned)(N / T_), (unsigned)(taps * (Cin / T_)), (unsigned)(sp * batch));
-        if (T_ == 128) hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<64>, g, dim3(256), 0, stream, p);
+        // buffer-resource loads when one batch slice of each operand is addressable with 31-bit byte offsets
+        const int64_t rows_x = (M / Trows) * (int64_t)p.Hin * Tin;
+        const int64_t yb = ((M - 1) * ldy + N) * 2, xb = ((rows_x - 1) * ldx + Cin) * 2;
+        static int use_buf = -1;
+        if (use_buf < 0) { const char* e = getenv("OSP_WGRAD_BUF"); use_buf = (e && atoi(e) == 0) ? 0 : 1; }
+        const bool buf = use_buf && yb > 0 && xb > 0 && yb < (int64_t)0x7fffff00 && xb < (int64_t)0x7fffff00;
+        p.y_bytes = buf ? (unsigned)yb : 0; p.x_bytes = buf ? (unsigned)xb : 0;
+        if (T_ == 128) {
+            if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<128, false, true>), g, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
+        } else {
+            if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<64, false, true>), g, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<64>, g, dim3(256), 0, stream, p);
+        }
     }
     else if (use_tr && !y_bf16 && !x_bf16 && N % 64 == 0 && Cin % 64 == 0 && (ldy % 4 == 0) && (ldx % 4 == 0) &&
              ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0 && (sYb % 4 == 0) && (sXb % 4 == 0)) {
