@@ -295,7 +295,7 @@ def main():
                                 "note": "same kernel, 3 extra untimed steps with the launches serialised on one stream"}
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read inside the timed
         # run); the committed summary of that pass is reported here when it matches the measured configuration
-        pmc = os.path.join(ROOT, "profiles", "r01g_pmc_glds.json")
+        pmc = os.path.join(ROOT, "profiles", "r01h_pmc_glds.json")
         if a.precision == "bf16" and not a.ragged and os.path.exists(pmc):
             with open(pmc) as fh:
                 pj = json.load(fh)
