@@ -39,6 +39,10 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._pending = []
+        # gloo on device tensors (the single-GPU test aid, OSP_DP_BACKEND=gloo) stages through the host from a worker thread
+        # that synchronises streams on its own; with the step's side streams in flight that took seconds per collective on
+        # the shared-GPU box (8-10 s/step vs 0.1 s), so the device is drained first.  RCCL orders on-stream: no host sync.
+        self._drain_first = self.world > 1 and dist.get_backend(group) == "gloo"
 
     @property
     def active(self):
@@ -48,6 +52,8 @@ class GradReducer:
         """Launch the all-reduce of every bucket; returns immediately (work proceeds on RCCL's stream)."""
         if not self.active:
             return
+        if self._drain_first and flat_grad.is_cuda:
+            torch.cuda.synchronize()
         n = flat_grad.numel()
         for o in range(0, n, self.bucket_elems):
             w = dist.all_reduce(flat_grad[o:min(n, o + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group,
