@@ -31,6 +31,13 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    # a library newer than every source needs nothing (the object directory does not travel to the GPU box; the .so does)
+    if not force and os.path.exists(LIB):
+        t = os.path.getmtime(LIB)
+        if all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in _sources()) and all(os.path.getmtime(h) <= t for h in hdrs):
+            from . import fastcall
+            fastcall.build(verbose=verbose)
+            return LIB
     jobs = []
     for f in _sources():
         src = os.path.join(CSRC, f)
