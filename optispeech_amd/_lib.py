@@ -48,6 +48,10 @@ class _Lib:
         if not os.path.exists(LIB_PATH):
             raise OspError(f"{LIB_PATH} not found: build it with `python -m optispeech_amd.build` "
                            "(the HIP extension is mandatory; there is no CPU/eager fallback)")
+        from . import build as _build
+        if os.path.isdir(_build.CSRC) and _build.library_hash(LIB_PATH) != _build.source_hash():
+            raise OspError(f"{LIB_PATH} was not built from the sources in {_build.CSRC} (content hash mismatch): rebuild it "
+                           "with `python -m optispeech_amd.build`")
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.cdll.osp_last_error.restype = ctypes.c_char_p
         self._fn = {}
@@ -80,8 +84,18 @@ class _Lib:
         # hot path (~850 calls per training step): keep the per-argument work minimal.  ctypes converts ints / floats /
         # None through the header-derived argtypes; tensors are passed as their device address.
         idx = self._fidx.get(name)
+        dev = _cur_device()
+        if _GUARD:
+            # kernels go to the current stream of torch's CURRENT device: a tensor living on another GPU would be addressed
+            # from the wrong device's stream (fault, or silent peer access unordered with that GPU's work)
+            for a in args:
+                if isinstance(a, torch.Tensor):
+                    if a.is_cuda and a.device.index != dev:
+                        raise OspError(f"{name}: tensor on cuda:{a.device.index} but the current device is cuda:{dev}; "
+                                       "call torch.cuda.set_device() (or wrap the call in torch.cuda.device(...))")
+                    break
         if idx is not None:
-            rc = self._fcall(idx, _raw_stream(_cur_device()), *args)
+            rc = self._fcall(idx, _raw_stream(dev), *args)
             if rc != 0:
                 raise OspError(f"{name} failed ({rc}): {self.cdll.osp_last_error().decode()}")
             return
@@ -90,7 +104,7 @@ class _Lib:
         cargs = [a.data_ptr() if isinstance(a, T) else a for a in args]
         if _GUARD and any(isinstance(a, T) and not a.is_cuda for a in args):
             raise OspError(f"{name}: tensor argument is not on the GPU")
-        cargs.append(_raw_stream(_cur_device()))      # torch's current HIP stream (raw handle)
+        cargs.append(_raw_stream(dev))      # torch's current HIP stream (raw handle)
         try:
             rc = f(*cargs)
         except ctypes.ArgumentError as e:

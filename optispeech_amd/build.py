@@ -20,6 +20,28 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+def source_hash():
+    """sha1 over the names and contents of csrc/*.{hip,cpp,h} and the compile flags: what the library was built FROM.
+    It is compiled into the library (``osp_source_hash()``, csrc/api.cpp) so that a shipped, git-ignored .so can be checked
+    against the sources next to it by content -- mtimes do not survive a checkout or the copy to the GPU box."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
+def library_hash(path=None):
+    """The source hash embedded in a built library (read from the file: no dlopen, so a rebuild in this process is safe)."""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    data = open(path, "rb").read()
+    i = data.find(b"OSP_SOURCE_HASH=")
+    return data[i + 16:i + 56].decode() if i >= 0 else None
+
+
 def _stale(obj, src, hdrs):
     if not os.path.exists(obj):
         return True
@@ -31,19 +53,21 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    # a library newer than every source needs nothing (the object directory does not travel to the GPU box; the .so does)
-    if not force and os.path.exists(LIB):
-        t = os.path.getmtime(LIB)
-        if all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in _sources()) and all(os.path.getmtime(h) <= t for h in hdrs):
-            from . import fastcall
-            fastcall.build(verbose=verbose)
-            return LIB
+    # a library built from exactly these sources needs nothing (the object directory does not travel to the GPU box; the
+    # .so does): compared by CONTENT hash, not by mtime
+    want = source_hash()
+    if not force and library_hash() == want:
+        from . import fastcall
+        fastcall.build(verbose=verbose)
+        return LIB
     jobs = []
     for f in _sources():
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJDIR, f.rsplit(".", 1)[0] + ".o")
-        if force or _stale(obj, src, hdrs):
+        if force or f == "api.cpp" or _stale(obj, src, hdrs):          # api.cpp carries the hash: always recompiled
             cmd = [HIPCC] + FLAGS + (["-x", "hip"] if f.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            if f == "api.cpp":
+                cmd.insert(-4, f'-DOSP_SOURCE_HASH="{want}"')
             jobs.append((f, cmd))
     def run(job):
         f, cmd = job
@@ -60,10 +84,11 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError("hipcc failed")
     objs = [os.path.join(OBJDIR, f.rsplit(".", 1)[0] + ".o") for f in _sources()]
-    if force or jobs or not os.path.exists(LIB):
+    if True:
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
         if verbose:
             print(f"[osp build] linked {LIB}")
+        assert library_hash() == want, "the linked library does not carry the source hash"
     from . import fastcall
     fastcall.build(verbose=verbose)
     return LIB

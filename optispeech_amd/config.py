@@ -55,6 +55,8 @@ class ModelConfig:
     lambda_mrd: float = 1.0                               # discriminator/vocos_disc.yaml
     lambda_mel: float = 45.0
     lambda_mr_stft: float = 2.5
+    num_speakers: int = 1                                 # data_args.num_speakers (> 1 enables sid_embed, generator/__init__.py:62-63)
+    num_languages: int = 1                                # text_processor.num_languages (> 1 enables lid_embed, :64-65)
     fe: FeatureExtractorArgs = field(default_factory=FeatureExtractorArgs)
 
     def no_dropout(self):
@@ -104,7 +106,8 @@ def make_generator(c: ModelConfig):
         decoder=_backbones(c)[1],
         vocoder=partial(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers,
                         drop_path=c.voc_drop_path),
-        loss_coeffs=loss_coeffs, feature_extractor=c.fe, num_speakers=1, num_languages=1, data_statistics=None)
+        loss_coeffs=loss_coeffs, feature_extractor=c.fe, num_speakers=c.num_speakers, num_languages=c.num_languages,
+        data_statistics=None)
 
 
 def make_optispeech(c: ModelConfig = None, batch_size=32, pretraining_steps=1000, optimizer=None, scheduler=None):
@@ -115,7 +118,9 @@ def make_optispeech(c: ModelConfig = None, batch_size=32, pretraining_steps=1000
     from .model.modules import (ConvNeXtBackbone, DurationPredictor, EnergyPredictor, PitchPredictor, TextEmbedding)
     from .model.optispeech import OptiSpeech, default_args
     from .model.vocoder import WaveNeXt
+    from . import rng
     c = c or ModelConfig()
+    rng.reset_streams()                   # dropout-site stream ids depend on the construction order inside this model only
 
     def pred(cls, spec, **kw):
         return partial(cls, num_layers=spec[0], intermediate_dim=spec[1], kernel_size=spec[2], dropout=spec[3],
@@ -140,6 +145,11 @@ def make_optispeech(c: ModelConfig = None, batch_size=32, pretraining_steps=1000
                                                                    lambda_mr_stft=c.lambda_mr_stft))
     train_args, data_args, inference_args = default_args(batch_size, c.fe)
     train_args.pretraining_steps = pretraining_steps
+    data_args.num_speakers = c.num_speakers
+    if c.num_languages > 1:
+        data_args.text_processor.num_languages = c.num_languages
+        data_args.text_processor.is_multi_language = True
+        data_args.text_processor.languages = [f"lang{i}" for i in range(c.num_languages)]
     return OptiSpeech(dim=c.dim, generator=gen, vocoder=voc, discriminator=disc, train_args=train_args,
                       data_args=data_args, inference_args=inference_args, optimizer=optimizer, scheduler=scheduler)
 

@@ -11,7 +11,8 @@
 
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict__ S, float* __restrict__ Pd,
                                                                const int64_t* __restrict__ klen, int H, int T1, int T2, int64_t rows,
-                                                               float scale, float drop_p, uint64_t seed, uint32_t stream_id) {
+                                                               float scale, float drop_p, uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id) {
+    if (seed_dev) seed += (uint64_t)*seed_dev;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict
 }
 
 __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dPd, int T2, int64_t rows,
-                                                               float scale, float drop_p, uint64_t seed, uint32_t stream_id) {
+                                                               float scale, float drop_p, uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id) {
+    if (seed_dev) seed += (uint64_t)*seed_dev;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -79,21 +81,21 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
 
 // S: (Z * T1, T2) f32, Z = B * H batch-major; klen: (B) int64 valid key counts.  Pd may be null (no dropout copy).
 extern "C" int osp_attn_softmax_fwd(float* S, float* Pd, const int64_t* klen, int64_t B, int64_t H, int64_t T1, int64_t T2, float scale,
-                                    float drop_p, int64_t seed, int64_t stream_id, hipStream_t stream) {
+                                    float drop_p, int64_t seed, const int64_t* seed_dev, int64_t stream_id, hipStream_t stream) {
     OSP_CHECK_ARG(S && klen && B > 0 && H > 0 && T1 > 0 && T2 > 0 && T2 <= 64 * ATT_MAXC, "bad attention shape (T2 <= 1024)");
     OSP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || Pd), "dropout needs a second output buffer");
     const int64_t rows = B * H * T1;
     hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, S, Pd, klen, (int)H, (int)T1, (int)T2,
-                       rows, scale, drop_p, (uint64_t)seed, (uint32_t)stream_id);
+                       rows, scale, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
 
 extern "C" int osp_attn_softmax_bwd(const float* P, float* dPd, int64_t rows, int64_t T2, float scale, float drop_p, int64_t seed,
-                                    int64_t stream_id, hipStream_t stream) {
+                                    const int64_t* seed_dev, int64_t stream_id, hipStream_t stream) {
     OSP_CHECK_ARG(P && dPd && rows > 0 && T2 > 0 && T2 <= 64 * ATT_MAXC, "bad attention shape (T2 <= 1024)");
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, P, dPd, (int)T2, rows, scale, drop_p,
-                       (uint64_t)seed, (uint32_t)stream_id);
+                       (uint64_t)seed, seed_dev, (uint32_t)stream_id);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

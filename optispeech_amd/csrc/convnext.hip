@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ b, float eps, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             const float* __restrict__ rowmask, float drop_p,
-                                                            uint64_t seed, uint32_t stream_id, int64_t rows, int C) {
+                                                            uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id, int64_t rows, int C) {
+    if (seed_dev) seed += (uint64_t)*seed_dev;      // per-step seed kept in device memory (hipGraph replay)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invC = 1.0f / (float)C;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -171,14 +172,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 extern "C" int osp_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean,
-                                 float* rstd, const float* rowmask, float drop_p, int64_t seed, int64_t stream_id,
+                                 float* rstd, const float* rowmask, float drop_p, int64_t seed, const int64_t* seed_dev, int64_t stream_id,
                                  int64_t rows, int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(x && w && b && y, "null operand");
     OSP_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
     OSP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "dropout rate");
     dim3 grid((unsigned)(cdiv(rows, 4) < 4096 ? cdiv(rows, 4) : 4096));
     const int nch = (int)cdiv(C, 256);
-#define L(N) hipLaunchKernelGGL((layernorm_fwd_kernel<N>), grid, dim3(256), 0, stream, x, w, b, eps, y, mean, rstd, rowmask, drop_p, (uint64_t)seed, (uint32_t)stream_id, rows, (int)C)
+#define L(N) hipLaunchKernelGGL((layernorm_fwd_kernel<N>), grid, dim3(256), 0, stream, x, w, b, eps, y, mean, rstd, rowmask, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, rows, (int)C)
     if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
 #undef L
     OSP_LAUNCH_CHECK();
@@ -194,10 +195,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* __restrict__ relu_src,
                                                             const float* __restrict__ rowmask, float drop_p, uint64_t seed,
-                                                            uint32_t stream_id, float* __restrict__ dx,
+                                                            const int64_t* __restrict__ seed_dev, uint32_t stream_id, float* __restrict__ dx,
                                                             float* __restrict__ dlnw, float* __restrict__ dlnb,
                                                             int64_t rows, int C) {
     __shared__ float red[2][4][256 * NCH];   // [w|b][wave][channel-in-lane-order]
+    if (seed_dev) seed += (uint64_t)*seed_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invC = 1.0f / (float)C;
     float4 aw[NCH], ab[NCH], gw[NCH];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 extern "C" int osp_layernorm_bwd(const float* dy, const float* xin, const float* mean, const float* rstd,
                                  const float* w, const float* relu_src, const float* rowmask, float drop_p,
-                                 int64_t seed, int64_t stream_id, float* dx, float* dlnw, float* dlnb, int64_t rows,
+                                 int64_t seed, const int64_t* seed_dev, int64_t stream_id, float* dx, float* dlnw, float* dlnb, int64_t rows,
                                  int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(dy && xin && rstd && w && dx, "null operand");
     OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr), "dlnw/dlnb come together");
@@ -279,7 +281,7 @@ extern "C" int osp_layernorm_bwd(const float* dy, const float* xin, const float*
     const int64_t blocks = cdiv(rows, 4 * FRAMES);   // FRAMES rows per wave => few atomics
     dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024));
     const int nch = (int)cdiv(C, 256);
-#define L(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), grid, dim3(256), 0, stream, dy, xin, mean, rstd, w, relu_src, rowmask, drop_p, (uint64_t)seed, (uint32_t)stream_id, dx, dlnw, dlnb, rows, (int)C)
+#define L(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), grid, dim3(256), 0, stream, dy, xin, mean, rstd, w, relu_src, rowmask, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, dx, dlnw, dlnb, rows, (int)C)
     if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
 #undef L
     OSP_LAUNCH_CHECK();

@@ -8,8 +8,9 @@
 
 __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
                                                              const float* __restrict__ pos, const float* __restrict__ scale,
-                                                             float sqrt_dim, float drop_p, uint64_t seed, uint32_t stream_id,
+                                                             float sqrt_dim, float drop_p, uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id,
                                                              float* __restrict__ out, int64_t rows, int T, int C) {
+    if (seed_dev) seed += (uint64_t)*seed_dev;
     const int lane = threadIdx.x & 63;
     const float sc = scale[0];
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
@@ -31,23 +32,24 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const int64_t* __re
     }
 }
 extern "C" int osp_text_embed_fwd(const int64_t* tok, const float* E, const float* pos, const float* scale, float sqrt_dim,
-                                  float drop_p, int64_t seed, int64_t stream_id, float* out, int64_t B, int64_t T,
+                                  float drop_p, int64_t seed, const int64_t* seed_dev, int64_t stream_id, float* out, int64_t B, int64_t T,
                                   int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(tok && E && pos && scale && out, "null operand");
     OSP_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
     const int64_t rows = B * T;
     hipLaunchKernelGGL(text_embed_fwd_kernel, dim3((unsigned)(cdiv(rows, 4) < 2048 ? cdiv(rows, 4) : 2048)), dim3(256), 0, stream,
-                       tok, E, pos, scale, sqrt_dim, drop_p, (uint64_t)seed, (uint32_t)stream_id, out, rows, (int)T, (int)C);
+                       tok, E, pos, scale, sqrt_dim, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, out, rows, (int)T, (int)C);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
 
 __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dy, const int64_t* __restrict__ tok,
                                                              const float* __restrict__ pos, float sqrt_dim, float drop_p,
-                                                             uint64_t seed, uint32_t stream_id, int64_t padding_idx,
+                                                             uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id, int64_t padding_idx,
                                                              float* __restrict__ dE, float* __restrict__ dscale, int64_t rows,
                                                              int T, int C) {
     __shared__ float scratch[16];
+    if (seed_dev) seed += (uint64_t)*seed_dev;
     const int lane = threadIdx.x & 63;
     float ds = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
@@ -74,13 +76,13 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
     if (dscale && threadIdx.x == 0) atomicAdd(dscale, ds);
 }
 extern "C" int osp_text_embed_bwd(const float* dy, const int64_t* tok, const float* pos, float sqrt_dim, float drop_p,
-                                  int64_t seed, int64_t stream_id, int64_t padding_idx, float* dE, float* dscale,
+                                  int64_t seed, const int64_t* seed_dev, int64_t stream_id, int64_t padding_idx, float* dE, float* dscale,
                                   int64_t B, int64_t T, int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(dy && tok && pos, "null operand");
     OSP_CHECK_ARG(C % 4 == 0, "C must be a multiple of 4");
     const int64_t rows = B * T;
     hipLaunchKernelGGL(text_embed_bwd_kernel, dim3((unsigned)(cdiv(rows, 4) < 256 ? cdiv(rows, 4) : 256)), dim3(256), 0, stream,
-                       dy, tok, pos, sqrt_dim, drop_p, (uint64_t)seed, (uint32_t)stream_id, padding_idx, dE, dscale, rows,
+                       dy, tok, pos, sqrt_dim, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, padding_idx, dE, dscale, rows,
                        (int)T, (int)C);
     OSP_LAUNCH_CHECK();
     return OSP_OK;

@@ -33,7 +33,12 @@ struct AdamArgs { float lr, beta1, beta2, eps, wd, bc1, bc2, max_norm, gscale; }
 
 __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, int64_t n, const double* __restrict__ sumsq,
-                                                         const float* __restrict__ lr_dev, AdamArgs a) {
+                                                         const float* __restrict__ lr_dev, const int64_t* __restrict__ step_dev, AdamArgs a) {
+    if (step_dev) {                                  // step counter kept in device memory (hipGraph replay)
+        const double st = (double)*step_dev;
+        a.bc1 = (float)(1.0 - pow((double)a.beta1, st));
+        a.bc2 = (float)(1.0 - pow((double)a.beta2, st));
+    }
     // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
     float coef = a.gscale;
     if (sumsq && a.max_norm > 0.f) {
@@ -63,19 +68,19 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         upd(p[i], g[i], m[i], v[i]);
 }
-// step = 1-based Adam step.  sumsq: device f64 sum of squares of the (unscaled) gradient or null (no clipping);
+// step = 1-based Adam step (read from *step_dev when given; lr from *lr_dev when given).  sumsq: device f64 sum of squares of the (unscaled) gradient or null (no clipping);
 // gscale: factor applied to every gradient first (1/world_size for data parallel averaging, 1/accumulation).
 extern "C" int osp_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
-                              const float* lr_dev, float lr, float beta1, float beta2, float eps, float wd,
+                              const float* lr_dev, const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float wd,
                               int64_t step, float max_norm, float gscale, hipStream_t stream) {
-    OSP_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "bad args");
+    OSP_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_dev), "bad args");
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.max_norm = max_norm; a.gscale = gscale;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
     const int64_t blocks = cdiv(n, 256 * 8);
     hipLaunchKernelGGL(adamw_clip_kernel, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, stream, p, g, m,
-                       v, n, sumsq, lr_dev, a);
+                       v, n, sumsq, lr_dev, step_dev, a);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

@@ -22,11 +22,11 @@ def init_from_env(backend=None):
     world, rank, local = env_world()
     if os.environ.get("OSP_DP_SINGLE_DEVICE") == "1":        # test aid: all ranks on GPU 0 (gloo moves the buckets via the host)
         local = 0
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)                # every backend: the kernels launch on the CURRENT device's stream
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("OSP_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 
@@ -64,6 +64,15 @@ class GradReducer:
         for w in self._pending:
             w.wait()
         self._pending.clear()
+
+    def broadcast_from_rank0(self, tensors):
+        """Make every replica start from rank 0's values (parameter arenas, buffers)."""
+        if not self.active:
+            return
+        if self._drain_first and any(t.is_cuda for t in tensors):
+            torch.cuda.synchronize()
+        for t in tensors:
+            dist.broadcast(t, src=0, group=self.group)
 
     def mean_scalars(self, t):
         """In-place mean over ranks of a small packed tensor of log scalars (replaces ~20 sync_dist all-reduces)."""

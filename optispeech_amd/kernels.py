@@ -11,6 +11,14 @@ from ._lib import call
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_SCALE_RES_MASK, EPI_GELU_BWD, EPI_RELU_BWD, EPI_AXMY, EPI_MASK = range(8)
 
 
+def _seed(seed):
+    """(host seed, device seed tensor or None): rng.seed() is an int in eager mode and an rng.DeviceSeed while a step is being
+    captured into / replayed from a hipGraph (the per-step seed then lives in device memory, csrc: ``seed_dev``)."""
+    if isinstance(seed, int):
+        return seed, None
+    return 0, seed.tensor
+
+
 def _f32(*ts):
     for t in ts:
         if t is not None:
@@ -112,7 +120,8 @@ def layernorm_fwd(x, w, b, eps, *, save=True, rowmask=None, drop_p=0.0, seed=0, 
     y = torch.empty_like(x)
     mean = torch.empty((rows,), device=x.device, dtype=torch.float32) if save else None
     rstd = torch.empty((rows,), device=x.device, dtype=torch.float32) if save else None
-    call("osp_layernorm_fwd", x, w, b, float(eps), y, mean, rstd, rowmask, float(drop_p), int(seed), int(stream_id),
+    sh, sd = _seed(seed)
+    call("osp_layernorm_fwd", x, w, b, float(eps), y, mean, rstd, rowmask, float(drop_p), sh, sd, int(stream_id),
          rows, C)
     return y, mean, rstd
 
@@ -124,7 +133,8 @@ def layernorm_bwd(dy, xin, mean, rstd, w, dlnw, dlnb, *, relu_src=None, rowmask=
     rows = dy.numel() // C
     assert dy.is_contiguous() and xin.is_contiguous()
     dx = torch.empty_like(dy)
-    call("osp_layernorm_bwd", dy, xin, mean, rstd, w, relu_src, rowmask, float(drop_p), int(seed), int(stream_id),
+    sh, sd = _seed(seed)
+    call("osp_layernorm_bwd", dy, xin, mean, rstd, w, relu_src, rowmask, float(drop_p), sh, sd, int(stream_id),
          dx, dlnw, dlnb, rows, C)
     return dx
 
@@ -284,13 +294,15 @@ def text_embed_fwd(tok, E, pos, scale, drop_p=0.0, seed=0, stream_id=0):
     C = E.shape[1]
     assert tok.dtype == torch.int64 and tok.is_contiguous() and pos.shape[0] >= T and pos.shape[1] == C
     out = torch.empty((B, T, C), device=E.device, dtype=torch.float32)
-    call("osp_text_embed_fwd", tok, E, pos, scale, float(C) ** 0.5, float(drop_p), int(seed), int(stream_id), out, B, T, C)
+    sh, sd = _seed(seed)
+    call("osp_text_embed_fwd", tok, E, pos, scale, float(C) ** 0.5, float(drop_p), sh, sd, int(stream_id), out, B, T, C)
     return out
 
 
 def text_embed_bwd(dy, tok, pos, dE, dscale, padding_idx=0, drop_p=0.0, seed=0, stream_id=0):
     B, T, C = dy.shape
-    call("osp_text_embed_bwd", dy.contiguous(), tok, pos, float(C) ** 0.5, float(drop_p), int(seed), int(stream_id),
+    sh, sd = _seed(seed)
+    call("osp_text_embed_bwd", dy.contiguous(), tok, pos, float(C) ** 0.5, float(drop_p), sh, sd, int(stream_id),
          int(padding_idx), dE, dscale, B, T, C)
 
 
@@ -427,12 +439,14 @@ def l1_sign(a, b, scale, gscale):
 def attn_softmax_fwd(S, klen, B, H, T1, T2, scale, drop_p=0.0, seed=0, stream_id=0):
     """in place: S (B*H, T1, T2) scores -> probabilities over the valid keys; returns (P, Pd) with Pd = dropout(P) (or P)."""
     Pd = torch.empty_like(S) if drop_p > 0.0 else None
-    call("osp_attn_softmax_fwd", S, Pd, klen, B, H, T1, T2, float(scale), float(drop_p), int(seed), int(stream_id))
+    sh, sd = _seed(seed)
+    call("osp_attn_softmax_fwd", S, Pd, klen, B, H, T1, T2, float(scale), float(drop_p), sh, sd, int(stream_id))
     return S, (Pd if Pd is not None else S)
 
 
 def attn_softmax_bwd(P, dPd, scale, drop_p=0.0, seed=0, stream_id=0):
     """in place: dPd (gradient w.r.t. the dropped probabilities) -> gradient w.r.t. the raw scores."""
     T2 = P.shape[-1]
-    call("osp_attn_softmax_bwd", P, dPd, P.numel() // T2, T2, float(scale), float(drop_p), int(seed), int(stream_id))
+    sh, sd = _seed(seed)
+    call("osp_attn_softmax_bwd", P, dPd, P.numel() // T2, T2, float(scale), float(drop_p), sh, sd, int(stream_id))
     return dPd

@@ -1,10 +1,10 @@
 """Host-side mirror of optispeech/model/vocoder/wavenext/disc/{__init__,_discriminators,loss}.py.
 
 VocosDiscriminator = MPD (5 periods) + MRD (3 resolutions) + hinge / feature-matching / mel / MR-STFT losses.
-Status (DESIGN.md, section "what runs where"): the STFT magnitudes and the spectral losses are HIP kernels
-(optispeech_amd/csrc/stft.hip); the Conv2d stacks of MPD/MRD are v1 = PyTorch-ROCm conv2d (MIOpen), listed as
-SURVEY.md section 8f row 1 ("next": hand-written implicit-GEMM).  Parameter names follow the reference's weight_norm
-schema (`weight_g` / `weight_v`).
+Every Conv2d stack runs on the hand-written kernels (optispeech_amd/disc_ops.py: bf16 MFMA conv-GEMMs in performance mode,
+split-bf16 products of the same kernels in the f32 parity mode); the STFT magnitudes and the spectral losses are HIP kernels
+too (csrc/stft.hip).  There is no torch conv2d / MIOpen path in the product: the torch reference the f32 mode is compared
+against lives in tests/_torch_disc_ref.py.  Parameter names follow the reference's weight_norm schema (`weight_g` / `weight_v`).
 """
 from types import SimpleNamespace
 
@@ -44,17 +44,6 @@ class _WNConv2d(nn.Module):
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
         self.weight_v = nn.Parameter(v)
 
-    def weight(self):
-        v = self.weight_v
-        return v * (self.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1))
-
-    def native_weight(self):
-        """(Cout, Cin, k, 1) -> kernel-native (Cout, k, Cin) for the (k,1) convolutions of DiscriminatorP."""
-        return self.weight().squeeze(-1).permute(0, 2, 1).contiguous()
-
-    def forward(self, x):
-        return F.conv2d(x, self.weight(), self.bias, self.stride, self.padding)
-
 
 class DiscriminatorP(nn.Module):
     """_discriminators.py:41-97."""
@@ -90,24 +79,14 @@ class DiscriminatorP(nn.Module):
                 return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
             return s.view(b, -1), [y2, y3, y4, y5, s]
-        if _F32_HIP and x.is_cuda:
-            # f32 parity mode on the same kernels (split-bf16 products, disc_ops.ConvStackPreciseFn); feature maps come out
-            # channels-last, which the (layout-agnostic) mean losses do not care about
-            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)
-            args = []
-            for conv in list(self.convs) + [self.conv_post]:
-                args += [conv.weight_v, conv.weight_g, conv.bias]
-            y1, y2, y3, y4, y5, s = ConvStackPreciseFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
-            return s.view(b, -1), [y2, y3, y4, y5, s]
-        x = x.view(b, c, t // self.period, self.period)
-        fmap = []
-        for i, conv in enumerate(self.convs):
-            x = F.leaky_relu(conv(x), self.lrelu_slope)
-            if i > 0:
-                fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
-        return torch.flatten(x, 1, -1), fmap
+        # f32 parity mode on the same kernels (split-bf16 products, disc_ops.ConvStackPreciseFn); feature maps come out
+        # channels-last, which the (layout-agnostic) mean losses do not care about
+        seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)
+        args = []
+        for conv in list(self.convs) + [self.conv_post]:
+            args += [conv.weight_v, conv.weight_g, conv.bias]
+        y1, y2, y3, y4, y5, s = ConvStackPreciseFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
+        return s.view(b, -1), [y2, y3, y4, y5, s]
 
 
 class DiscriminatorR(nn.Module):
@@ -141,22 +120,13 @@ class DiscriminatorR(nn.Module):
                 return (r[5].reshape(nograd_head, -1), list(r)), (y[5].reshape(y[5].shape[0], -1), list(y))
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
             return s.reshape(s.shape[0], -1), [y1, y2, y3, y4, y5, s]
-        if _F32_HIP and x.is_cuda:
-            n_fft, hop, win = self.resolution
-            spec = spectral.stft_magnitude(x, n_fft, hop, None, None)
-            args = []
-            for conv in list(self.convs) + [self.conv_post]:
-                args += [conv.weight_v, conv.weight_g, conv.bias]
-            ys = ConvStackPreciseFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
-            return ys[5].reshape(ys[5].shape[0], -1), list(ys)
-        fmap = []
-        x = self.spectrogram(x).unsqueeze(1)
-        for conv in self.convs:
-            x = F.leaky_relu(conv(x), self.lrelu_slope)
-            fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
-        return torch.flatten(x, 1, -1), fmap
+        n_fft, hop, win = self.resolution
+        spec = spectral.stft_magnitude(x, n_fft, hop, None, None)
+        args = []
+        for conv in list(self.convs) + [self.conv_post]:
+            args += [conv.weight_v, conv.weight_g, conv.bias]
+        ys = ConvStackPreciseFn.apply(spec.unsqueeze(-1), MRD_SPEC, self.lrelu_slope, *args)
+        return ys[5].reshape(ys[5].shape[0], -1), list(ys)
 
 
 def _replay_scores(d, B):
@@ -252,8 +222,6 @@ class _Multi(nn.Module):
         return rs, gs, frs, fgs
 
 
-#: f32 parity mode: discriminators on the hand-written kernels (split-bf16 products); "0" = torch conv2d (MIOpen)
-_F32_HIP = os.environ.get("OSP_F32_DISC_HIP", "1") != "0"
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
 #: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
 _FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"

@@ -86,6 +86,11 @@ class OptiSpeech(nn.Module):
         #: same weights inside one step -> identical activations) instead of evaluating the discriminators a second time.
         #: Off by default: the benchmarked step does every forward the reference does.
         self.replay_disc_forward = os.environ.get("OSP_DISC_REPLAY", "0") == "1"
+        #: replay the step from hipGraphs (optispeech_amd/graphs.py): captured on the first step of each (batch shape,
+        #: regime), replayed afterwards.  Off by default in the library (a captured step needs fixed shapes); bench.py
+        #: turns it on
+        self.graph_steps = os.environ.get("OSP_GRAPH_STEPS", "0") == "1"
+        self._step_graphs = {}
         self._dstream = None
         self._disc_param_list = None
         self._reducers = None
@@ -116,6 +121,9 @@ class OptiSpeech(nn.Module):
             opts, scheds = self.configure_optimizers()
             self._opts = (opts, [s["scheduler"] for s in scheds])
             self._reducers = (GradReducer(), GradReducer())
+            # data parallelism keeps replicas identical by construction from here on (same averaged gradients, same update);
+            # the starting point is rank 0's weights and buffers, whatever each rank seeded or loaded
+            self._reducers[0].broadcast_from_rank0([o.arena.data for o in opts] + [b for b in self.buffers()])
         return self._opts[0]
 
     def lr_schedulers(self):
@@ -143,57 +151,88 @@ class OptiSpeech(nn.Module):
         return gen_outputs
 
     def training_step(self, batch, batch_idx=0, **kwargs):
-        """base_lightning_module.py:78-126."""
+        """base_lightning_module.py:78-126.
+
+        The step is a sequence of five stages (generator forward / generator backward / discriminator phase / two optimiser
+        updates, ``_stage_*`` below) with the gradient all-reduces between them.  Eager mode issues them in the order below;
+        with ``graph_steps`` the same stage functions are captured once into hipGraphs and replayed (``optispeech_amd/graphs.py``),
+        which removes the ~20 ms of Python / autograd / dispatch time per step that bound the eager step."""
         ta = self.train_args
         accum = ta.gradient_accumulate_batches
-        scale = float(accum) if accum is not None else 1.0
-        apply = ((batch_idx + 1) % accum == 0) if accum is not None else True
-        train_discriminator = self.global_step >= ta.pretraining_steps
-        opt_g, opt_d = self.optimizers()
-        sched_g, sched_d = self.lr_schedulers()
+        if self.graph_steps and accum is None and torch.is_tensor(batch.get("x")) and self.device.type == "cuda":
+            from ..graphs import graphed_training_step
+            return graphed_training_step(self, batch, batch_idx)
+        st = self._new_step_state(batch_idx)
         red_g, red_d = self._reducers
         rng.advance()
-        logs = {}
         # ---- generator phase (discriminator weights frozen = toggle_optimizer; training_step_g freezes them after the
         # shared real-wave pass, which needs the parameter graph for the discriminator phase)
-        loss_g, (wav, wav_hat) = self.training_step_g(batch, train_discriminator, logs,
-                                                       share_real=train_discriminator and self.share_real_pass)
-        if apply:
-            opt_g.zero_grad()
-        # the discriminator-phase inputs are fixed from here on: stage them before the generator's backward is queued, so
-        # that the discriminator-phase forward (side streams) overlaps that backward (this stream)
-        pre = self.discriminator.prepare_disc_inputs(wav, wav_hat.detach()) if train_discriminator and self._real_pass is None else None
-        (loss_g / scale).backward()
-        red_g.start(opt_g.arena.grad)
-        for p in self._disc_params():
-            p.requires_grad_(True)
+        self._stage_g_forward(st, batch)
+        self._stage_g_backward(st)
+        red_g.start(self.optimizers()[0].arena.grad)
         # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce).
         # With ``pipeline_steps`` its loss / backward / optimizer step are issued from a second "calling" stream: the
         # calling stream proper only carries the generator work, so the NEXT step's generator forward (which needs the
         # updated generator weights, not the discriminator's) overlaps this step's discriminator backward.  The
         # discriminator stream is joined before anything reads discriminator state again (training_step_g, fetch_logs,
         # state_dict, join()).
-        dctx = self._disc_phase_stream() if (train_discriminator and self.pipeline_steps) else contextlib.nullcontext()
-        if train_discriminator:
+        dctx = self._disc_phase_stream() if (st.train_d and self.pipeline_steps) else contextlib.nullcontext()
+        if st.train_d:
             with dctx:
-                loss_d = self.training_step_d(batch, (wav, wav_hat.detach()), logs, pre=pre, replay=self.replay_disc_forward)
-                if apply:
-                    opt_d.zero_grad()
-                (loss_d / scale).backward()
-                red_d.start(opt_d.arena.grad)
+                self._stage_d(st, batch)
+                red_d.start(self.optimizers()[1].arena.grad)
         red_g.wait()
-        if apply:
-            opt_g.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_g.world)
-            sched_g.step()
-            self.global_step += 1
-        if train_discriminator:
+        self._stage_opt_g(st)
+        if st.train_d:
             with dctx:
                 red_d.wait()
-                if apply:
-                    opt_d.step(max_norm=ta.gradient_clip_val, grad_scale=1.0 / red_d.world)
-                    sched_d.step()
-                    self.global_step += 1
-        self.last_logs = logs
+                self._stage_opt_d(st)
+        self.last_logs = st.logs
+
+    # The five stages of a step.  ``st`` carries what flows between them; every stage only enqueues device work.
+    def _new_step_state(self, batch_idx=0):
+        ta = self.train_args
+        accum = ta.gradient_accumulate_batches
+        self.optimizers()
+        return SimpleNamespace(scale=float(accum) if accum is not None else 1.0,
+                               apply=((batch_idx + 1) % accum == 0) if accum is not None else True,
+                               train_d=self.global_step >= ta.pretraining_steps, logs={}, loss_g=None, wav=None, wav_hat=None,
+                               pre=None)
+
+    def _stage_g_forward(self, st, batch):
+        st.loss_g, (st.wav, st.wav_hat) = self.training_step_g(batch, st.train_d, st.logs,
+                                                               share_real=st.train_d and self.share_real_pass)
+        # the discriminator-phase inputs are fixed from here on: stage them before the generator's backward is queued, so
+        # that the discriminator-phase forward (side streams) overlaps that backward (this stream)
+        st.pre = (self.discriminator.prepare_disc_inputs(st.wav, st.wav_hat.detach())
+                  if st.train_d and self._real_pass is None else None)
+
+    def _stage_g_backward(self, st):
+        if st.apply:
+            self.optimizers()[0].zero_grad()
+        (st.loss_g / st.scale).backward()
+        st.loss_g = None
+
+    def _stage_d(self, st, batch):
+        for p in self._disc_params():
+            p.requires_grad_(True)
+        loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre, replay=self.replay_disc_forward)
+        if st.apply:
+            self.optimizers()[1].zero_grad()
+        (loss_d / st.scale).backward()
+        st.pre = None
+
+    def _stage_opt_g(self, st):
+        if st.apply:
+            self.optimizers()[0].step(max_norm=self.train_args.gradient_clip_val, grad_scale=1.0 / self._reducers[0].world)
+            self.lr_schedulers()[0].step()
+            self.global_step += 1
+
+    def _stage_opt_d(self, st):
+        if st.apply:
+            self.optimizers()[1].step(max_norm=self.train_args.gradient_clip_val, grad_scale=1.0 / self._reducers[1].world)
+            self.lr_schedulers()[1].step()
+            self.global_step += 1
 
     def _disc_params(self):
         """The discriminator's parameter list, walked once (toggled twice per step: toggle_optimizer of the reference)."""
@@ -210,7 +249,7 @@ class OptiSpeech(nn.Module):
 
     def join(self):
         """The current stream waits for a discriminator phase still in flight (``pipeline_steps``); no host sync."""
-        if self._dstream is not None:
+        if self._dstream is not None and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream().wait_stream(self._dstream)
 
     def state_dict(self, *args, **kwargs):
@@ -375,6 +414,7 @@ class OptiSpeech(nn.Module):
         parameter name and stored in the reference layout, step counters, schedule positions, dropout RNG position)
         live under ``"osp"`` so that a resumed run continues exactly."""
         from .. import rng
+        self.join()                               # a pipelined discriminator update may still be writing weights / moments
         opts = self.optimizers()
         extra = {"rng": dict(rng._state), "global_step": self.global_step, "optimizers": []}
         for opt, sch in zip(opts, self.lr_schedulers()):
@@ -388,6 +428,8 @@ class OptiSpeech(nn.Module):
         """Restore what save_checkpoint put under ``"osp"`` (after the weights were loaded and the model moved to its device)."""
         from .. import rng
         extra = ckpt["osp"] if "osp" in ckpt else ckpt
+        self.join()
+        self._step_graphs.clear()                 # captured steps hold the old optimiser scalars
         rng._state.update(extra["rng"])
         self.global_step = int(extra["global_step"])
         for opt, sch, st in zip(self.optimizers(), self.lr_schedulers(), extra["optimizers"]):

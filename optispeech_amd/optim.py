@@ -79,6 +79,9 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros_like(self.arena.data)
         self.step_count = 0
         self._sumsq = torch.zeros(1, device=self.arena.data.device, dtype=torch.float64)
+        #: (lr f32[1], step int64[1]) device tensors while the step is captured in / replayed from a hipGraph: the kernel
+        #: then reads both from device memory (the replay loop refreshes them), not from its launch arguments
+        self.dev_scalars = None
 
     def zero_grad(self):
         self.arena.zero_grad()
@@ -93,8 +96,9 @@ class FusedAdamW:
         self.step_count += 1
         ss = self.grad_sumsq() if max_norm else None
         values.bump_param_epoch()                 # derived weight packs (disc_ops weight-norm cache) are stale from here on
+        lr_dev, step_dev = self.dev_scalars if self.dev_scalars is not None else (None, None)
         call("osp_adamw_clip", self.arena.data, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.arena.numel, ss,
-             None, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+             lr_dev, step_dev, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
              float(self.weight_decay), int(self.step_count), float(max_norm or 0.0), float(grad_scale))
 
     def state_dict(self):

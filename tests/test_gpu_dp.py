@@ -1,0 +1,136 @@
+"""Data parallelism on the REAL training step (the reference's DDP contract configs/trainer/ddp.yaml:4-9,
+reducers at base_lightning_module.py:99,119): two ranks (both on GPU 0, gloo moving the buckets through the host -- RCCL needs
+one GPU per rank) run ``OptiSpeech.training_step`` on two different micro-batches.  8e's own parity target:
+
+    the N-rank result equals the mean of the N single-rank gradient sets, and replicas stay identical after the update.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(seed, rank_seed_offset=0):
+    from oracle import schema as S
+    from optispeech_amd import rng
+    from optispeech_amd.config import ModelConfig, make_optispeech
+    c = S.SMALL
+    cfg = ModelConfig(dim=c.dim, enc_inter=c.enc_inter, dec_inter=c.dec_inter, dur=c.dur + (0.0,), pitch=c.pitch + (0.0,),
+                      energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers).no_dropout()
+    torch.manual_seed(seed + rank_seed_offset)              # rank_seed_offset != 0: replicas that did NOT seed identically
+    rng.manual_seed(seed, 0)
+    m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to("cuda").train()
+    return cfg, m
+
+
+def _batches(cfg):
+    from optispeech_amd.config import synthetic_batch
+    out = []
+    for r in range(2):
+        b = synthetic_batch(2, 24, 96, cfg, seed=50 + r, ragged=True, device="cuda")
+        out.append((b, torch.tensor([0.25 + 0.5 * r, 0.6 - 0.3 * r], device="cuda")))
+    return out
+
+
+def _grads_of_one_step(m, batch, r01):
+    """(G-arena gradient, D-arena gradient) of one training step from the CURRENT weights, without updating them."""
+    got = {}
+    og, od = m.optimizers()
+    for name, o in (("g", og), ("d", od)):
+        o.step = (lambda n, oo: (lambda *a, **k: got.__setitem__(n, oo.arena.grad.detach().clone())))(name, o)
+    m.generator.segment_rand01 = r01
+    m.training_step(batch, 0)
+    torch.cuda.synchronize()
+    return got["g"], got["d"]
+
+
+def _worker(rank, world, port, graph, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), OSP_DP_SINGLE_DEVICE="1", OSP_DP_BACKEND="gloo")
+        import torch.distributed as dist
+        from optispeech_amd import dp, precision
+        precision.set_precision("f32")
+        # ---- single-rank references, before the process group exists (their reducers are inert)
+        cfg, ref = _build(7)
+        batches = _batches(cfg)
+        ref.optimizers()
+        assert not ref._reducers[0].active
+        w0 = [o.arena.data.clone() for o in ref.optimizers()]
+        singles = [_grads_of_one_step(ref, b, r01) for b, r01 in batches]
+        mean_g = (singles[0][0] + singles[1][0]) / 2
+        mean_d = (singles[0][1] + singles[1][1]) / 2
+        # ---- the two-rank run: rank r sees micro-batch r; rank 1 deliberately starts from DIFFERENT weights, which the
+        # broadcast from rank 0 in optimizers() must repair
+        w, r, _ = dp.init_from_env()
+        assert (w, r) == (world, rank) and dist.get_backend() == "gloo"
+        cfg, m = _build(7, rank_seed_offset=rank)
+        m.graph_steps = graph
+        m.graph_warmup_steps = 1
+        og, od = m.optimizers()
+        assert m._reducers[0].active and m._reducers[0].world == 2
+        assert torch.equal(og.arena.data, w0[0]) and torch.equal(od.arena.data, w0[1]), "replicas do not start from rank 0's weights"
+        b, r01 = batches[rank]
+        m.generator.segment_rand01 = r01
+        m.training_step(b, 0)
+        logs = m.fetch_logs()
+        torch.cuda.synchronize()
+        ok = True
+        msgs = []
+        # after the step the gradient arenas still hold what the update consumed: the all-reduced SUM (1/world is folded into
+        # the update kernel's grad_scale)
+        for name, o, mean in (("g", og, mean_g), ("d", od, mean_d)):
+            got = o.arena.grad.detach() / world
+            err = ((got - mean).norm() / mean.norm()).item()
+            msgs.append(f"{name}: |sum/world - mean of single-rank grads| / |mean| = {err:.2e}")
+            ok = ok and err < 2e-4
+        # replicas identical after the update: compare every rank's arenas bit for bit
+        for o in (og, od):
+            mine = o.arena.data.detach().clone()
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            same = torch.equal(both[0], both[1])
+            ok = ok and same
+            msgs.append(f"replicas bit-identical: {same}")
+            moved = (mine - w0[0 if o is og else 1]).abs().max().item()
+            ok = ok and moved > 0
+        q.put((rank, bool(ok), msgs, {k: float(v) for k, v in logs.items() if k.startswith("total_loss")}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                # noqa: BLE001
+        import traceback
+        q.put((rank, False, [traceback.format_exc()], {}))
+        raise
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_rank_training_step_equals_mean_of_single_rank_gradients(graph):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, graph, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    res.sort()
+    for rank, ok, msgs, logs in res:
+        assert ok, (rank, msgs)
+    # the logged losses are the mean over ranks (one packed all-reduce): identical on both
+    assert res[0][3] == res[1][3] and all(np.isfinite(v) for v in res[0][3].values())
+    for p in procs:
+        assert p.exitcode == 0

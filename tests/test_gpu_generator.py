@@ -276,3 +276,45 @@ def test_synthesise_vs_golden(golden):
     assert relerr(out["pitch"], g["pitch"]) < 1e-3 and relerr(out["energy"], g["energy"]) < 1e-3
     assert relerr(out["wav"], g["wav"]) < 1e-3
     assert out["rtf"] > 0 and out["latency"] > 0
+
+
+def test_multispeaker_sids_lids_vs_reference_golden(golden):
+    """sids / lids -> sid_embed / lid_embed added to the encoder output (generator/__init__.py:62-65,112-117,235-246): the
+    training forward + backward and synthesise() with explicit and with defaulted ids, against values the REFERENCE produced
+    (tools/make_golden_multispeaker.py)."""
+    import copy
+    from optispeech_amd.config import make_generator
+    g = golden("gen_small_multispk")
+    cfg = copy.deepcopy(_small_cfg())
+    cfg.num_speakers, cfg.num_languages = 3, 2
+    schema = S.generator_schema(S.SMALL)
+    schema["generator.sid_embed.weight"] = (3, S.SMALL.dim)
+    schema["generator.lid_embed.weight"] = (2, S.SMALL.dim)
+    W = S.make_weights(schema, int(g["seed"]))
+    gen = make_generator(cfg).to(DEV).train()
+    gen.load_state_dict({k[len("generator."):]: v for k, v in W.items()}, strict=True)
+    gen.segment_rand01 = torch.from_numpy(g["rand01"])
+    b = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith("in_")}
+    sids, lids = torch.from_numpy(g["sids"]).to(DEV), torch.from_numpy(g["lids"]).to(DEV)
+    out = gen(b["x"], b["x_lengths"], b["mel"], b["mel_lengths"], b["pitches"], b["energies"], sids, lids)
+    assert np.array_equal(out["_aux"]["durations"].cpu().numpy(), g["durations"])
+    assert np.array_equal(out["start_idx"].cpu().numpy(), g["start_idx"])
+    for k in ("loss", "align_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(out[k].item() - float(g[k])) <= 1e-4 * abs(float(g[k])), k
+    assert relerr(out["wav_hat"], g["wav_hat"]) < 1e-3
+    out["loss"].backward()
+    assert relerr(gen.sid_embed.weight.grad, g["grad_sid_embed"]) < 2e-3
+    assert relerr(gen.lid_embed.weight.grad, g["grad_lid_embed"]) < 2e-3
+    for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
+        got = _ref_grad(gen, k)
+        assert got is not None and abs(got.double().norm().item() - n) <= 2e-3 * max(n, 1e-6) + 1e-8, k
+    # inference
+    gen.eval()
+    with torch.no_grad():
+        gen.duration_predictor.linear.bias.fill_(float(g["dur_bias"]))
+    x, xl = torch.from_numpy(g["syn_x"]).to(DEV), torch.from_numpy(g["syn_x_lengths"])
+    for tag, kw in (("syn", dict(sids=sids, lids=lids)), ("syn0", dict())):
+        o = gen.synthesise(x, xl, d_factor=1.1, p_factor=1.6, e_factor=1.2, **kw)
+        assert np.array_equal(o["durations"].numpy(), g[tag + "_durations"]), tag
+        assert np.array_equal(o["wav_lengths"].numpy(), g[tag + "_wav_lengths"])
+        assert relerr(o["wav"], g[tag + "_wav"]) < 1e-3, tag

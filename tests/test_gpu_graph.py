@@ -1,0 +1,79 @@
+"""hipGraph replay of the training step (BASELINE.json configs[1]): the captured step -- one graph on a
+single GPU, the five-segment data-parallel stage order when forced -- must give what the eager step gives, including the
+per-step scalars that live in device memory while replaying (dropout seed, AdamW step count, learning rate)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mode, steps=3):
+    from optispeech_amd import rng
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    cfg = ModelConfig()                                           # BASELINE widths, dropout / drop-path ON
+    batch = synthetic_batch(2, 24, 96, cfg, seed=5, device="cuda")
+    torch.manual_seed(3)
+    torch.cuda.manual_seed(3)
+    rng.manual_seed(3, 0)
+    m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to("cuda").train()
+    m.generator.segment_rand01 = torch.rand(2, generator=torch.Generator().manual_seed(1)).cuda()
+    m.optimizers()
+    for sch in m.lr_schedulers():                                 # short warm-up: the learning rate changes every step
+        sch.warmup = 4
+        sch.opt.lr = sch.base_lr * (1.0 / 4)
+        sch.last_step = 1
+    if mode != "eager":
+        m.graph_steps = True
+        m.graph_warmup_steps = 1
+        m.graph_force_segments = mode == "segments"
+    per_step = []
+    for i in range(steps):
+        m.training_step(batch, i)
+        per_step.append(m.fetch_logs())
+    torch.cuda.synchronize()
+    opt_g, opt_d = m.optimizers()
+    host = (m.global_step, opt_g.step_count, opt_d.step_count, opt_g.lr, opt_d.lr, rng.host_seed(),
+            [s.last_step for s in m.lr_schedulers()])
+    return per_step, {k: v.detach().clone() for k, v in m.state_dict().items()}, host, m
+
+
+@pytest.mark.parametrize("mode", ["graph", "segments"])
+def test_graphed_step_matches_eager(mode):
+    from optispeech_amd import precision
+    precision.set_precision("bf16")
+    try:
+        la, sa, ha, _ = _run("eager")
+        lb, sb, hb, m = _run(mode)
+        assert len(m._step_graphs) == 1
+        sg = next(iter(m._step_graphs.values()))
+        assert len(sg.graphs) == (1 if mode == "graph" else 5)
+        assert ha == hb, (ha, hb)                                 # step counts, schedule position, lr, seed: same bookkeeping
+        # every step of the graph run is a replay (the capture's warm-up is rolled back)
+        for i, (x, y) in enumerate(zip(la, lb)):
+            assert x.keys() == y.keys()
+            for k in x:
+                # tolerance of two eager runs against each other: f32 atomics order + the discrete MAS path amplify round-off
+                assert abs(x[k] - y[k]) <= (2e-3 if i == 0 else 2e-2) * abs(x[k]) + 1e-4, (i, k, x[k], y[k])
+        moved = 0
+        for k in sa:
+            if sa[k].is_floating_point():
+                assert torch.allclose(sa[k], sb[k], rtol=1e-3, atol=1.5e-3), (k, (sa[k] - sb[k]).abs().max().item())
+                moved += 1
+        assert moved > 100
+    finally:
+        precision.set_precision("f32")
+
+
+def test_graph_replay_advances_dropout_seed_and_weights():
+    """Replays are not re-runs of the captured step: the dropout masks change (seed in device memory), the weights keep moving
+    and the logged losses change from replay to replay."""
+    from optispeech_amd import precision
+    precision.set_precision("bf16")
+    try:
+        logs, _, _, m = _run("graph", steps=4)
+        vals = [l["total_loss/generator"] for l in logs]
+        assert all(np.isfinite(v) for v in vals)
+        assert len({round(v, 6) for v in vals[1:]}) == 3, vals     # three replays, three different losses
+    finally:
+        precision.set_precision("f32")

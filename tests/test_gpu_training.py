@@ -219,8 +219,8 @@ def test_pipelined_steps_match_serial_steps():
 
 @pytest.mark.parametrize("which", ["multiperioddisc", "multiresddisc"])
 def test_f32_mode_split_bf16_stacks_match_torch_conv2d(which):
-    """f32 parity mode: the hand-written stacks (split-bf16 products, ConvStackPreciseFn) vs torch's conv2d (MIOpen) on the
-    same weights -- scores, feature maps, input gradient and every parameter gradient within 2e-4 of the tensor scale."""
+    """f32 parity mode: the hand-written stacks (split-bf16 products, ConvStackPreciseFn) vs torch's conv2d (MIOpen; test-side
+    restatement in tests/_torch_disc_ref.py) on the same weights -- scores, feature maps, input gradient and every parameter gradient within 2e-4 of the tensor scale."""
     from optispeech_amd import precision
     from optispeech_amd.model import discriminator as D
     from oracle import schema as S
@@ -231,20 +231,18 @@ def test_f32_mode_split_bf16_stacks_match_torch_conv2d(which):
     m.load_state_dict(W)
     y = (torch.rand(3, 16384, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
     res = {}
-    try:
+    from tests import _torch_disc_ref as TR
+    if True:
         for hip in (False, True):
-            D._F32_HIP = hip
             yh = (torch.rand(3, 16384, generator=torch.Generator().manual_seed(2)) * 2 - 1).cuda().requires_grad_(True)
             for p in m.parameters():
                 p.requires_grad_(True)
                 p.grad = None
-            rs, gs, frs, fgs = m(y, yh)
+            rs, gs, frs, fgs = m(y, yh) if hip else TR.multi(m, y, yh)
             loss = D._hinge_d(rs, gs) + 0.1 * D._feature_matching(frs, fgs) + D._hinge_g(gs)
             loss.backward()
             torch.cuda.synchronize()
             res[hip] = (loss.item(), [g.detach().clone() for g in gs], yh.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
-    finally:
-        D._F32_HIP = True
     a, b = res[False], res[True]
     rel = lambda u, v: ((u.double() - v.double()).abs().max() / v.double().abs().max().clamp_min(1e-30)).item()   # noqa: E731
     assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0])

@@ -62,6 +62,7 @@ REPLACES = {
     "osp_hinge_grad": "autograd of the same",
     "osp_last_error": "error text of the last failing call on this thread",
     "osp_abi_version": "ABI version of this library",
+    "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
 }
 
 PREAMBLE = '''/* libosp_hip -- C ABI of the MI355X-native OptiSpeech hot path (generated by tools/gen_header.py; do not edit).
