@@ -559,7 +559,8 @@ extern "C" int osp_cast_bf16(const float* x, void* y, int64_t n, hipStream_t str
 // k-contiguous bf16 layout lets the GEMM use 16-byte operand loads instead of its transposing element loader, which is
 // ~2x slower than the GEMM itself on these small shapes.  32x32 tiles through LDS, reads along the unit-stride axis.
 // Algorithmic bytes: 4 read + 2 written per weight.
-__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int N, int taps,
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ kscale,
+                                                        unsigned short* __restrict__ out, int N, int taps,
                                                         int K, int64_t sN, int64_t sT, int64_t sK) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z, n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int n = along_n ? n0 + tx : n0 + r, k = along_n ? k0 + r : k0 + tx;
-        const float v = (n < N && k < K) ? src[(int64_t)n * sN + (int64_t)k * sK] : 0.f;
+        const float v = (n < N && k < K) ? src[(int64_t)n * sN + (int64_t)k * sK] * (kscale ? kscale[k] : 1.f) : 0.f;
         if (along_n) tile[r][tx] = v; else tile[tx][r] = v;      // tile[k_local][n_local]
     }
     __syncthreads();
@@ -579,10 +580,11 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
         if (n < N && k < K) out[((int64_t)n * taps + tap) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][r]);
     }
 }
-extern "C" int osp_pack_bf16(const float* w, void* out, int64_t N, int64_t taps, int64_t K, int64_t sN, int64_t sT, int64_t sK,
-                             hipStream_t stream) {
+// kscale (optional, K floats): every element is multiplied by kscale[k] first (layer-scale gamma folded into the dgrad weights).
+extern "C" int osp_pack_bf16(const float* w, const float* kscale, void* out, int64_t N, int64_t taps, int64_t K, int64_t sN, int64_t sT,
+                             int64_t sK, hipStream_t stream) {
     OSP_CHECK_ARG(w && out && N > 0 && taps > 0 && K > 0, "bad args");
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32), (unsigned)taps), dim3(256), 0, stream, w,
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)cdiv(K, 32), (unsigned)cdiv(N, 32), (unsigned)taps), dim3(256), 0, stream, w, kscale,
                        (unsigned short*)out, (int)N, (int)taps, (int)K, sN, sT, sK);
     OSP_LAUNCH_CHECK();
     return OSP_OK;

@@ -135,6 +135,31 @@ def wnorm_packed(v, g, want_f32, want_t):
     return pack
 
 
+def wnorm_pack_many(convs, want_f32):
+    """Weight-norm packs of a list of conv modules (``weight_v`` / ``weight_g``) whose cached pack is stale, in ONE launch
+    (osp_wnorm_fwd_multi) -- the per-conv osp_wnorm_fwd launches were 48 per discriminator pass.  ``want_f32``: also produce the
+    f32 native copy for every conv (parity mode) or only for the narrow first layers (None).  Fills the same per-parameter cache
+    wnorm_packed() reads; returns True when anything was launched (the caller must then order its side streams behind it)."""
+    from . import values
+    todo = []
+    for conv in convs:
+        v, g = conv.weight_v, conv.weight_g
+        cout, cin, KH, KW = v.shape[0], v.shape[1], v.shape[3], v.shape[2]      # reference layout (Cout, Cin, k_w/freq, k_h/time)
+        small = cin == 1 and cout in (16, 32, 64) and KH * KW <= cout
+        f32 = bool(want_f32) or small
+        stamp = (values.param_epoch(), v._version, g._version, v.data_ptr(), g.data_ptr())
+        hit = getattr(v, "_osp_wn_pack", None)
+        if hit is not None and hit[0] == stamp and (hit[1][1] is not None or not f32) and hit[1][2] is not None:
+            continue
+        todo.append((v, g, f32, stamp))
+    if not todo:
+        return False
+    packs = K.wnorm_fwd_multi([(v.detach(), g.detach(), f32, True) for v, g, f32, _ in todo])
+    for (v, g, f32, stamp), pack in zip(todo, packs):
+        v._osp_wn_pack = (stamp, pack)
+    return True
+
+
 def g_stream_is_side():
     """True when the current stream is not the device's default stream (a sub-discriminator stream)."""
     return torch.cuda.current_stream() != torch.cuda.default_stream()
@@ -235,6 +260,7 @@ def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds
     sizes = [vs[i].numel() if need_w[i] else 0 for i in range(6)]
     flat = torch.zeros((sum(sizes),), device=g.device, dtype=torch.float32) if sum(sizes) else None
     offs = [sum(sizes[:i]) for i in range(6)]
+    wn_items = []                                             # (dW native f32, v, g, 1/||v||, dv, dg) of every layer: ONE launch
     for i in range(5, -1, -1):
         inp = acts[i - 1] if i > 0 else x
         KH, KW, sh, sw, ph, pw = spec[i]
@@ -252,7 +278,7 @@ def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds
                 K.conv2d_wgrad_bf16(g.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
                                     Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
                                     pad_w=pw, step_h=sh, step_w=sw)
-            K.wnorm_bwd(dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i]))
+            wn_items.append((dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i])))
         if i > 0 and (need_x or any(need_w[:i])):
             g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp, extra=extras[i - 1],
                              slope=slope, out_bf16=True)
@@ -261,6 +287,8 @@ def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds
         else:
             g = None
             break
+    if wn_items:
+        K.wnorm_bwd_multi(wn_items)
     if any(need_w) and g_stream_is_side():
         # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
         # engine does not know that the stream backward() was called from must wait for this node's stream: say so.
@@ -420,15 +448,14 @@ class L1MeanFn(torch.autograd.Function):
 
 class FeatureMatchSumFn(torch.autograd.Function):
     """sum_i mean |target_i - y_i| over a whole list of feature-map pairs in ONE autograd node (FeatureMatchingLoss,
-    disc/loss.py:71-85): n fused |a-b| reductions accumulate into one scalar; the backward writes sign(y - target) / numel
-    per pair.  Inputs: n targets followed by n generated maps."""
+    disc/loss.py:71-85) and ONE launch per 32 pairs (osp_l1_sum_multi: the |a-b| reductions of all pairs accumulate into one
+    scalar); the backward writes sign(y - target) / numel per pair, again one launch.  Inputs: n targets, then n generated maps."""
 
     @staticmethod
     def forward(ctx, n, *maps):
         tg, ys = [t.contiguous() for t in maps[:n]], [t.contiguous() for t in maps[n:]]
         out = torch.zeros((), device=ys[0].device, dtype=torch.float32)
-        for a, b in zip(tg, ys):
-            K.l1_sum(a, b, 1.0 / b.numel(), out)
+        K.l1_sum_multi(tg, ys, out)
         ctx.save_for_backward(*tg, *ys)
         ctx.n = n
         return out
@@ -437,20 +464,19 @@ class FeatureMatchSumFn(torch.autograd.Function):
     def backward(ctx, gout):
         n, saved = ctx.n, ctx.saved_tensors
         g = gout.reshape(1).float().contiguous()
-        grads = [K.l1_sign(a, b, 1.0 / b.numel(), g) for a, b in zip(saved[:n], saved[n:])]
+        grads = K.l1_sign_multi(list(saved[:n]), list(saved[n:]), g)
         return (None,) + (None,) * n + tuple(grads)
 
 
 class HingeSumFn(torch.autograd.Function):
-    """sum_i mean(clamp(1 + sgn_i * x_i, min=0)) over a list of score maps in one node (GeneratorLoss / DiscriminatorLoss,
-    disc/loss.py:16-65).  ``sgns``: tuple of +-1 per tensor."""
+    """sum_i mean(clamp(1 + sgn_i * x_i, min=0)) over a list of score maps in one node and one launch (GeneratorLoss /
+    DiscriminatorLoss, disc/loss.py:16-65).  ``sgns``: tuple of +-1 per tensor."""
 
     @staticmethod
     def forward(ctx, sgns, *xs):
         xs = [x.contiguous().float() for x in xs]
         out = torch.zeros((), device=xs[0].device, dtype=torch.float32)
-        for s, x in zip(sgns, xs):
-            K.call("osp_hinge_sum", x, x.numel(), float(s), 1.0 / x.numel(), out)
+        K.hinge_sum_multi(xs, sgns, out)
         ctx.save_for_backward(*xs)
         ctx.sgns = sgns
         return out
@@ -458,12 +484,11 @@ class HingeSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         g = gout.reshape(1).float().contiguous()
-        grads = []
-        for s, x, need in zip(ctx.sgns, ctx.saved_tensors, ctx.needs_input_grad[1:]):
-            if not need:
-                grads.append(None)
-                continue
-            dx = torch.empty_like(x)
-            K.call("osp_hinge_grad", x, x.numel(), float(s), 1.0 / x.numel(), g, dx)
-            grads.append(dx)
+        need = ctx.needs_input_grad[1:]
+        idx = [i for i, nd in enumerate(need) if nd]
+        grads = [None] * len(need)
+        if idx:
+            dxs = K.hinge_grad_multi([ctx.saved_tensors[i] for i in idx], [ctx.sgns[i] for i in idx], g)
+            for i, dx in zip(idx, dxs):
+                grads[i] = dx
         return (None,) + tuple(grads)

@@ -122,10 +122,18 @@ class StepGraphs:
             return [([lambda: m._stage_g_forward(st, b), lambda: m._stage_g_backward(st), lambda: m._stage_d(st, b),
                       lambda: m._stage_opt_g(st), lambda: m._stage_opt_d(st)], None)]
         return [([lambda: m._stage_g_forward(st, b)], None),
-                ([lambda: m._stage_d(st, b)], lambda: self.red_d.start(opt_d.arena.grad)),
+                ([lambda: self._fresh_ready_event(st), lambda: m._stage_d(st, b)], lambda: self.red_d.start(opt_d.arena.grad)),
                 ([lambda: m._stage_g_backward(st)], lambda: (self.red_d.wait(), self.red_g.start(opt_g.arena.grad))),
                 ([lambda: m._stage_opt_d(st)], lambda: self.red_g.wait()),
                 ([lambda: m._stage_opt_g(st)], None)]
+
+    @staticmethod
+    def _fresh_ready_event(st):
+        """The 'inputs ready' event prepare_disc_inputs recorded belongs to the previous segment's capture: a stream of this
+        capture cannot wait on it.  Dropping it makes the discriminator phase record its own (its inputs are complete anyway:
+        the previous graph has been launched in full)."""
+        if st.pre is not None:
+            st.pre = (st.pre[0], None)
 
     def _run_eager(self):
         """One step through the same stage order, eagerly (warm-up before the capture: allocator pools, lazily created streams,

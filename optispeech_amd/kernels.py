@@ -54,7 +54,7 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
         if batch == 1 and w_strides[2] != 1:
             # k-strided (transposed / flipped) weights: one pack launch into the k-contiguous bf16 layout
             wp = torch.empty((n_out, taps, cin), device=a.device, dtype=torch.bfloat16)
-            call("osp_pack_bf16", w, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
+            call("osp_pack_bf16", w, None, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
             w, w_bf16, w_strides = wp, 1, (taps * cin, cin, 1)
         call("osp_conv_gemm_bf16", a, 0, lda, M, T, T, cin, taps, 1, 1, -pad, a_rowscale, w, w_bf16, w_strides[0], w_strides[1],
              w_strides[2], n_out, out, 0, ldc_, T, 1, 0, epi, bias, gamma, res, 0, res.stride(-2) if res is not None else 0,
@@ -314,11 +314,102 @@ def _isbf(t):
     return int(t is not None and t.dtype == torch.bfloat16)
 
 
-def pack_bf16(w, n_out, taps, cin, w_strides):
-    """(n_out, taps, cin) k-contiguous bf16 copy of a weight addressed through element strides (osp_pack_bf16)."""
+def pack_bf16(w, n_out, taps, cin, w_strides, kscale=None):
+    """(n_out, taps, cin) k-contiguous bf16 copy of a weight addressed through element strides (osp_pack_bf16); ``kscale``
+    (cin floats) multiplies along the reduction index first."""
     wp = torch.empty((n_out, taps, cin), device=w.device, dtype=torch.bfloat16)
-    call("osp_pack_bf16", w, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
+    call("osp_pack_bf16", w, kscale, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
     return wp
+
+
+def colsum_prod(a, b, rowf, out):
+    """out[c] += sum_m rowf[m] * a[m, c] * b[m, c]  (f32, (M, C) contiguous)."""
+    M, C = a.shape
+    call("osp_colsum_prod", a, b, rowf, out, M, C)
+
+
+def cast_bf16_rows(x, rowscale):
+    """bf16(rowscale[m] * x[m, :]) for an (M, C) f32 matrix."""
+    M, C = x.shape
+    y = torch.empty((M, C), device=x.device, dtype=torch.bfloat16)
+    call("osp_cast_bf16_rows", x, rowscale, y, M, C)
+    return y
+
+
+def _host_i64(vals):
+    import numpy as np
+    return np.asarray(vals, dtype=np.int64)
+
+
+def _host_f32(vals):
+    import numpy as np
+    return np.asarray(vals, dtype=np.float32)
+
+
+def l1_sum_multi(targets, ys, out):
+    """out += sum_i mean |target_i - y_i| over a list of same-dtype tensor pairs, one launch per 32 pairs."""
+    a, b = _host_i64([t.data_ptr() for t in targets]), _host_i64([t.data_ptr() for t in ys])
+    n, sc = _host_i64([t.numel() for t in ys]), _host_f32([1.0 / t.numel() for t in ys])
+    bf = _host_i64([_isbf(t) for t in ys])
+    call("osp_l1_sum_multi", a.ctypes.data, b.ctypes.data, n.ctypes.data, sc.ctypes.data, bf.ctypes.data, len(ys), out)
+
+
+def l1_sign_multi(targets, ys, gscale):
+    """[gscale * sign(y_i - target_i) / numel_i] for the same list (feature-matching gradient), one launch per 32 pairs."""
+    gbs = [torch.empty_like(t) for t in ys]
+    a, b = _host_i64([t.data_ptr() for t in targets]), _host_i64([t.data_ptr() for t in ys])
+    o, n = _host_i64([t.data_ptr() for t in gbs]), _host_i64([t.numel() for t in ys])
+    sc = _host_f32([1.0 / t.numel() for t in ys])
+    bf = _host_i64([_isbf(t) for t in ys])
+    call("osp_l1_sign_multi", a.ctypes.data, b.ctypes.data, o.ctypes.data, n.ctypes.data, sc.ctypes.data, bf.ctypes.data, len(ys), gscale)
+    return gbs
+
+
+def hinge_sum_multi(xs, sgns, out):
+    x, n = _host_i64([t.data_ptr() for t in xs]), _host_i64([t.numel() for t in xs])
+    sg, sc = _host_f32(sgns), _host_f32([1.0 / t.numel() for t in xs])
+    call("osp_hinge_sum_multi", x.ctypes.data, n.ctypes.data, sg.ctypes.data, sc.ctypes.data, len(xs), out)
+
+
+def hinge_grad_multi(xs, sgns, gscale):
+    dxs = [torch.empty_like(t) for t in xs]
+    x, o = _host_i64([t.data_ptr() for t in xs]), _host_i64([t.data_ptr() for t in dxs])
+    n, sg, sc = _host_i64([t.numel() for t in xs]), _host_f32(sgns), _host_f32([1.0 / t.numel() for t in xs])
+    call("osp_hinge_grad_multi", x.ctypes.data, o.ctypes.data, n.ctypes.data, sg.ctypes.data, sc.ctypes.data, len(xs), gscale)
+    return dxs
+
+
+def _wn_desc(rows):
+    import numpy as np
+    ptr = lambda t: 0 if t is None else t.data_ptr()                          # noqa: E731
+    return np.asarray([[ptr(r[k]) for k in range(9)] + list(r[9:13]) for r in rows], dtype=np.int64)
+
+
+def wnorm_fwd_multi(items):
+    """items: [(v, g, want_f32, want_t)] -> [(wn, wn32, wt, inv)]: the weight-norm packs of many convs in one launch per 32."""
+    outs, rows = [], []
+    for v, g, want_f32, want_t in items:
+        Cout, Cin, P, Q = v.shape
+        dev = v.device
+        wn = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.bfloat16)
+        wn32 = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.float32) if want_f32 else None
+        wt = torch.empty((Cin, Q, P, Cout), device=dev, dtype=torch.bfloat16) if want_t else None
+        inv = torch.empty((Cout,), device=dev, dtype=torch.float32)
+        outs.append((wn, wn32, wt, inv))
+        rows.append((v, g, wn, wn32, wt, inv, None, None, None, Cout, Cin, P, Q))
+    d = _wn_desc(rows)
+    call("osp_wnorm_fwd_multi", d.ctypes.data, len(rows))
+    return outs
+
+
+def wnorm_bwd_multi(items):
+    """items: [(dwn, v, g, inv, dv, dg)] (dv / dg accumulated), one launch per 32 convs."""
+    rows = []
+    for dwn, v, g, inv, dv, dg in items:
+        Cout, Cin, P, Q = v.shape
+        rows.append((v, g, None, None, None, inv, dwn, dv, dg, Cout, Cin, P, Q))
+    d = _wn_desc(rows)
+    call("osp_wnorm_bwd_multi", d.ctypes.data, len(rows))
 
 
 def param_bf16(p, transposed=False):

@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import precision, spectral
 from ..disc_ops import (MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, FeatureMatchSumFn, HingeSumFn,
-                        L1MeanFn)
+                        L1MeanFn, wnorm_pack_many)
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -169,9 +169,13 @@ class _Multi(nn.Module):
             return rs, gs, frs, fgs
         real_needs_grad = any(p.requires_grad for p in self.parameters())
         B = y.shape[0]
+        # weight-norm packs of every conv of this family in one launch (cached per optimiser epoch: the generator phase, its
+        # real / generated halves and the discriminator phase of a step share them)
+        packed = wnorm_pack_many([c for d in self.discriminators for c in list(d.convs) + [d.conv_post]], not precision.is_bf16())
         if precision.is_bf16() and _DISC_STREAMS and y.is_cuda:
+            ready = pre[1] if (pre is not None and not packed) else None      # packs just launched: the side streams wait for them too
             return self._forward_concurrent(pre[0] if pre is not None else torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join,
-                                            pre[1] if pre is not None else None, replay)
+                                            ready, replay)
         for d in self.discriminators:
             if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
                 o, fm = d(torch.cat([y, y_hat], 0))

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
-from .. import ops
+from .. import ops, precision
 from .alignments import (AlignmentModule, GaussianUpsampling, average_by_duration, expand_by_duration,
                          viterbi_decode)
 
@@ -69,17 +69,18 @@ class OptiSpeechGenerator(nn.Module):
         input_padding_mask = ~sequence_mask(x_lengths, Tt)                  # :96-102
         target_padding_mask = ~sequence_mask(mel_lengths, Tm)               # :99-103
 
-        h, _ = self.text_embedding(x)                                       # :106
-        h = self.encoder(h, input_padding_mask)                             # :109
-        if sids is not None:
-            h = h + self.sid_embed(sids.view(-1)).unsqueeze(1)              # :112-114
-        if lids is not None:
-            h = h + self.lid_embed(lids.view(-1)).unsqueeze(1)              # :115-117
+        with precision.index_path():        # exact-f32 forward of everything the (discrete) alignment depends on, in every mode
+            h, _ = self.text_embedding(x)                                       # :106
+            h = self.encoder(h, input_padding_mask)                             # :109
+            if sids is not None:
+                h = h + self.sid_embed(sids.view(-1)).unsqueeze(1)              # :112-114
+            if lids is not None:
+                h = h + self.lid_embed(lids.view(-1)).unsqueeze(1)              # :115-117
 
-        feats = mel.transpose(1, 2).contiguous()                            # :122
-        log_p_attn = self.alignment_module(text=h, feats=feats, text_lengths=x_lengths, feats_lengths=mel_lengths,
-                                           x_masks=input_padding_mask)      # :120-126
-        durations, path, bin_item = viterbi_decode(log_p_attn, x_lengths, mel_lengths)      # :127
+            feats = mel.transpose(1, 2).contiguous()                            # :122
+            log_p_attn = self.alignment_module(text=h, feats=feats, text_lengths=x_lengths, feats_lengths=mel_lengths,
+                                               x_masks=input_padding_mask)      # :120-126
+            durations, path, bin_item = viterbi_decode(log_p_attn, x_lengths, mel_lengths)      # :127
         # :174 -- issued here (side stream) so that it overlaps everything up to the loss sum; joined below
         forwardsum_loss, bin_loss = ops.AlignLossFn.apply(log_p_attn, x_lengths, mel_lengths, path, bin_item)
         duration_hat = self.duration_predictor(h.detach(), input_padding_mask)              # :128
@@ -87,7 +88,10 @@ class OptiSpeechGenerator(nn.Module):
         h, pitch_hat = self.pitch_predictor(h, input_padding_mask, p_avg)                   # :135
         h, energy_hat = self.energy_predictor(h, input_padding_mask, e_avg)                 # :136
         y = self.feature_upsampler(h, durations, x_lengths, mel_lengths, Tm)                # :139-141
-        y = self.decoder(y, target_padding_mask)                                            # :144
+        # :144 -- only the DETACHED decoder output is used below (:149-161: the vocoder sees segment.detach(), and nothing else
+        # reads y), so the decoder receives no gradient in the reference either: run it without a tape (no saved activations)
+        with torch.no_grad():
+            y = self.decoder(y.detach(), target_padding_mask)
 
         segment_size = min(self.segment_size, y.shape[1])                                   # :147
         num_frames = (mel_lengths - 4).to(torch.float32)                                    # :148
@@ -131,6 +135,12 @@ class OptiSpeechGenerator(nn.Module):
         x_lengths = x_lengths.to(dev).contiguous()
         Tt = x.shape[1]
         input_padding_mask = ~sequence_mask(x_lengths, Tt)
+        with precision.index_path():        # durations are integers: their inputs stay exact-f32 in every mode
+            return self._synthesise_body(x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0,
+                                         input_padding_mask)
+
+    def _synthesise_body(self, x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0,
+                         input_padding_mask):
         h, _ = self.text_embedding(x)                                       # :229
         h = self.encoder(h, input_padding_mask)                             # :232
         if (self.num_speakers > 1) and sids is None:
@@ -142,6 +152,7 @@ class OptiSpeechGenerator(nn.Module):
         if lids is not None:
             h = h + self.lid_embed(lids.view(-1)).unsqueeze(1)
         durations = self.duration_predictor.infer(h, input_padding_mask, factor=d_factor)   # :249
+        precision.leave_index_path()        # everything below is continuous: back to the configured precision
         if durations_override is not None:
             durations = durations_override.to(dev).masked_fill(input_padding_mask, 0)
         h, pitch = self.pitch_predictor.infer(h, input_padding_mask, p_factor)              # :252

@@ -72,17 +72,14 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         M = B * T
         dy2 = dy.contiguous().view(M, C)
         if _want(gamma):
-            t = dy2 * z
-            if rowf is not None:
-                t = t * rowf[:, None]
-            gsink(gamma).add_(t.sum(0))
-        W2g = W2 * gamma[:, None]
+            K.colsum_prod(dy2, z, rowf, gsink(gamma))            # dgamma[c] += sum_m rowf[m] dy[m,c] z[m,c]   (one launch)
         # du[m,k] = rowf[m] * sum_n dy[m,n] * gamma[n] W2[n,k] * gelu'(u[m,k])
         if ctx.lowp:
-            du = K.conv_gemm_bf16(dy2, K.pack_bf16(W2g, I, 1, C, (1, 0, I)), I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU_BWD,
-                                  rowscale=rowf, aux_in=u, out_bf16=True)
+            # gamma is folded into the transposed bf16 weight pack (kscale), the row factor into the bf16 copy of dy
+            du = K.conv_gemm_bf16(dy2, K.pack_bf16(W2.detach(), I, 1, C, (1, 0, I), kscale=gamma.detach()), I, M=M, Trows=M, Tin=M,
+                                  cin=C, epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u, out_bf16=True)
             if _want(W2):
-                dys = K.cast_bf16(dy2 * rowf[:, None] if rowf is not None else dy2)
+                dys = K.cast_bf16_rows(dy2, rowf)
                 K.conv_wgrad_bf16(dys, g, gsink(W2), gsink(b2) if _want(b2) else None, M=M, Trows=M, Tin=M, n=C, cin=I,
                                   oscale=gamma)
             dh = K.conv_gemm_bf16(du, K.param_bf16(W1, transposed=True), C, M=M, Trows=M, Tin=M, cin=I)
@@ -90,6 +87,7 @@ class ConvNeXtBlockFn(torch.autograd.Function):
                 K.conv_wgrad_bf16(du, K.cast_bf16(h.view(M, C)), gsink(W1), gsink(b1) if _want(b1) else None, M=M, Trows=M,
                                   Tin=M, n=I, cin=C)
         else:
+            W2g = W2 * gamma[:, None]
             du = K.conv_gemm(dy2, W2g, I, cin=C, w_strides=(1, 0, I), epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u)
             if _want(W2):
                 K.conv_wgrad(dy2, g, gsink(W2), gsink(b2) if _want(b2) else None, arow=rowf, oscale=gamma)

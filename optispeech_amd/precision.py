@@ -18,3 +18,42 @@ def get_precision() -> str:
 
 def is_bf16() -> bool:
     return _mode["v"] == "bf16"
+
+
+# ---- index-critical path
+# The monotonic alignment search, the durations it yields and the duration predictor's integer output at inference are
+# DISCRETE functions of the encoder output / the attention log-probabilities: bf16 operand rounding upstream moves a few
+# token boundaries (7 of 256 tokens on the reference-run full-size golden), after which nothing downstream is comparable with
+# the f32 reference.  north_star asks for bit-exact alignment / length-regulator indexing, so in bf16 mode the forward of the
+# text embedding -> encoder -> alignment module (and, in synthesise, the duration predictor) stays on the exact-f32 kernels:
+# ~75 GFLOP of the step's ~8 TFLOP (+0.9 ms at the BASELINE shape).  The same kernels on the same inputs as the f32 mode,
+# hence bit-identical indices by construction.  OSP_INDEX_PATH_F32=0 switches it off (pure bf16, as autocast would run it).
+import contextlib as _contextlib
+import os as _os
+
+_index_f32 = {"v": _os.environ.get("OSP_INDEX_PATH_F32", "1") != "0"}
+
+
+def set_index_path_f32(on: bool):
+    _index_f32["v"] = bool(on)
+
+
+_entered = {"v": False}
+
+
+@_contextlib.contextmanager
+def index_path():
+    if _mode["v"] == "bf16" and _index_f32["v"]:
+        _mode["v"], _entered["v"] = "f32", True
+        try:
+            yield
+        finally:
+            _mode["v"], _entered["v"] = "bf16", False
+    else:
+        yield
+
+
+def leave_index_path():
+    """Inside ``index_path()``: switch back to bf16 for the rest of the block (the context's exit is then a no-op)."""
+    if _entered["v"]:
+        _mode["v"] = "bf16"

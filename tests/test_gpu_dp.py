@@ -81,6 +81,9 @@ def _worker(rank, world, port, graph, q):
         m.graph_steps = graph
         m.graph_warmup_steps = 1
         og, od = m.optimizers()
+        for sch in m.lr_schedulers():                     # no warm-up (its first step has lr 0): the update must move the weights
+            sch.warmup = 0
+            sch.opt.lr = sch.base_lr
         assert m._reducers[0].active and m._reducers[0].world == 2
         assert torch.equal(og.arena.data, w0[0]) and torch.equal(od.arena.data, w0[1]), "replicas do not start from rank 0's weights"
         b, r01 = batches[rank]

@@ -60,6 +60,14 @@ REPLACES = {
     "osp_l1_sign": "autograd of the same",
     "osp_hinge_sum": "GeneratorLoss / DiscriminatorLoss hinge terms mean(clamp(1 -/+ d, min=0)): disc/loss.py:11-65",
     "osp_hinge_grad": "autograd of the same",
+    "osp_l1_sum_multi": "FeatureMatchingLoss.forward over ALL feature-map pairs of a discriminator family in one launch: disc/loss.py:68-85",
+    "osp_l1_sign_multi": "autograd of the same",
+    "osp_hinge_sum_multi": "GeneratorLoss / DiscriminatorLoss hinge terms of all sub-discriminators in one launch: disc/loss.py:11-65",
+    "osp_hinge_grad_multi": "autograd of the same",
+    "osp_wnorm_fwd_multi": "torch.nn.utils.weight_norm forward of many convs in one launch (see osp_wnorm_fwd)",
+    "osp_wnorm_bwd_multi": "autograd of weight_norm for many convs in one launch (see osp_wnorm_bwd)",
+    "osp_colsum_prod": "autograd of the layer scale `self.gamma * x`: ConvNeXtBlock.forward generator/modules/convnext.py:45-46",
+    "osp_cast_bf16_rows": "no reference counterpart: row-scaled f32 -> bf16 operand copy (drop-path / mask factor folded in)",
     "osp_last_error": "error text of the last failing call on this thread",
     "osp_abi_version": "ABI version of this library",
     "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
