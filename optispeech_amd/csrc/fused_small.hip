@@ -273,7 +273,7 @@ extern "C" int osp_wnorm_bwd_multi(const int64_t* desc_host, int64_t count, hipS
 }
 
 // ------------------------------------------------------------------------------------------------ ConvNeXt backward pieces
-// out[c] += sum_m rowf[m] * a[m, c] * b[m, c]      (C % 4 == 0; rowf may be null)
+// out[c] += sum_m rowf[m] * a[m, c] * b[m, c]      (C % 4 == 0; rowf may be null; b null = 1: a plain column sum)
 __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           const float* __restrict__ rowf, float* __restrict__ out, int64_t M, int C,
                                                           int rows_per_block) {
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restric
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub < nsub)
         for (int64_t m = m0 + sub; m < m1; m += nsub) {
-            const float4 x = *reinterpret_cast<const float4*>(a + m * C + col * 4), y = *reinterpret_cast<const float4*>(b + m * C + col * 4);
+            const float4 x = *reinterpret_cast<const float4*>(a + m * C + col * 4);
+            const float4 y = b ? *reinterpret_cast<const float4*>(b + m * C + col * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
             const float r = rowf ? rowf[m] : 1.f;
             acc.x = fmaf(r * x.x, y.x, acc.x); acc.y = fmaf(r * x.y, y.y, acc.y); acc.z = fmaf(r * x.z, y.z, acc.z); acc.w = fmaf(r * x.w, y.w, acc.w);
         }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restric
     }
 }
 extern "C" int osp_colsum_prod(const float* a, const float* b, const float* rowf, float* out, int64_t M, int64_t C, hipStream_t stream) {
-    OSP_CHECK_ARG(a && b && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "C must be a multiple of 4, <= 1024");
+    OSP_CHECK_ARG(a && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "C must be a multiple of 4, <= 1024");
     const int rpb = 256;
     hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream, a, b, rowf, out, M, (int)C, rpb);
     OSP_LAUNCH_CHECK();

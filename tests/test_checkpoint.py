@@ -129,3 +129,16 @@ def test_onnx_io_signature_matches_synthesise():
     out = m.synthesise(InferenceInputs(clean_text="", x=x, x_lengths=xl, d_factor=1.1, p_factor=1.6, e_factor=1.2))
     assert torch.equal(torch.as_tensor(out.wav).cpu(), wav.cpu()) and torch.equal(torch.as_tensor(out.durations).cpu(), durations.cpu())
     assert torch.equal(torch.as_tensor(out.wav_lengths).cpu(), wav_lengths.cpu())
+
+
+def test_hifigan_generator_state_dict_is_the_reference_schema(golden):
+    """The causal HiFi-GAN generator keeps the key names and shapes of the reference modules with
+    torch weight_norm applied (`*.conv.weight_g`, `*.deconv.weight_v`, `*.pad_buffer` ...): the golden's key list comes from the
+    reference's own modules (tools/make_golden_hifigan.py)."""
+    from optispeech_amd.model.hifigan import Generator
+    from tests.tools_cfg_hifigan import CFG
+    g = golden("hifigan_small")
+    sd = Generator(**CFG).state_dict()
+    assert list(sd) == g["keys"].tolist()
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(g["w_" + k].shape), k

@@ -135,10 +135,30 @@ def test_conv2d_bf16_forward_dgrad_wgrad(U, H, W, cin, cout, spec):
     assert relerr(dw.permute(0, 3, 1, 2), w.grad) < 1e-2 and relerr(db, b.grad) < 1e-2
 
 
+# Tolerances of the bf16 (= benchmarked) precision mode, and where they come from (tools/bf16_parity_diag.py prints the numbers):
+#   * indices (MAS path -> durations, segment starts, wav lengths): EXACT.  The index-critical path (text embedding -> encoder ->
+#     alignment module -> MAS; the duration predictor at inference) runs on the exact-f32 kernels in every mode
+#     (optispeech_amd/precision.py: index_path), i.e. the same kernels on the same inputs as the f32 parity mode.
+#   * waveform: bf16 has 8 significand bits (unit round-off 2^-9 = 2e-3).  The decoder + vocoder chain 12 ConvNeXt blocks and the
+#     head = 26 bf16-operand GEMMs with f32 accumulation and an f32 residual stream; measured max |dwav| / max |wav| = 1.9e-2
+#     (small golden) / 2.6e-2 (full size, B = 2), rms 5e-3.  Bound: 4e-2 max, 1e-2 rms.  (The reference's own `16-mixed` run differs
+#     from its f32 run by the same mechanism; north_star's 1e-3 is the f32-mode bound, tests/test_gpu_training.py.)
+#   * scalar losses: 3e-2 (adversarial / feature-matching terms through bf16 activations), acoustic-model losses 1e-3.
+#   * gradient norms: discriminator parameters 6 % (measured worst 2.4 %), acoustic-model parameters 3e-2 (measured 1.4e-2).
+#     Vocoder parameter gradients are NOT compared in this mode: the log-STFT-magnitude term's gradient is chaotic at the golden's
+#     state (f64 oracle: 1e-4 relative noise on wav_hat turns d(mag)/d(wav_hat) to cosine -0.47, tools/bf16_stft_diag.py); they
+#     are compared per loss component in test_gan_components_bf16_vs_f32_grads below.
+WAV_MAX, WAV_RMS = 4e-2, 1e-2
+
+
+def _wav_err(got, want):
+    got, want = got.detach().double().cpu(), torch.as_tensor(np.asarray(want)).double()
+    return ((got - want).abs().max() / want.abs().max()).item(), ((got - want).norm() / want.norm()).item()
+
+
 def test_gan_step_bf16_mode_vs_reference_golden(golden):
-    """The hand-written discriminator stacks (bf16 mode) against values produced by the REFERENCE (f32 CPU): losses within
-    3 %, discriminator gradient norms within 15 % -- the bf16-operand tolerance, on top of the exact f32-mode test in
-    tests/test_gpu_training.py."""
+    """The benchmarked precision against values produced by the REFERENCE (f32 CPU): exact indices, waveform / losses / gradient
+    norms within the bf16 bounds stated above -- no outlier allowance."""
     from optispeech_amd import precision
     from tests.test_gpu_training import _small_model, _ref_grads
     g = golden("gen_small_gan")
@@ -152,16 +172,25 @@ def test_gan_step_bf16_mode_vs_reference_golden(golden):
         for p in m.discriminator.parameters():
             p.requires_grad_(False)
         loss_g, (wav, wav_hat) = m.training_step_g(batch, True, logs)
+        aux = m._last_gen_outputs["_aux"]
         assert np.array_equal(m._last_gen_outputs["start_idx"].cpu().numpy(), g["start_idx"])
+        assert np.array_equal(aux["durations"].cpu().numpy(), g["durations"])
+        assert relerr(wav, torch.from_numpy(g["wav"])) == 0.0                 # index-exact ground-truth segment
+        wmax, wrms = _wav_err(wav_hat, g["wav_hat"])
+        assert wmax < WAV_MAX and wrms < WAV_RMS, (wmax, wrms)
         for k in ("loss_gen_mp", "loss_gen_mrd", "loss_fm_mp", "loss_fm_mrd", "mr_stft_loss"):
             got, want = logs["gen_adv_loss/train_" + k].item(), float(g["genlog_" + k])
             assert abs(got - want) <= 3e-2 * abs(want) + 1e-3, (k, got, want)
         assert abs(loss_g.item() - float(g["loss_g"])) <= 2e-2 * abs(float(g["loss_g"]))
-        # Generator gradients are NOT compared here: the log-STFT-magnitude term's gradient is chaotic at this state
-        # (f64 oracle: 1e-4 relative noise on wav_hat turns d(mag)/d(wav_hat) to cosine -0.47, tools/bf16_stft_diag.py),
-        # so any operand rounding upstream decorrelates it.  The adversarial / feature-matching gradients through the
-        # hand-written stacks are compared per component in test_gan_components_bf16_vs_f32_grads below.
         loss_g.backward()
+        gg = _ref_grads(m.generator)
+        checked = 0
+        for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
+            if k.startswith("vocoder.") or n < 1e-6:
+                continue
+            assert abs(gg[k].double().norm().item() - n) <= 3e-2 * n, (k, gg[k].double().norm().item(), n)
+            checked += 1
+        assert checked > 60
         for p in m.discriminator.parameters():
             p.requires_grad_(True)
         m.optimizers()[1].zero_grad()
@@ -169,13 +198,74 @@ def test_gan_step_bf16_mode_vs_reference_golden(golden):
         assert abs(loss_d.item() - float(g["loss_d"])) <= 2e-2 * abs(float(g["loss_d"]))
         loss_d.backward()
         gd = _ref_grads(m.discriminator)
-        bad = 0
         for k, n in zip(g["grad_d_names"].tolist(), g["grad_d_norms"].tolist()):
-            if n > 1e-4 and abs(gd[k].double().norm().item() - n) > 0.15 * n:
-                bad += 1
-        assert bad <= 3, bad
+            if n > 1e-4:
+                assert abs(gd[k].double().norm().item() - n) <= 6e-2 * n, (k, gd[k].double().norm().item(), n)
     finally:
         precision.set_precision("f32")
+
+
+def test_full_size_generator_bf16_mode_vs_reference_golden(golden):
+    """BASELINE widths (B = 2, T_text <= 128, T_mel <= 800) at the benchmarked precision against the reference-run golden:
+    durations / segment starts exact, every loss within 1e-3, acoustic-model gradient norms within 3e-2, and the waveform within
+    the bf16 bound of the f32-mode run of the same kernels (which the f32 test pins to the reference's checksums)."""
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_generator
+    from oracle import schema as S
+    from tests.test_gpu_generator import _ref_grad
+    g = golden("gen_full_b2")
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            precision.set_precision(mode)
+            gen = make_generator(ModelConfig().no_dropout()).to(DEV).train()
+            W = S.make_weights(S.generator_schema(S.Cfg()), int(g["seed"]))
+            gen.load_state_dict({k[len("generator."):]: v for k, v in W.items()})
+            gen.segment_rand01 = torch.from_numpy(g["rand01"])
+            b = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith("in_") and k != "in_wav"}
+            out = gen(b["x"], b["x_lengths"], b["mel"], b["mel_lengths"], b["pitches"], b["energies"], None, None)
+            out["loss"].backward()
+            res[mode] = (out, gen)
+    finally:
+        precision.set_precision("f32")
+    out, gen = res["bf16"]
+    assert np.array_equal(out["_aux"]["durations"].cpu().numpy(), g["durations"])
+    assert np.array_equal(out["start_idx"].cpu().numpy(), g["start_idx"])
+    for k in ("loss", "align_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert abs(out[k].item() - float(g[k])) <= 1e-3 * abs(float(g[k])), (k, out[k].item(), float(g[k]))
+    wmax, wrms = _wav_err(out["wav_hat"], res["f32"][0]["wav_hat"].detach().cpu())
+    assert wmax < WAV_MAX and wrms < WAV_RMS, (wmax, wrms)
+    assert abs(out["wav_hat"].double().norm().item() - float(g["wav_hat_l2"])) <= 2e-3 * float(g["wav_hat_l2"])
+    for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
+        if k.startswith("vocoder.") or n < 1e-6:
+            continue
+        got = _ref_grad(gen, k)
+        assert abs(got.double().norm().item() - n) <= 3e-2 * n, (k, got.double().norm().item(), n)
+
+
+def test_synthesise_bf16_mode_vs_reference_golden(golden):
+    """synthesise() at the precision bench.py measures RTF in: integer durations / wav lengths exact, waveform within the bf16 bound."""
+    from optispeech_amd import precision
+    from optispeech_amd.config import make_generator
+    from oracle import schema as S
+    from tests.test_gpu_generator import _small_cfg
+    g = golden("synth_small")
+    precision.set_precision("bf16")
+    try:
+        gen = make_generator(_small_cfg()).to(DEV).eval()
+        W = S.make_weights(S.generator_schema(S.SMALL), int(g["seed"]))
+        W["generator.duration_predictor.linear.bias"].fill_(float(g["dur_bias"]))
+        gen.load_state_dict({k[len("generator."):]: v for k, v in W.items()})
+        out = gen.synthesise(torch.from_numpy(g["in_x"]).to(DEV), torch.from_numpy(g["in_x_lengths"]), d_factor=1.1,
+                             p_factor=1.6, e_factor=1.2)
+        assert precision.get_precision() == "bf16"
+    finally:
+        precision.set_precision("f32")
+    assert np.array_equal(out["durations"].numpy(), g["durations"])
+    assert np.array_equal(out["wav_lengths"].numpy(), g["wav_lengths"])
+    wmax, wrms = _wav_err(out["wav"], g["wav"])
+    assert wmax < WAV_MAX and wrms < WAV_RMS, (wmax, wrms)
+    assert relerr(out["pitch"], torch.from_numpy(g["pitch"])) < 5e-3 and relerr(out["energy"], torch.from_numpy(g["energy"])) < 5e-3
 
 
 @pytest.mark.parametrize("comp", ["gen_mp", "fm_mp", "gen_mrd", "fm_mrd"])

@@ -1,0 +1,147 @@
+"""the dilated / transposed 1-D convolutions of the HiFi-GAN-style vocoder (csrc/a16_conv.hip) against
+torch's functional ops, and the causal generator built from them against a golden produced by RUNNING THE REFERENCE's layer
+modules (tools/make_golden_hifigan.py) -- forward, every gradient, and the chunked streaming inference()."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+TOL = {"f32": 2e-4, "bf16": 2e-2}
+
+
+@pytest.fixture(params=["f32", "bf16"])
+def mode(request):
+    from optispeech_amd import precision
+    precision.set_precision(request.param)
+    yield request.param
+    precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k,dil", [(2, 50, 32, 32, 3, 1), (2, 50, 32, 32, 3, 3), (3, 77, 16, 24, 7, 5), (1, 40, 64, 64, 11, 5),
+                                                 (2, 33, 80, 32, 7, 1), (2, 64, 8, 1, 7, 1)])
+def test_dilated_causal_conv1d_vs_torch(mode, B, T, cin, cout, k, dil):
+    """y = F.conv1d(F.pad(x, ((k-1)*dil, 0)), w, b, dilation=dil) and its three gradients (CausalConv1d, conv_layer.py:118-159)."""
+    from optispeech_amd.model import hifigan as H
+    x = rnd(B, cin, T, seed=1).requires_grad_(True)
+    w = rnd(cout, cin, k, seed=2, scale=1.0 / np.sqrt(cin * k)).requires_grad_(True)
+    b = rnd(cout, seed=3, scale=0.1).requires_grad_(True)
+    pad = (k - 1) * dil
+    y = F.conv1d(F.pad(x, (pad, 0)), w, b, dilation=dil)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xg = x.detach().transpose(1, 2).contiguous().to(DEV)
+    wn = w.detach().permute(0, 2, 1).contiguous().to(DEV)                        # native (Cout, k, Cin)
+    got = H.conv1d_dilated_fwd(xg, wn, b.detach().to(DEV), k, dil, pad)
+    assert rel(got.transpose(1, 2), y) < TOL[mode]
+    dx, dw, db = H.conv1d_dilated_bwd(gy.transpose(1, 2).contiguous().to(DEV), xg, wn, k, dil, pad, True, True)
+    assert rel(dx.transpose(1, 2), x.grad) < TOL[mode]
+    assert rel(dw.permute(0, 2, 1), w.grad) < TOL[mode] and rel(db, b.grad) < TOL[mode]
+
+
+@pytest.mark.parametrize("B,T,cin,cout,s", [(2, 20, 32, 16, 2), (2, 17, 64, 32, 8), (3, 9, 16, 8, 4), (1, 30, 32, 32, 3)])
+def test_conv_transpose1d_vs_torch(mode, B, T, cin, cout, s):
+    """F.conv_transpose1d(x, w, b, stride=s) with k = 2s (and k = 3s for the last case) and its gradients."""
+    from optispeech_amd.model import hifigan as H
+    k = 2 * s if s != 3 else 9
+    x = rnd(B, cin, T, seed=1).requires_grad_(True)
+    w = rnd(cin, cout, k, seed=2, scale=1.0 / np.sqrt(cin * k / s)).requires_grad_(True)
+    b = rnd(cout, seed=3, scale=0.1).requires_grad_(True)
+    y = F.conv_transpose1d(x, w, b, stride=s)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xg = x.detach().transpose(1, 2).contiguous().to(DEV)
+    wt = w.detach().permute(0, 2, 1).contiguous().to(DEV)                        # (Cin, k, Cout)
+    got = H.conv_transpose1d_fwd(xg, wt, b.detach().to(DEV), k, s)
+    assert got.shape[1] == (T - 1) * s + k and rel(got.transpose(1, 2), y) < TOL[mode]
+    dx, dwt, db = H.conv_transpose1d_bwd(gy.transpose(1, 2).contiguous().to(DEV), xg, wt, k, s, True, True)
+    assert rel(dx.transpose(1, 2), x.grad) < TOL[mode]
+    assert rel(dwt.permute(0, 2, 1), w.grad) < TOL[mode] and rel(db, b.grad) < TOL[mode]
+
+
+def test_causal_modules_vs_torch_functional(mode):
+    """CausalConv1d / CausalConvTranspose1d with weight norm: zero left pad + dilation, replicate pad + crop [s:-s]."""
+    from optispeech_amd.model.hifigan import CausalConv1d, CausalConvTranspose1d
+    torch.manual_seed(0)
+    c = CausalConv1d(16, 24, 5, dilation=3).to(DEV)
+    d = CausalConvTranspose1d(24, 8, kernel_size=8, stride=4).to(DEV)
+    x = rnd(2, 16, 31, seed=5).to(DEV).requires_grad_(True)
+    y = d(F.leaky_relu(c(x), 0.1))
+    gy = rnd(*y.shape, seed=6).to(DEV)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), {n: p.grad.clone() for n, p in list(c.named_parameters()) + list(d.named_parameters())})
+    # torch restatement on the same parameters
+    def wn(m):
+        v = m.weight_v
+        return v * (m.weight_g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    for p in list(c.parameters()) + list(d.parameters()):
+        p.grad = None
+    x2 = x.detach().clone().requires_grad_(True)
+    h = F.conv1d(F.pad(x2, (c.pad_length, 0)), wn(c.conv), c.conv.bias, dilation=3)
+    h = F.leaky_relu(h, 0.1)
+    h = F.pad(h, (d.pad_length, 0), mode="replicate")
+    y2 = F.conv_transpose1d(h, wn(d.deconv), d.deconv.bias, stride=4)[:, :, 4:-4]
+    y2.backward(gy)
+    assert y2.shape == got[0].shape == (2, 8, 31 * 4)
+    assert rel(got[0], y2) < TOL[mode] and rel(got[1], x2.grad) < 2 * TOL[mode]
+    for n, p in list(c.named_parameters()) + list(d.named_parameters()):
+        assert rel(got[2][n], p.grad) < 3 * TOL[mode], n
+
+
+def _golden_generator(g):
+    from tests.tools_cfg_hifigan import CFG
+    from optispeech_amd.model.hifigan import Generator
+    m = Generator(**CFG).to(DEV)
+    sd = {k: torch.from_numpy(g["w_" + k]) for k in g["keys"].tolist()}
+    assert set(sd) == set(m.state_dict()), set(sd) ^ set(m.state_dict())                  # the reference's key schema
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def test_generator_vs_reference_golden(mode, golden):
+    """Forward and every gradient of the causal generator against the reference-run golden (f32: inside north_star's 1e-3)."""
+    g = golden("hifigan_small")
+    m = _golden_generator(g)
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    (y * torch.from_numpy(g["G"]).to(DEV)).sum().backward()
+    tol = 1e-3 if mode == "f32" else 4e-2
+    assert rel(y, torch.from_numpy(g["y"])) < tol
+    assert rel(x.grad, torch.from_numpy(g["dx"])) < tol
+    n = 0
+    for k, p in m.named_parameters():
+        want = torch.from_numpy(g["g_" + k])
+        if want.abs().max() > 1e-6:
+            assert rel(p.grad, want) < 2 * tol, k
+            n += 1
+    assert n > 100
+
+
+def test_streaming_inference_vs_reference_golden(golden):
+    """StreamGenerator.inference(): chunks of 5 / 7 / 11 frames through the pad buffers == the reference's streaming output."""
+    from optispeech_amd import precision
+    precision.set_precision("f32")
+    g = golden("hifigan_small")
+    m = _golden_generator(g).eval()
+    x = torch.from_numpy(g["x"])[:1].to(DEV)
+    outs, pos = [], 0
+    for n in g["stream_chunks"].tolist():
+        outs.append(m.inference(x[:, :, pos:pos + n]))
+        pos += n
+    y = torch.cat(outs, -1)
+    assert rel(y, torch.from_numpy(g["y_stream"])) < 1e-3
+    m.reset_buffer()
+    again = m.inference(x[:, :, :5])
+    assert rel(again, torch.from_numpy(g["y_stream"])[:, :, :again.shape[-1]]) < 1e-3

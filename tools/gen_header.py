@@ -68,6 +68,10 @@ REPLACES = {
     "osp_wnorm_bwd_multi": "autograd of weight_norm for many convs in one launch (see osp_wnorm_bwd)",
     "osp_colsum_prod": "autograd of the layer scale `self.gamma * x`: ConvNeXtBlock.forward generator/modules/convnext.py:45-46",
     "osp_cast_bf16_rows": "no reference counterpart: row-scaled f32 -> bf16 operand copy (drop-path / mask factor folded in)",
+    "osp_conv1d_dilated_fwd": "CausalConv1d / nn.Conv1d(dilation=d): vocoder/streaming_hifigan/modules/conv_layer.py:18-60,118-159 (callers residual_block.py:44-70)",
+    "osp_conv1d_dilated_bwd": "autograd of the same (input, weight and bias gradients)",
+    "osp_conv_transpose1d_fwd": "CausalConvTranspose1d / nn.ConvTranspose1d(stride s): vocoder/streaming_hifigan/modules/conv_layer.py:63-115,162-200",
+    "osp_conv_transpose1d_bwd": "autograd of the same (input and weight gradients)",
     "osp_last_error": "error text of the last failing call on this thread",
     "osp_abi_version": "ABI version of this library",
     "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
