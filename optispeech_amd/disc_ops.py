@@ -289,6 +289,9 @@ def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds
             break
     if wn_items:
         K.wnorm_bwd_multi(wn_items)
+        if all(need_w):
+            from .dp import reduce_ready
+            reduce_ready(list(params))                       # data parallel: this stack's gradient slice is complete -> all-reduce it now
     if any(need_w) and g_stream_is_side():
         # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
         # engine does not know that the stream backward() was called from must wait for this node's stream: say so.

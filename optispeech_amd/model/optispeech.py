@@ -121,6 +121,9 @@ class OptiSpeech(nn.Module):
             opts, scheds = self.configure_optimizers()
             self._opts = (opts, [s["scheduler"] for s in scheds])
             self._reducers = (GradReducer(), GradReducer())
+            for o, r in zip(opts, self._reducers):
+                if hasattr(o, "arena"):
+                    o.arena.reducer = r
             # data parallelism keeps replicas identical by construction from here on (same averaged gradients, same update);
             # the starting point is rank 0's weights and buffers, whatever each rank seeded or loaded
             self._reducers[0].broadcast_from_rank0([o.arena.data for o in opts] + [b for b in self.buffers()])
@@ -164,12 +167,15 @@ class OptiSpeech(nn.Module):
             return graphed_training_step(self, batch, batch_idx)
         st = self._new_step_state(batch_idx)
         red_g, red_d = self._reducers
+        # gradients are exchanged once per optimiser step: on the batches that only accumulate, nothing is all-reduced
+        red_g.eager_ranges = red_d.eager_ranges = st.apply
         rng.advance()
         # ---- generator phase (discriminator weights frozen = toggle_optimizer; training_step_g freezes them after the
         # shared real-wave pass, which needs the parameter graph for the discriminator phase)
         self._stage_g_forward(st, batch)
         self._stage_g_backward(st)
-        red_g.start(self.optimizers()[0].arena.grad)
+        if st.apply:
+            red_g.start_rest(self.optimizers()[0].arena.grad)
         # ---- discriminator phase (independent of the G update, so it overlaps the G-gradient all-reduce).
         # With ``pipeline_steps`` its loss / backward / optimizer step are issued from a second "calling" stream: the
         # calling stream proper only carries the generator work, so the NEXT step's generator forward (which needs the
@@ -180,7 +186,10 @@ class OptiSpeech(nn.Module):
         if st.train_d:
             with dctx:
                 self._stage_d(st, batch)
-                red_d.start(self.optimizers()[1].arena.grad)
+                # every sub-discriminator's slice was already launched when its backward finished (dp.reduce_ready, from
+                # disc_ops._stack_backward): gradient-ready order, overlapping the other stacks' backward; this adds the rest
+                if st.apply:
+                    red_d.start_rest(self.optimizers()[1].arena.grad)
         red_g.wait()
         self._stage_opt_g(st)
         if st.train_d:

@@ -28,10 +28,14 @@ class FlatArena:
         self.offsets = offs
         self.data = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        #: data-parallel reducer of this arena's gradients (set by the trainer); backward code that knows a parameter range is
+        #: complete launches that range's all-reduce right away (optispeech_amd/dp.py: reduce_ready)
+        self.reducer = None
         for p, o in zip(self.params, offs):
             self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
             p.data = self.data[o:o + p.numel()].view(p.shape)
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._osp_arena = (self, o)
 
     def zero_grad(self):
         self.grad.zero_()

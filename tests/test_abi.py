@@ -65,3 +65,23 @@ def test_native_marshalling_module_covers_the_header():
     import torch
     with pytest.raises(RuntimeError, match="not on the GPU"):
         fast.call(i, 0, *([torch.zeros(4)] * nargs))
+
+
+def _build_comm_example(out):
+    """hipcc: the C++ host program of tests/native/comm_example.cpp against include/osp.h + libosp_hip.so (nothing from torch)."""
+    from optispeech_amd.build import build
+    lib = build(verbose=False)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", f"-I{os.path.join(ROOT, 'include')}",
+                           os.path.join(ROOT, "tests", "native", "comm_example.cpp"), "-o", out, f"-L{os.path.dirname(lib)}", "-losp_hip",
+                           f"-Wl,-rpath,{os.path.dirname(lib)}"])
+    return out
+
+
+def test_native_comm_example_compiles_and_links(tmp_path):
+    """The non-torch gradient-exchange example INTEGRATION.md shows is real code: it compiles against the generated header and
+    links against the library's osp_comm_* / osp_allreduce_bucket symbols (it is RUN by tests/test_gpu_dp.py on the GPU box)."""
+    exe = _build_comm_example(os.path.join(tmp_path, "comm_example"))
+    assert os.path.getsize(exe) > 0
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", exe], text=True)
+    for n in ("osp_comm_unique_id", "osp_comm_init", "osp_allreduce_bucket", "osp_comm_destroy"):
+        assert n in syms, n

@@ -40,6 +40,13 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, local)
     want = sum(gathered)
     ok = torch.allclose(arena.grad, want, rtol=1e-6, atol=1e-7)
+    # gradient-ready ranges (launched from inside the backward in the real step) + the closing remainder == one full all-reduce
+    arena.grad.copy_(local)
+    red.start_range(arena.grad, 16, 200)
+    red.start_range(arena.grad, 400, 420)
+    red.start_rest(arena.grad)
+    red.wait()
+    ok = ok and torch.allclose(arena.grad, want, rtol=1e-6, atol=1e-7) and not red._covered
     logs = torch.tensor([float(rank), 2.0 * rank + 1.0])
     red.mean_scalars(logs)
     ok = ok and torch.allclose(logs, torch.tensor([(world - 1) / 2.0, float(world)]))

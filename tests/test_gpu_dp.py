@@ -137,3 +137,30 @@ def test_two_rank_training_step_equals_mean_of_single_rank_gradients(graph):
     assert res[0][3] == res[1][3] and all(np.isfinite(v) for v in res[0][3].values())
     for p in procs:
         assert p.exitcode == 0
+
+
+def test_native_comm_c_abi_single_rank(tmp_path):
+    """The RCCL communicator behind the C ABI (csrc/comm.cpp) on this box's one GPU: (1) the C++ host example of
+    tests/native/comm_example.cpp runs (unique id -> init -> all-reduce -> destroy, sum over 1 rank = identity), (2) the same entry
+    points through GradReducer's native path (OSP_DP_BACKEND=native), with gradient-ready ranges + remainder."""
+    import subprocess
+    from tests.test_abi import _build_comm_example
+    exe = _build_comm_example(os.path.join(tmp_path, "comm_example"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    from optispeech_amd import dp
+    world = dp.init_native_comm()
+    try:
+        assert world == 1
+        red = dp.GradReducer(bucket_bytes=1 << 20)
+        assert red.native and red.world == 1 and not red.active
+        red._force_active = True
+        g = torch.randn(3_000_001, device="cuda")
+        want = g.clone()
+        red.start_range(g, 1024, 500_000)
+        red.start_rest(g)
+        red.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+    finally:
+        dp.destroy_native_comm()

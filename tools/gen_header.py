@@ -72,6 +72,11 @@ REPLACES = {
     "osp_conv1d_dilated_bwd": "autograd of the same (input, weight and bias gradients)",
     "osp_conv_transpose1d_fwd": "CausalConvTranspose1d / nn.ConvTranspose1d(stride s): vocoder/streaming_hifigan/modules/conv_layer.py:63-115,162-200",
     "osp_conv_transpose1d_bwd": "autograd of the same (input and weight gradients)",
+    "osp_comm_unique_id": "rendezvous id of the gradient communicator (Lightning DDP strategy setup, configs/trainer/ddp.yaml:4-9)",
+    "osp_comm_init": "DDP process-group construction for the gradient all-reduce (configs/trainer/ddp.yaml:4-9)",
+    "osp_comm_world": "number of ranks of the initialised communicator (0 = none)",
+    "osp_allreduce_bucket": "DDP's bucketed gradient all-reduce (torch.nn.parallel.DistributedDataParallel reducer behind manual_backward, base_lightning_module.py:99,119)",
+    "osp_comm_destroy": "process-group teardown",
     "osp_last_error": "error text of the last failing call on this thread",
     "osp_abi_version": "ABI version of this library",
     "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
