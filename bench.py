@@ -167,11 +167,18 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7):
     dur = torch.randint(4, 9, (n_sent, 128), generator=g)
     inputs = InferenceInputs(clean_text="", x=x, x_lengths=x_len, d_factor=1.0, p_factor=1.0, e_factor=1.0)
     model.eval()
-    outs = [model.synthesise(inputs, durations_override=dur) for _ in range(3)]
+    res = {}
+    for graph in (False, True):                                 # eager launches, then the hipGraph-captured decode (configs[4])
+        model.generator.graph_decode = graph
+        res[graph] = [model.synthesise(inputs, durations_override=dur) for _ in range(4)][-1]
+    model.generator.graph_decode = False
     model.train()
-    o = outs[-1]
+    o, oe = res[True], res[False]
+    same = bool(torch.equal(torch.as_tensor(o.wav), torch.as_tensor(oe.wav)))
     audio_s = float(o.wav_lengths.sum()) / model.sample_rate
-    return {"rtf": o.rtf, "am_rtf": o.am_rtf, "v_rtf": o.v_rtf, "latency_ms": o.latency, "sentences": n_sent,
+    return {"decode": "hipGraph-captured (upsampler + decoder graph, vocoder graph; eager text encoder / predictors / one length sync)",
+            "eager": {"rtf": oe.rtf, "latency_ms": oe.latency}, "graph_output_equals_eager": same,
+            "rtf": o.rtf, "am_rtf": o.am_rtf, "v_rtf": o.v_rtf, "latency_ms": o.latency, "sentences": n_sent,
             "padded_audio_s": o.wav.shape[-1] / model.sample_rate, "total_audio_s": audio_s,
             "aggregate_audio_s_per_s": audio_s / (o.latency * 1e-3)}
 

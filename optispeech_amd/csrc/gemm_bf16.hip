@@ -27,14 +27,20 @@ __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
 // BM_ = 256: 4 waves of 128x64 (128 accumulator registers), three 48 KB stages, 1 workgroup / CU, prefetch distance 2.
 //   Per k-slab a CU then reads (128 + 64) * 64 * 2 B * 4 waves = 96 KB of fragments for 2 * 256*128*64 flop, i.e. LDS
 //   traffic per flop is 2/3 of the 128x128 tile's (which is LDS-bandwidth bound: 96 KB + 32 KB DMA per 512 MFMA clocks).
-template <int BM_, int NST, int BN_ = TBN>
+// NW = 8 (512 threads, two waves per SIMD): 256x256 tiles as 2 (M) x 4 (N) waves of 128x64 -- per k-step a wave reads
+//   (128 + 64) rows x 32 B of fragments for 8 MFMAs (the 4-wave 128x128 tile: (64 + 64) x 32 B for 4), and a CU stages
+//   (256 + 256) x 128 B per slab for 4x the flops of a 128x128 tile (2x fewer HBM / L2 bytes per flop); two 64 KB stages,
+//   one barrier per slab, 1 workgroup / CU whose second wave per SIMD covers the other's LDS latency.
+template <int BM_, int NST, int BN_ = TBN, int NW = 4>
 __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem) {
     const GemmB pp = gemm_select_phase(pin);
-    constexpr int RA = BM_ / 32, RB = BN_ / 32, TM_ = BM_ / 64, TN_ = BN_ / 64;   // rows staged per thread (A, B); 32x32 tiles per wave along M
+    constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
+    constexpr int RA = BM_ / (8 * NW), RB = BN_ / (8 * NW), TM_ = BM_ / (32 * WM_), TN_ = BN_ / (32 * WN_);   // rows staged per thread (A, B); 32x32 tiles per wave
+    static_assert(TM_ == 2 || TM_ == 4, "wave tile is 64 or 128 rows");
     unsigned short* As = smem;                       // [NST][BM_][64]
     unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][BN_][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * (BM_ / 2), wn0 = (wave & 1) * (BN_ / 2);
+    const int wm0 = (wave / WN_) * (BM_ / WM_), wn0 = (wave % WN_) * (BN_ / WN_);
     int mb_, nb_;
     xcd_tile(mb_, nb_);
     const int m0 = mb_ * BM_, n0 = nb_ * BN_;
@@ -205,6 +211,11 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp
 // narrow outputs (N <= 64: the DiscriminatorR stacks): 128x64 tiles, 48 KB of LDS -> 3 workgroups / CU
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const GemmB pp) {
     conv_gemm_bf16_glds_body<128, 2, 64>(pp, glds_smem);
+}
+// 8 waves, 256x256 tiles, two 64 KB stages (the epilogue's wave-private staging tiles need 144 KB: that is what is allocated)
+#define GLDS8_LDS (8 * 128 * (32 * 2 + 8) * 2)
+__global__ __launch_bounds__(512) void conv_gemm_bf16_glds8_kernel(const GemmB pp) {
+    conv_gemm_bf16_glds_body<256, 2, 256, 8>(pp, glds_smem);
 }
 // one workgroup per CU (144 KB of LDS): let the register allocator use the whole 512-entry file of a single wave / SIMD
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_bf16_glds256_kernel(const GemmB pp) {
@@ -436,6 +447,28 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         return OSP_OK;
     }
     if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 128) {
+        // 8-wave 256x256 tiles when they still give every CU work: OSP_GEMM_W8 = 0 (never) / 1 (whenever >= 1 tile per 2 CUs) /
+        // unset: the measured crossover (tools/gemm_w8_probe.py)
+        static int w8 = -2, w8_attr = 0;
+        static int64_t w8_min = 0;
+        if (w8 == -2) {
+            const char* e = getenv("OSP_GEMM_W8"); w8 = e ? atoi(e) : -1;
+            const char* t = getenv("OSP_GEMM_W8_MIN"); w8_min = t ? atoll(t) : 160;
+        }
+        const int64_t t256 = cdiv(M, 256) * cdiv(N, 256) * batch;
+        // measured (tools/gemm_w8_probe.py, profiles/r02_gemm_w8_probe.txt): +23..30 % where the reduction is long (K >= 2560: the
+        // 512->1024 and 1024->1024 DiscriminatorP layers at M ~ 13k: 760 -> 950-990 TFLOP/s), -20 % on short-K / narrow layers
+        // (K = 640, N = 512: the 256x256 prologue / epilogue is not amortised), neutral at half batch (too few tiles: not taken)
+        if (w8 != 0 && N >= 256 && t256 >= (w8 == 1 ? 128 : w8_min) && (w8 == 1 || taps * Cin >= 2304)) {
+            if (!w8_attr) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
+                w8_attr = 1;
+            }
+            const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
+            hipLaunchKernelGGL(conv_gemm_bf16_glds8_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
+            OSP_LAUNCH_CHECK();
+            return OSP_OK;
+        }
         static int big = -1, attr_done = 0;
         if (big < 0) { const char* e = getenv("OSP_GEMM_BIG"); big = (e && atoi(e) == 1) ? 1 : 0; }
         if (!attr_done) {

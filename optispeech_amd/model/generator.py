@@ -58,6 +58,9 @@ class OptiSpeechGenerator(nn.Module):
             self.lid_embed = torch.nn.Embedding(self.num_languages, dim)
         #: test hook: fixed uniform draws in [0,1) for the segment starts (None = torch.rand)
         self.segment_rand01 = None
+        #: synthesise(): replay the shape-static part (upsampler, decoder, vocoder) from captured hipGraphs
+        self.graph_decode = __import__("os").environ.get("OSP_GRAPH_DECODE", "0") == "1"
+        self._decode_graphs = {}
 
     # ------------------------------------------------------------------------------------------ training forward
     def forward(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids):
@@ -123,6 +126,46 @@ class OptiSpeechGenerator(nn.Module):
                          "energy_hat": energy_hat, "decoder_out": y, "segment": segment,
                          "bin_loss": bin_loss.detach(), "forwardsum_loss": forwardsum_loss.detach()}}
 
+    # ------------------------------------------------------------------------------------------ captured decode
+    def _graphed_decode(self, h, durations, x_lengths, y_lengths, y_max, am_t0, dev):
+        """Upsampler + decoder, then the vocoder, replayed from hipGraphs captured per (B, T_text, y_max, precision).  Returns
+        (wav, acoustic-model ms, vocoder ms) with the reference's two timing points."""
+        key = (tuple(h.shape), int(y_max), precision.get_precision())
+        ent = self._decode_graphs.get(key)
+        if ent is None:
+            if len(self._decode_graphs) >= 8:
+                self._decode_graphs.pop(next(iter(self._decode_graphs)))
+            st = {"h": h.clone(), "d": durations.clone(), "xl": x_lengths.clone(), "yl": y_lengths.clone()}
+
+            def am():
+                mask = ~sequence_mask(st["yl"], y_max)
+                return self.decoder(self.feature_upsampler(st["h"], st["d"], st["xl"], st["yl"], y_max), mask), mask
+
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):                                  # warm-up: allocator pools, weight packs, kernel attributes
+                    y, mask = am()
+                    self.vocoder(y, f0=None, padding_mask=mask)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g_am, g_voc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_am):
+                st["y"], st["mask"] = am()
+            with torch.cuda.graph(g_voc, pool=g_am.pool()):
+                st["wav"] = self.vocoder(st["y"], f0=None, padding_mask=st["mask"])
+            ent = self._decode_graphs[key] = (st, g_am, g_voc)
+        st, g_am, g_voc = ent
+        st["h"].copy_(h); st["d"].copy_(durations); st["xl"].copy_(x_lengths); st["yl"].copy_(y_lengths)
+        g_am.replay()
+        torch.cuda.synchronize(dev)
+        am_infer = (perf_counter() - am_t0) * 1000
+        v_t0 = perf_counter()
+        g_voc.replay()
+        torch.cuda.synchronize(dev)
+        return st["wav"], am_infer, (perf_counter() - v_t0) * 1000
+
     # ------------------------------------------------------------------------------------------ inference
     @torch.inference_mode()
     def synthesise(self, x, x_lengths, sids=None, lids=None, d_factor=1.0, p_factor=1.0, e_factor=1.0,
@@ -163,17 +206,24 @@ class OptiSpeechGenerator(nn.Module):
             durations = torch.ones_like(durations)
             y_lengths = durations.sum(dim=1)
             y_max_length = int(y_lengths.max())
-        target_padding_mask = ~sequence_mask(y_lengths, y_max_length)
-        y = self.feature_upsampler(h, durations, x_lengths, y_lengths.contiguous(), y_max_length)   # :263-265
-        y = self.decoder(y, target_padding_mask)                                            # :268
-        torch.cuda.synchronize(dev)
-        am_infer = (perf_counter() - am_t0) * 1000
-        v_t0 = perf_counter()
-        f0_cond, _ = expand_by_duration(pitch.unsqueeze(-1), durations)                     # :273-276 (unused by WaveNeXt)
-        wav = self.vocoder(y, f0=f0_cond, padding_mask=target_padding_mask)                 # :277-281
-        wav_lengths = y_lengths * self.hop_length                                           # :282
-        torch.cuda.synchronize(dev)
-        v_infer = (perf_counter() - v_t0) * 1000
+        if self.graph_decode and x.is_cuda:
+            # BASELINE.json configs[4] "hipGraph-captured decode": everything after the one length sync is shape-static in
+            # (B, T_text, y_max_length) -- upsampler + decoder and the vocoder replay from two captured graphs (two, because
+            # the reference times the acoustic model and the vocoder separately, :270-284)
+            wav, am_infer, v_infer = self._graphed_decode(h, durations, x_lengths, y_lengths.contiguous(), y_max_length, am_t0, dev)
+            wav_lengths = y_lengths * self.hop_length
+        else:
+            target_padding_mask = ~sequence_mask(y_lengths, y_max_length)
+            y = self.feature_upsampler(h, durations, x_lengths, y_lengths.contiguous(), y_max_length)   # :263-265
+            y = self.decoder(y, target_padding_mask)                                            # :268
+            torch.cuda.synchronize(dev)
+            am_infer = (perf_counter() - am_t0) * 1000
+            v_t0 = perf_counter()
+            f0_cond, _ = expand_by_duration(pitch.unsqueeze(-1), durations)                     # :273-276 (unused by WaveNeXt)
+            wav = self.vocoder(y, f0=f0_cond, padding_mask=target_padding_mask)                 # :277-281
+            wav_lengths = y_lengths * self.hop_length                                           # :282
+            torch.cuda.synchronize(dev)
+            v_infer = (perf_counter() - v_t0) * 1000
         wav_t = wav.shape[-1] / (self.sample_rate * 1e-3)                                   # :285
         am_rtf, v_rtf = am_infer / wav_t, v_infer / wav_t
         return {"wav": wav.detach().cpu(), "wav_lengths": wav_lengths.detach().cpu(),

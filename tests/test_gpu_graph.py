@@ -77,3 +77,36 @@ def test_graph_replay_advances_dropout_seed_and_weights():
         assert len({round(v, 6) for v in vals[1:]}) == 3, vals     # three replays, three different losses
     finally:
         precision.set_precision("f32")
+
+
+def test_graph_captured_decode_equals_eager_synthesise(golden):
+    """BASELINE.json configs[4]: synthesise() with the decode replayed from hipGraphs returns exactly the eager result, for
+    two different batches through the same and through a new capture."""
+    from oracle import schema as S
+    from optispeech_amd import precision
+    from optispeech_amd.config import make_generator
+    from tests.test_gpu_generator import _small_cfg
+    precision.set_precision("bf16")
+    try:
+        g = golden("synth_small")
+        gen = make_generator(_small_cfg()).to("cuda").eval()
+        W = S.make_weights(S.generator_schema(S.SMALL), int(g["seed"]))
+        W["generator.duration_predictor.linear.bias"].fill_(float(g["dur_bias"]))
+        gen.load_state_dict({k[len("generator."):]: v for k, v in W.items()})
+        x, xl = torch.from_numpy(g["in_x"]).cuda(), torch.from_numpy(g["in_x_lengths"])
+        x2 = x.flip(0).contiguous()
+        xl2 = xl.flip(0).contiguous()
+        outs = {}
+        for graph in (False, True, True):
+            gen.graph_decode = graph
+            a = gen.synthesise(x, xl, d_factor=1.1, p_factor=1.6, e_factor=1.2)
+            b = gen.synthesise(x2, xl2, d_factor=1.3, p_factor=1.0, e_factor=1.0)
+            outs.setdefault(graph, []).append((a, b))
+        assert len(gen._decode_graphs) >= 1
+        (ea, eb) = outs[False][0]
+        for ga, gb in outs[True]:
+            assert np.array_equal(ga["durations"].numpy(), ea["durations"].numpy()) and np.array_equal(ga["durations"].numpy(), g["durations"])
+            assert torch.equal(ga["wav"], ea["wav"]) and torch.equal(gb["wav"], eb["wav"])
+            assert ga["rtf"] > 0 and ga["latency"] > 0
+    finally:
+        precision.set_precision("f32")
