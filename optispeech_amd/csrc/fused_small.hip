@@ -302,8 +302,11 @@ __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restric
 }
 extern "C" int osp_colsum_prod(const float* a, const float* b, const float* rowf, float* out, int64_t M, int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(a && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "C must be a multiple of 4, <= 1024");
-    const int rpb = 256;
-    hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream, a, b, rowf, out, M, (int)C, rpb);
+    // ~1024 workgroups whatever M is (the encoder / vocoder calls have M = 2-4k rows: 256 rows per block left 8-16 blocks on a
+    // 256-CU part, 54 us per launch); at least 8 rows per block so the atomics stay few
+    int64_t rpb = cdiv(M, 1024);
+    rpb = rpb < 8 ? 8 : (rpb > 256 ? 256 : rpb);
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream, a, b, rowf, out, M, (int)C, (int)rpb);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

@@ -31,7 +31,7 @@ __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
 //   (128 + 64) rows x 32 B of fragments for 8 MFMAs (the 4-wave 128x128 tile: (64 + 64) x 32 B for 4), and a CU stages
 //   (256 + 256) x 128 B per slab for 4x the flops of a 128x128 tile (2x fewer HBM / L2 bytes per flop); two 64 KB stages,
 //   one barrier per slab, 1 workgroup / CU whose second wave per SIMD covers the other's LDS latency.
-template <int BM_, int NST, int BN_ = TBN, int NW = 4>
+template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false>
 __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem) {
     const GemmB pp = gemm_select_phase(pin);
     constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
@@ -154,7 +154,16 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
                 const int row = wn0 + 32 * j + l31;
                 b[j] = *reinterpret_cast<const bf16x8*>(bs + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
             }
-            if (ld >= 0) issue_quarter(ld, ksidx);
+            if constexpr (EARLY) {
+                // the whole next slab is requested during the first two k-steps, so the last load has two k-steps of MFMA
+                // time (>= 1000 cycles with two waves per SIMD) to land before the slab-closing vmcnt(0)
+                if (ld >= 0 && ks < 2) {
+                    issue_quarter(ld, std::integral_constant<int, 2 * (ks & 1)>{});
+                    issue_quarter(ld, std::integral_constant<int, 2 * (ks & 1) + 1>{});
+                }
+            } else {
+                if (ld >= 0) issue_quarter(ld, ksidx);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -216,6 +225,9 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const Gemm
 #define GLDS8_LDS (8 * 128 * (32 * 2 + 8) * 2)
 __global__ __launch_bounds__(512) void conv_gemm_bf16_glds8_kernel(const GemmB pp) {
     conv_gemm_bf16_glds_body<256, 2, 256, 8>(pp, glds_smem);
+}
+__global__ __launch_bounds__(512) void conv_gemm_bf16_glds8e_kernel(const GemmB pp) {
+    conv_gemm_bf16_glds_body<256, 2, 256, 8, true>(pp, glds_smem);
 }
 // one workgroup per CU (144 KB of LDS): let the register allocator use the whole 512-entry file of a single wave / SIMD
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_bf16_glds256_kernel(const GemmB pp) {
@@ -465,7 +477,13 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
                 w8_attr = 1;
             }
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
-            hipLaunchKernelGGL(conv_gemm_bf16_glds8_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
+            static int early = -1;
+            if (early < 0) {
+                const char* e = getenv("OSP_GEMM_W8_EARLY"); early = (e && atoi(e) == 0) ? 0 : 1;      // +1..3 % in A/B runs (tools/gemm_quick.py)
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8e_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
+            }
+            if (early) hipLaunchKernelGGL(conv_gemm_bf16_glds8e_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
+            else hipLaunchKernelGGL(conv_gemm_bf16_glds8_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
             OSP_LAUNCH_CHECK();
             return OSP_OK;
         }
