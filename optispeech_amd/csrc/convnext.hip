@@ -10,6 +10,7 @@
 // input row is fetched (7 + FRAMES - 1) / FRAMES times (from L2) instead of 7.
 // Algorithmic HBM bytes per frame: forward 2*C*4 (+C*4 when xhat is saved for training); see DESIGN.md.
 #include "osp_common.h"
+#include <stdlib.h>
 
 #define FRAMES 8
 #define MAXCH 4   // chunks of 256 channels per lane => C <= 1024
@@ -21,80 +22,83 @@ __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
 __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int NCH>
+// Round 2: a wave owns a run of FR consecutive frames and requests ALL FR + 6 input rows of the run before it computes
+// anything (FR + 6 independent 1 KiB loads in flight per wave instead of one dependent load per frame: the round-1 loop
+// used the row it had just requested and exposed a full memory latency per frame -- 39 % of the HBM roofline at the
+// decoder shape).  The 6 halo rows are shared with the neighbouring runs and come from L2; with FR = 16 the
+// request amplification is 22 / 16.  Everything after the loads runs out of registers: 7 FMAs per channel, two wave
+// reductions, one or two 1 KiB stores per frame.
+template <int NCH, int FR>
 __global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dw,
                                                              const float* __restrict__ dwb, const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, float eps,
                                                              float* __restrict__ h, float* __restrict__ xhat,
                                                              float* __restrict__ rstd_out, int B, int T, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int runs_per_utt = (T + FRAMES - 1) / FRAMES;
+    const int runs_per_utt = (T + FR - 1) / FR;
     const int run = blockIdx.x * 4 + wave;
     if (run >= B * runs_per_utt) return;
-    const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FRAMES;
+    const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FR;
     const float* xb = x + (int64_t)b * T * C;
     bool act[NCH];
-    float4 w[NCH][7], bias[NCH], gw[NCH], gb[NCH];
+    float4 rows[NCH][FR + 6];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int ch = k * 256 + lane * 4;
         act[k] = ch < C;
-        if (act[k]) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) w[k][j] = *reinterpret_cast<const float4*>(dw + (int64_t)j * C + ch);
-            bias[k] = *reinterpret_cast<const float4*>(dwb + ch);
-            gw[k] = *reinterpret_cast<const float4*>(lnw + ch);
-            gb[k] = *reinterpret_cast<const float4*>(lnb + ch);
+        for (int r = 0; r < FR + 6; ++r) {
+            const int t = t0 + r - 3;
+            const bool ok = act[k] && t >= 0 && t < T;
+            const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)(ok ? t : t0) * C + (act[k] ? ch : 0));   // unconditional load, index select
+            rows[k][r] = ok ? v : f4zero();
         }
     }
-    // sliding window: win[k][j] = x[t + j - 3]
-    float4 win[NCH][7];
-    auto ldrow = [&](int k, int t) -> float4 {
-        if (!act[k] || t < 0 || t >= T) return f4zero();
-        return *reinterpret_cast<const float4*>(xb + (int64_t)t * C + k * 256 + lane * 4);
-    };
+    float4 w[NCH][7], bias[NCH], gw[NCH], gb[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k)
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = act[k] ? k * 256 + lane * 4 : 0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) win[k][j + 1] = ldrow(k, t0 + j - 3);
+        for (int j = 0; j < 7; ++j) w[k][j] = *reinterpret_cast<const float4*>(dw + (int64_t)j * C + ch);
+        bias[k] = *reinterpret_cast<const float4*>(dwb + ch);
+        gw[k] = *reinterpret_cast<const float4*>(lnw + ch);
+        gb[k] = *reinterpret_cast<const float4*>(lnb + ch);
+    }
     const float invC = 1.0f / (float)C;
-    for (int f = 0; f < FRAMES; ++f) {
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
         const int t = t0 + f;
-        if (t >= T) break;
-        float4 c[NCH];
-        float s = 0.f;
+        if (t < T) {                                            // wave-uniform
+            float4 c[NCH];
+            float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
+            for (int k = 0; k < NCH; ++k) {
+                float4 a = act[k] ? bias[k] : f4zero();
 #pragma unroll
-            for (int j = 0; j < 6; ++j) win[k][j] = win[k][j + 1];
-            win[k][6] = ldrow(k, t + 3);
-            float4 a = act[k] ? bias[k] : f4zero();
-            if (act[k]) {
-#pragma unroll
-                for (int j = 0; j < 7; ++j) a = f4fma(w[k][j], win[k][j], a);
+                for (int j = 0; j < 7; ++j) a = f4fma(w[k][j], rows[k][f + j], a);
+                c[k] = act[k] ? a : f4zero();
+                s += f4sum(c[k]);
             }
-            c[k] = a;
-            s += f4sum(a);
+            const float mean = wave_sum(s) * invC;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (act[k]) {
+                    c[k].x -= mean; c[k].y -= mean; c[k].z -= mean; c[k].w -= mean;
+                    v += c[k].x * c[k].x + c[k].y * c[k].y + c[k].z * c[k].z + c[k].w * c[k].w;
+                }
+            const float rstd = rsqrtf(wave_sum(v) * invC + eps);
+            const int64_t row = ((int64_t)b * T + t) * C;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                if (act[k]) {
+                    const float4 n = make_float4(c[k].x * rstd, c[k].y * rstd, c[k].z * rstd, c[k].w * rstd);
+                    const int ch = k * 256 + lane * 4;
+                    if (xhat) *reinterpret_cast<float4*>(xhat + row + ch) = n;
+                    *reinterpret_cast<float4*>(h + row + ch) = f4fma(n, gw[k], gb[k]);
+                }
+            if (rstd_out && lane == 0) rstd_out[(int64_t)b * T + t] = rstd;
         }
-        const float mean = wave_sum(s) * invC;
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-            if (act[k]) {
-                c[k].x -= mean; c[k].y -= mean; c[k].z -= mean; c[k].w -= mean;
-                v += c[k].x * c[k].x + c[k].y * c[k].y + c[k].z * c[k].z + c[k].w * c[k].w;
-            }
-        const float rstd = rsqrtf(wave_sum(v) * invC + eps);
-        const int64_t row = ((int64_t)b * T + t) * C;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-            if (act[k]) {
-                const float4 n = make_float4(c[k].x * rstd, c[k].y * rstd, c[k].z * rstd, c[k].w * rstd);
-                const int ch = k * 256 + lane * 4;
-                if (xhat) *reinterpret_cast<float4*>(xhat + row + ch) = n;
-                *reinterpret_cast<float4*>(h + row + ch) = f4fma(n, gw[k], gb[k]);
-            }
-        if (rstd_out && lane == 0) rstd_out[(int64_t)b * T + t] = rstd;
     }
 }
 
@@ -103,11 +107,12 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
                                   int64_t T, int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(x && dw && dwb && lnw && lnb && h, "null operand");
     OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
-    const int64_t runs = B * cdiv(T, FRAMES);
-    dim3 grid((unsigned)cdiv(runs, 4));
     const int nch = (int)cdiv(C, 256);
-#define L(N) hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N>), grid, dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, xhat, rstd, (int)B, (int)T, (int)C)
-    if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
+    // frames per wave: 8 (one or two 256-channel chunks; 16 halves the occupancy: 174 VGPRs), 4 beyond
+#define L(N, F) hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * cdiv(T, F), 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, xhat, rstd, (int)B, (int)T, (int)C)
+    static int fr1 = -1;
+    if (fr1 < 0) { const char* e = getenv("OSP_DWCONV_FR"); fr1 = e ? atoi(e) : 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
+    if (nch == 1) { if (fr1 == 8) L(1, 8); else if (fr1 == 4) L(1, 4); else L(1, 16); } else if (nch == 2) L(2, 8); else if (nch == 3) L(3, 4); else L(4, 4);
 #undef L
     OSP_LAUNCH_CHECK();
     return OSP_OK;
