@@ -224,9 +224,9 @@ def _selectors(precision):
 
     def hbm(name, args):
         if name == "osp_dwconv7_ln_fwd":
-            Bn, T, C = args[9], args[10], args[11]
-            if Bn * T == M_DEC and C == 256:                    # decoder shape (32 x 800 x 256): read x, write h (+ xhat, rstd when saved)
-                return "dwconv7_ln_fwd", Bn * T * (C * 4 * (2 + (args[7] is not None)) + 4 * (args[8] is not None))
+            Bn, T, C = args[10], args[11], args[12]
+            if Bn * T == M_DEC and C == 256:                    # decoder shape (32 x 800 x 256): read x (f32), write h (f32 or bf16) (+ xhat, rstd when saved)
+                return "dwconv7_ln_fwd", Bn * T * (C * (4 + (2 if args[7] else 4) + 4 * (args[8] is not None)) + 4 * (args[9] is not None))
         if name == "osp_layernorm_bwd":
             rows, C = args[14], args[15]
             if rows * C >= 1 << 20:                             # read dy, xin (+ relu source), write dx

@@ -32,7 +32,7 @@ template <int NCH, int FR>
 __global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dw,
                                                              const float* __restrict__ dwb, const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, float eps,
-                                                             float* __restrict__ h, float* __restrict__ xhat,
+                                                             void* __restrict__ h, int h_bf16, float* __restrict__ xhat,
                                                              float* __restrict__ rstd_out, int B, int T, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int runs_per_utt = (T + FR - 1) / FR;
@@ -95,21 +95,30 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __rest
                     const float4 n = make_float4(c[k].x * rstd, c[k].y * rstd, c[k].z * rstd, c[k].w * rstd);
                     const int ch = k * 256 + lane * 4;
                     if (xhat) *reinterpret_cast<float4*>(xhat + row + ch) = n;
-                    *reinterpret_cast<float4*>(h + row + ch) = f4fma(n, gw[k], gb[k]);
+                    const float4 o = f4fma(n, gw[k], gb[k]);
+                    if (h_bf16) {                               // the consumer is the bf16 GEMM: half the bytes, no cast launch later
+                        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+                        v2 p0, p1; p0[0] = (__bf16)o.x; p0[1] = (__bf16)o.y; p1[0] = (__bf16)o.z; p1[1] = (__bf16)o.w;
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(h) + row + ch) =
+                            make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1));
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(h) + row + ch) = o;
+                    }
                 }
             if (rstd_out && lane == 0) rstd_out[(int64_t)b * T + t] = rstd;
         }
     }
 }
 
+// h_bf16 != 0: h is written as bf16 (the operand the bf16 pointwise GEMM reads); xhat / rstd stay f32.
 extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* dwb, const float* lnw,
-                                  const float* lnb, float eps, float* h, float* xhat, float* rstd, int64_t B,
+                                  const float* lnb, float eps, void* h, int64_t h_bf16, float* xhat, float* rstd, int64_t B,
                                   int64_t T, int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(x && dw && dwb && lnw && lnb && h, "null operand");
     OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
     const int nch = (int)cdiv(C, 256);
     // frames per wave: 8 (one or two 256-channel chunks; 16 halves the occupancy: 174 VGPRs), 4 beyond
-#define L(N, F) hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * cdiv(T, F), 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, xhat, rstd, (int)B, (int)T, (int)C)
+#define L(N, F) hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * cdiv(T, F), 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, (int)C)
     static int fr1 = -1;
     if (fr1 < 0) { const char* e = getenv("OSP_DWCONV_FR"); fr1 = e ? atoi(e) : 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
     if (nch == 1) { if (fr1 == 8) L(1, 8); else if (fr1 == 4) L(1, 4); else L(1, 16); } else if (nch == 2) L(2, 8); else if (nch == 3) L(3, 4); else L(4, 4);

@@ -93,14 +93,14 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
          taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
 
 
-def dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, eps, save):
+def dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, eps, save, h_bf16=False):
     _f32(x, dw, dwb, lnw, lnb)
     B, T, C = x.shape
     assert x.is_contiguous() and dw.shape == (7, C)
-    h = torch.empty_like(x)
+    h = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if h_bf16 else torch.float32)
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty((B, T), device=x.device, dtype=torch.float32) if save else None
-    call("osp_dwconv7_ln_fwd", x, dw, dwb, lnw, lnb, float(eps), h, xhat, rstd, B, T, C)
+    call("osp_dwconv7_ln_fwd", x, dw, dwb, lnw, lnb, float(eps), h, int(h_bf16), xhat, rstd, B, T, C)
     return h, xhat, rstd
 
 

@@ -35,10 +35,11 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         M = B * T
         save = any(ctx.needs_input_grad)
         x = x.contiguous()
-        h, xhat, rstd = K.dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, 1e-6, save)
+        ctx.lowp = _precision.is_bf16() and I % 64 == 0 and C % 64 == 0
+        # lowp: h goes straight out as bf16 (its only consumers are the bf16 pointwise GEMM and its weight-gradient GEMM)
+        h, xhat, rstd = K.dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, 1e-6, save, h_bf16=ctx.lowp)
         h2 = h.view(M, C)
         z = torch.empty((M, C), device=x.device, dtype=torch.float32) if save else None
-        ctx.lowp = _precision.is_bf16() and I % 64 == 0 and C % 64 == 0
         if ctx.lowp:
             # performance mode: the I-wide intermediates (pre-activation u, gelu(u)) live in bf16 -- what autocast does
             # to these matmul outputs in the reference's default `16-mixed` precision; the block's input / output /
@@ -84,7 +85,7 @@ class ConvNeXtBlockFn(torch.autograd.Function):
                                   oscale=gamma)
             dh = K.conv_gemm_bf16(du, K.param_bf16(W1, transposed=True), C, M=M, Trows=M, Tin=M, cin=I)
             if _want(W1):
-                K.conv_wgrad_bf16(du, K.cast_bf16(h.view(M, C)), gsink(W1), gsink(b1) if _want(b1) else None, M=M, Trows=M,
+                K.conv_wgrad_bf16(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None, M=M, Trows=M,
                                   Tin=M, n=I, cin=C)
         else:
             W2g = W2 * gamma[:, None]

@@ -13,7 +13,7 @@ def timeit(f, reps=50):
     return a.elapsed_time(b) / reps * 1e3
 for (B, T, C) in [(32, 800, 256), (32, 128, 256), (32, 64, 384), (64, 800, 384)]:
     x = torch.randn(B, T, C, device=dev); dw = torch.randn(7, C, device=dev); z = torch.zeros(C, device=dev); o = torch.ones(C, device=dev)
-    for save in (False, True):
-        t = timeit(lambda: K.dwconv7_ln_fwd(x, dw, z, o, z, 1e-6, save))
-        byt = B * T * C * 4 * (3 if save else 2)
-        print(f"FR={os.environ.get('OSP_DWCONV_FR','16')} B={B} T={T} C={C} save={int(save)}: {t:6.1f} us  {byt/t/1e6:6.2f} TB/s = {byt/t/1e6/8*100:4.1f} % of 8 TB/s")
+    for save, hb in ((False, False), (True, False), (False, True), (True, True)):
+        t = timeit(lambda: K.dwconv7_ln_fwd(x, dw, z, o, z, 1e-6, save, h_bf16=hb))
+        byt = B * T * C * (4 + (2 if hb else 4) + (4 if save else 0))
+        print(f"FR={os.environ.get('OSP_DWCONV_FR','8')} B={B} T={T} C={C} save={int(save)} h_bf16={int(hb)}: {t:6.1f} us  {byt/t/1e6:6.2f} TB/s = {byt/t/1e6/8*100:4.1f} % of 8 TB/s")
