@@ -441,6 +441,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     }
 }
 
+// ---- 8-wave transposed-read variant (round 2): 256 (N) x 256 (Cin) tiles, 512 threads = 2 (N) x 4 (Cin) waves of 128 x 64.
+// Same LDS image as the T = 128 kernel above -- each operand slab is kept as TWO [64 frames][128 channels] sub-slabs, so the
+// staging addresses, the XOR swizzle and the ds_read_b64_tr_b16 fragment reads are unchanged -- but a workgroup stages
+// 2 x (256 + 256) x 64 x 2 B for 4x the flops (half the L2 / HBM bytes per flop), and a wave reads (128 + 64) x 32 B of fragments
+// per 8 MFMAs instead of 128 x 32 B per 4.  128 KB of LDS: one workgroup per CU, two waves per SIMD.
+// The bias gradient does not get accumulator registers here (4 more 32x32 accumulators would not fit beside the 128): the
+// waves that own Cin block 0 add up their own A fragments on the VALU (8 frames of one channel per lane).
+extern __shared__ __attribute__((aligned(1024))) unsigned short wg8_smem[];
+template <bool BUF>
+__global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
+    constexpr int SK = 64, T = 128, SUB = SK * T;            // one sub-slab: 64 frames x 128 channels (16 KB)
+    constexpr int S = 16, RPI = 4;                           // 16-byte slots per row, rows per wave instruction
+    unsigned short* smem = wg8_smem;                         // [2 stages][y0, y1, x0, x1][SUB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    // XCD-aware work order (1-D grid).  The (taps x Cin-tiles) workgroups of one (batch, frame split, N tile) read the SAME dY
+    // slabs, and the taps of one Cin tile read X slabs shifted by one frame: with one workgroup per tap and tile, the operands
+    // were fetched 20x (1.07 GB through the fabric for 53 MB of unique data on the 1024x1024x5 layer: the kernel was bound by
+    // that, not by the MFMAs).  Workgroups are dispatched round-robin over the 8 XCDs; the linear id is folded so that every
+    // XCD owns a contiguous range of work items ordered (split, N tile) -> (tap, Cin tile): the ~32 workgroups resident on an
+    // XCD walk the same frames of the same dY panel at the same time and share it (and the X panels) through that XCD's L2.
+    const int ctiles = p.Cin / 256, ntiles = p.N / 256, inner = p.taps * ctiles;
+    const int total = gridDim.x, lin = blockIdx.x, xcd = lin & 7, local = lin >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int pid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + local;
+    const int grp = pid / inner, within = pid - grp * inner;              // grp = (bz * splits + sp) * ntiles + nt
+    const int j = within / ctiles, c0 = (within - j * ctiles) * 256;
+    const int zs = grp / ntiles, n0 = (grp - zs * ntiles) * 256;
+    const int bz = zs / p.splits, sp = zs - bz * p.splits;
+    const unsigned short* dY = reinterpret_cast<const unsigned short*>(p.dY) + (int64_t)bz * p.sYb;
+    const unsigned short* X = reinterpret_cast<const unsigned short*>(p.X) + (int64_t)bz * p.sXb;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
+    const bool do_bias = (p.db != nullptr) && (within == 0);
+    const bool bias_wave = __builtin_amdgcn_readfirstlane((int)(do_bias && wn == 0)) != 0;
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
+    const int64_t ldy = p.ldy, ldx = p.ldx;
+    auto swz = [](int row) { return 4 * (row & 3); };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // staging: per slab and operand 2 sub-slabs x 16 row blocks of 4 rows; wave w, pair i: sub-slab i & 1, row block 2 w + (i >> 1)
+    const int srow = lane / S, lslot = (lane % S) ^ swz(srow);
+    const int ldy32 = (int)ldy, ldx32 = (int)ldx;
+    __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(dY), 0, BUF ? (int)p.y_bytes : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, BUF ? (int)p.x_bytes : 0, 0x00020000);
+    auto issue_pair = [&](int mk, int buf, int i) {
+        const int sub = i & 1, row0 = RPI * (2 * wave + (i >> 1)), m = mk + row0 + srow;
+        unsigned short* ys = smem + buf * (4 * SUB) + sub * SUB;
+        unsigned short* xs = smem + buf * (4 * SUB) + (2 + sub) * SUB;
+        const int ycol = n0 + sub * T + lslot * 8, xcol = c0 + sub * T + lslot * 8;
+        const bool mv = m < mend;
+        const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
+        const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
+        const bool xv = mv && (unsigned)tt < (unsigned)p.Tin && (unsigned)hh < (unsigned)p.Hin;
+        if constexpr (BUF) {
+            const unsigned yo = mv ? (unsigned)(m * ldy32 + ycol) * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, yo, 0, 0, 0);
+            const unsigned xo = xv ? (unsigned)(((u * p.Hin + hh) * p.Tin + tt) * ldx32 + xcol) * 2u : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, xo, 0, 0, 0);
+        } else {
+            const unsigned short* src = mv ? dY + (int64_t)m * ldy + ycol : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, 0, 0);
+            const unsigned short* xsrc = xv ? X + (int64_t)((u * p.Hin + hh) * p.Tin + tt) * ldx + xcol : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
+                                             (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, 0, 0);
+        }
+    };
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1, kg = lane >> 5;
+    auto frag = [&](const unsigned short* base, int col0, int ks) -> bf16x8 {
+        const int col = col0 + 16 * g16 + 4 * (r16 & 3);
+        const int pslot = (col >> 3) ^ swz(r16 >> 2);
+        const unsigned short* a0 = base + (16 * ks + 8 * kg + (r16 >> 2)) * T + pslot * 8 + (col & 7);
+        const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)a0;
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * T * 2) : "memory");
+        union { struct { s16x4 l, h; } s; bf16x8 v; } u;
+        u.s.l = lo; u.s.h = hi;
+        return u.v;
+    };
+    auto mma = [&](int buf, int mk_next) {
+        const unsigned short* ys = smem + buf * (4 * SUB) + wm * SUB;
+        const unsigned short* xs = smem + buf * (4 * SUB) + (2 + (wn >> 1)) * SUB;
+        const int xc0 = (wn & 1) * 64;
+#pragma unroll
+        for (int ks = 0; ks < SK / 16; ++ks) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag(ys, 32 * i, ks);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) b[jj] = frag(xs, xc0 + 32 * jj, ks);
+            if (mk_next >= 0) issue_pair(mk_next, buf ^ 1, ks);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : : "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+            if (bias_wave) {                                  // scalar condition; lane (l31, lh) holds channel l31, frames 8 lh .. 8 lh + 7
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sacc += (float)a[i][q];
+                    bsum[i] += sacc;
+                }
+            }
+        }
+    };
+    const int niter = (mend - mbeg + SK - 1) / SK;
+    if (niter > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_pair(mbeg, 0, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const int buf = it & 1;
+            mma(buf, it + 1 < niter ? mbeg + (it + 1) * SK : -1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int c = c0 + wn * 64 + 32 * jj + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * 128 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* dst = dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c;
+                const float val = (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r];
+                if (p.splits == 1) *dst += val;
+                else atomicAdd(dst, val);
+            }
+        }
+    if (bias_wave) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);                     // the two 8-frame halves of every k-step
+            const int n = n0 + wm * 128 + 32 * i + l31;
+            if (lh == 0) atomicAdd(p.db + (int64_t)bz * p.sDb + n, (p.oscale ? p.oscale[n] : 1.f) * tot);
+        }
+    }
+}
+
 static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
                                    int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
                                    int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
@@ -489,7 +644,27 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         if (use_buf < 0) { const char* e = getenv("OSP_WGRAD_BUF"); use_buf = (e && atoi(e) == 0) ? 0 : 1; }
         const bool buf = use_buf && yb > 0 && xb > 0 && yb < (int64_t)0x7fffff00 && xb < (int64_t)0x7fffff00;
         p.y_bytes = buf ? (unsigned)yb : 0; p.x_bytes = buf ? (unsigned)xb : 0;
-        if (T_ == 128) {
+        // 8-wave 256 x 256 tiles for the wide layers (DiscriminatorP 512->1024 and 1024->1024): OSP_WGRAD_W8 = 0 switches them off
+        static int w8 = -1;
+        if (w8 < 0) {
+            const char* e = getenv("OSP_WGRAD_W8"); w8 = (e && atoi(e) == 0) ? 0 : 1;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_tr8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_tr8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        }
+        if (w8 && N % 256 == 0 && Cin % 256 == 0 && M >= 4096) {
+            const int64_t tl8 = (N / 256) * taps * (Cin / 256) * batch;
+            static int64_t tgt8 = -1;
+            if (tgt8 < 0) { const char* e = getenv("OSP_WGRAD_W8_TARGET"); tgt8 = e ? atoll(e) : 256; }
+            int64_t sp8 = tl8 >= tgt8 / 2 ? 1 : tgt8 / tl8;                              // workgroups over the launch (1 resident per CU)
+            if (sp8 < 1) sp8 = 1;
+            int64_t ch8 = cdiv(cdiv(M, sp8), TBK) * TBK;
+            if (ch8 < 4 * TBK) ch8 = 4 * TBK;
+            sp8 = cdiv(M, ch8);
+            p.chunk = (int)ch8; p.splits = (int)sp8;
+            const dim3 g8((unsigned)((N / 256) * taps * (Cin / 256) * sp8 * batch));
+            if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr8_kernel<true>), g8, dim3(512), 131072, stream, p);
+            else hipLaunchKernelGGL((conv_wgrad_bf16_tr8_kernel<false>), g8, dim3(512), 131072, stream, p);
+        } else if (T_ == 128) {
             if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<128, false, true>), g, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
         } else {

@@ -426,3 +426,28 @@ def test_conv_gemm_bf16_gelu_relu_bwd_epilogues(M, cin, n_out, aux_bf16):
     assert relerr(got.float(), want_gelu) < 1e-2
     got = K.conv_gemm_bf16(dyg, wg, n_out, M=M, Trows=M, Tin=M, cin=cin, epi=K.EPI_RELU_BWD, aux_in=ug, out_bf16=True)
     assert relerr(got.float(), want_relu) < 1e-2
+
+
+@pytest.mark.parametrize("U,W,cin,cout,sw", [(40, 331, 512, 1024, 3), (70, 64, 1024, 1024, 1), (33, 200, 256, 256, 1)])
+def test_conv_wgrad_bf16_8wave_tiles(U, W, cin, cout, sw):
+    """The 8-wave 256x256 weight-gradient kernel (conv_wgrad_bf16_tr8_kernel: N, Cin multiples of 256, >= 4096 rows, bf16 operands)
+    against torch's conv2d weight / bias gradients on the same bf16-rounded operands; (1,5) kernels as in DiscriminatorP."""
+    from optispeech_amd import disc_ops as D
+    KH, KW, ph, pw = 1, 5, 0, 2
+    x = bfr(rnd(U, cin, 1, W, seed=1))
+    w = rnd(cout, cin, KH, KW, seed=2, scale=0.02).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=(1, sw), padding=(ph, pw))
+    dy = bfr(rnd(*y.shape, seed=3))
+    y.backward(dy)
+    assert U * y.shape[-1] >= 4096
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    dw, db = D.conv2d_wgrad(dyg, xg, KH, KW, 1, sw, ph, pw)
+    assert relerr(dw.permute(0, 3, 1, 2), w.grad) < 2e-3 and relerr(db, b.grad) < 2e-3
+    # accumulation semantics: a second call adds
+    from optispeech_amd import kernels as K
+    Ho, Wo = y.shape[2], y.shape[3]
+    K.conv2d_wgrad_bf16(dyg.view(-1, cout), xg.view(-1, cin), dw, db, M=U * Ho * Wo, Trows=Ho * Wo, Wrows=Wo, Hin=1, Win=W, n=cout, cin=cin,
+                        taps=KH * KW, KW=KW, pad_h=ph, pad_w=pw, step_h=1, step_w=sw)
+    assert relerr(dw.permute(0, 3, 1, 2), 2 * w.grad) < 2e-3 and relerr(db, 2 * b.grad) < 2e-3
