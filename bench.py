@@ -48,6 +48,11 @@ def parse():
                          "step.  Off by default: on ROCm 7.2 a captured multi-stream graph executes its branches almost serially "
                          "(29.9 vs 24.5 ms per step, tools/graph_probe.py), so the eager schedule is the faster one; the replay is "
                          "still measured and reported as `graph_replay_step`")
+    ap.add_argument("--graph-segments", action="store_true",
+                    help="replay the acoustic model / vocoder forward and backward from captured hipGraph segments inside the eager "
+                         "multi-stream step (OptiSpeech.graph_segments): host enqueue 21 -> 15 ms per step, but the step is GPU-bound and "
+                         "the device runs the graph-launched chains ~1 ms slower than the eagerly launched ones on ROCm 7.2 "
+                         "(23.6 vs 22.5 ms), so it is off by default")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial schedule: do not issue the discriminator phase from its own stream (OptiSpeech.pipeline_steps)")
@@ -262,6 +267,7 @@ def main():
     # n's discriminator backward.  --graph times the hipGraph replay of the same step instead (optispeech_amd/graphs.py)
     model.graph_steps = a.graph
     model.pipeline_steps = not a.graph and not a.no_pipeline
+    model.graph_segments = a.graph_segments and not a.graph
     timer = KernelTimer(_selectors(a.precision))
     timer.install()
 
@@ -293,14 +299,14 @@ def main():
     # kernel's own (inside the timed region the launches replay from a graph -- no host code runs between them -- and eight
     # discriminator streams share the GPU, so a bracketed launch there would time whatever ran beside it).
     from optispeech_amd.model import discriminator as _disc
-    keep_streams, keep_graph, keep_pipe = _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps
-    _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps = False, False, False
+    keep_streams, keep_graph, keep_pipe, keep_seg = _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments
+    _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments = False, False, False, False
     timer.enabled = True
     for i in range(3):
         model.training_step(batch, a.warmup + a.steps + i)
     sync()
     timer.enabled = False
-    _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps = keep_streams, keep_graph, keep_pipe
+    _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments = keep_streams, keep_graph, keep_pipe, keep_seg
     ksum = timer.summary()
     # secondary figure: the acoustic-model-only step of the first `pretraining_steps` steps (no adversarial
     # losses, no discriminator phase: base_lightning_module.py:88,108-110,149-150); same batch, 3 warm-up + 10 timed steps
@@ -409,7 +415,8 @@ def main():
             else:
                 cpu = cpu_baseline_sweep(a.cpu_batch, a.cpu_steps, a.cpu_threads)
         sched = ("hipGraph replay (one graph per step)" if world == 1 else "hipGraph replay (5 segments, RCCL all-reduces between them)") \
-            if model.graph_steps else ("eager, serial" if a.no_pipeline else "eager, pipelined (pipeline_steps)")
+            if model.graph_steps else (("eager multi-stream step" + (", serial" if a.no_pipeline else ", pipelined (pipeline_steps)")
+                                        + (", acoustic model + vocoder forward / backward replayed from hipGraph segments" if model.graph_segments else "")))
         out = {"metric": "mel-frames/sec/GPU (train step) + RTF (synthesize), ConvNeXt@22.05kHz, 1/2/4/8 MI355X",
                "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

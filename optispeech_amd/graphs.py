@@ -232,3 +232,108 @@ def graphed_training_step(model, batch, batch_idx=0):
             model._step_graphs.pop(next(iter(model._step_graphs)))
         sg = model._step_graphs[key] = StepGraphs(model, batch, warmup=int(getattr(model, "graph_warmup_steps", 2)))
     sg.replay(batch)
+
+
+# =================================================================================================== graphed segments
+# The whole-step graph above loses to the eager step on ROCm 7.2 because the runtime executes the captured multi-stream graph
+# with little concurrency.  What the eager step pays instead is host time: ~22 ms of Python / autograd / dispatch per step, about
+# two thirds of it for the acoustic model and the vocoder -- long, essentially LINEAR launch chains.  Graphed segments take
+# exactly those chains out of Python and leave the multi-stream part (the eight discriminator stacks) eager:
+#
+#   forward graph + backward graph per segment, wrapped in an autograd Function (what torch.cuda.make_graphed_callables does,
+#   adapted to this package's direct-to-arena parameter gradients): the forward replays graph F from static inputs into static
+#   outputs, the backward copies the incoming output gradients into static buffers and replays graph B, whose captured kernels
+#   accumulate the parameter gradients straight into the flat gradient arena (fixed addresses).
+class GraphedSegment:
+    def __init__(self, fn, inputs, warmup=2):
+        dev = inputs[0].device
+        self.static_in = [t.detach().clone() for t in inputs]
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)          # gives the Function's outputs a grad_fn
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                outs = fn(*self.static_in)
+                go = [o for o in outs if o.requires_grad]
+                # zero output gradients: the warm-up backward adds zeros to the gradient arena
+                torch.autograd.backward(go, [torch.zeros_like(o) for o in go])
+            del outs, go
+            torch.cuda.synchronize(dev)
+            self.gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gf, stream=s, capture_error_mode="thread_local"):
+                outs = fn(*self.static_in)
+            self.outs = tuple(outs)
+            self.grad_idx = [i for i, o in enumerate(self.outs) if o.requires_grad]
+            self.static_go = [torch.zeros_like(self.outs[i]) for i in self.grad_idx]
+            self.gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gb, pool=self.gf.pool(), stream=s, capture_error_mode="thread_local"):
+                torch.autograd.backward([self.outs[i] for i in self.grad_idx], self.static_go)
+            self.outs = tuple(o.detach() for o in self.outs)
+        cur.wait_stream(s)
+
+    def __call__(self, *inputs):
+        return _GraphedFn.apply(self, self.anchor, *inputs)
+
+
+class _GraphedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, anchor, *inputs):
+        for st, t in zip(seg.static_in, inputs):
+            if t is not st:
+                st.copy_(t, non_blocking=True)
+        seg.gf.replay()
+        ctx.seg = seg
+        ctx.set_materialize_grads(False)
+        outs = tuple(o.view_as(o) for o in seg.outs)
+        nd = [o for i, o in enumerate(outs) if i not in seg.grad_idx]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        seg = ctx.seg
+        for k, i in enumerate(seg.grad_idx):
+            if grads[i] is None:
+                seg.static_go[k].zero_()
+            else:
+                seg.static_go[k].copy_(grads[i])
+        seg.gb.replay()
+        return (None, None) + (None,) * len(seg.static_in)
+
+
+class GeneratorSegments:
+    """Acoustic model and vocoder of one OptiSpeech model as two graphed segments for one batch signature."""
+
+    def __init__(self, model, tensors):
+        gen = model.generator
+        dev = model.device
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._ring = [(torch.zeros(1, dtype=torch.int64).pin_memory(), [None]) for _ in range(16)]
+        self._slot = 0
+        self.push_seed()
+
+        def am(x, x_lengths, mel, mel_lengths, pitches, energies):
+            o = gen._forward_am(x, x_lengths, mel, mel_lengths, pitches, energies, None, None, vocoder_hook=None)
+            return (o["loss"], o["align_loss"], o["duration_loss"], o["pitch_loss"], o["energy_loss"], o["_aux"]["segment"], o["start_idx"])
+
+        rng.use_device_seed(self.seed_dev)
+        gen_state = torch.cuda.get_rng_state(dev)               # the warm-up runs draw drop-path masks: a capture advances nothing
+        try:
+            self.am = GraphedSegment(am, tensors)
+            self.voc = GraphedSegment(lambda seg: (gen.vocoder(seg, f0=None),), (self.am.outs[5],))
+        finally:
+            rng.use_device_seed(None)
+            torch.cuda.set_rng_state(gen_state, dev)
+        self.segment_size = int(self.am.outs[5].shape[1])
+
+    def push_seed(self):
+        """The seed the step about to run uses (rng.advance() has been called by training_step), into device memory."""
+        h, ev = self._ring[self._slot]
+        self._slot = (self._slot + 1) % len(self._ring)
+        if ev[0] is not None:
+            ev[0].synchronize()
+        h[0] = rng.host_seed()
+        self.seed_dev.copy_(h, non_blocking=True)
+        ev[0] = torch.cuda.current_stream().record_event()

@@ -65,6 +65,19 @@ class OptiSpeechGenerator(nn.Module):
     # ------------------------------------------------------------------------------------------ training forward
     def forward(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids):
         """generator/__init__.py:72-192.  ``mel`` arrives in the reference layout (B, n_feats, T_mel)."""
+        return self._forward_am(x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids, vocoder_hook=self._run_vocoder)
+
+    def _run_vocoder(self, segment):
+        # :161 (f0 unused by WaveNeXt).  The vocoder's graph is disjoint from the acoustic model's (``segment`` is detached):
+        # built on its own stream, its backward overlaps the acoustic model's backward
+        if _VOC_STREAM and segment.is_cuda and torch.is_grad_enabled():
+            return ops.run_on_side_stream("vocoder", lambda: self.vocoder(segment, f0=None), [segment])
+        return self.vocoder(segment, f0=None)
+
+    def _forward_am(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids, vocoder_hook=None):
+        """The acoustic-model part of forward(): everything up to the detached decoder segment, plus the acoustic losses (which
+        do not depend on the vocoder).  ``vocoder_hook(segment) -> wav_hat`` runs where the reference calls the vocoder (:161);
+        None = the caller runs the vocoder itself (graph-segment mode, optispeech_amd/graphs.py)."""
         B = x.shape[0]
         Tt, Tm = x.shape[1], mel.shape[2]
         x_lengths = x_lengths.contiguous()
@@ -102,12 +115,7 @@ class OptiSpeechGenerator(nn.Module):
         r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=y.device)
         start_idx = (r.to(y.device) * max_start).to(torch.long)                             # utils/segments.py:32-34
         segment = K.gather_rows(y.detach(), start_idx, segment_size)                        # :149-153, detach :161
-        # :161 (f0 unused by WaveNeXt).  The vocoder's graph is disjoint from the acoustic model's (``segment`` is detached):
-        # built on its own stream, its backward overlaps the acoustic model's backward
-        if _VOC_STREAM and segment.is_cuda and torch.is_grad_enabled():
-            wav_hat = ops.run_on_side_stream("vocoder", lambda: self.vocoder(segment, f0=None), [segment])
-        else:
-            wav_hat = self.vocoder(segment, f0=None)
+        wav_hat = vocoder_hook(segment) if vocoder_hook is not None else None
 
         c = self.loss_coeffs
         duration_loss, pitch_loss, energy_loss = ops.VarianceLossFn.apply(

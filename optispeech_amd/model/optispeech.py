@@ -91,6 +91,10 @@ class OptiSpeech(nn.Module):
         #: turns it on
         self.graph_steps = os.environ.get("OSP_GRAPH_STEPS", "0") == "1"
         self._step_graphs = {}
+        #: acoustic model + vocoder (forward and backward) replayed from captured hipGraphs inside the otherwise eager,
+        #: multi-stream step (optispeech_amd/graphs.py: GeneratorSegments): removes ~2/3 of the step's host time
+        self.graph_segments = os.environ.get("OSP_GRAPH_SEGMENTS", "0") == "1"
+        self._gen_segments = {}
         self._dstream = None
         self._disc_param_list = None
         self._reducers = None
@@ -138,9 +142,13 @@ class OptiSpeech(nn.Module):
         """base_lightning_module.py:24-45; the ground-truth segment gather happens on the device."""
         dev = self.device
         t = lambda v: v.to(dev, non_blocking=True) if v is not None else None      # noqa: E731
-        gen_outputs = self.generator(x=t(batch["x"]), x_lengths=t(batch["x_lengths"]), mel=t(batch["mel"]),
-                                     mel_lengths=t(batch["mel_lengths"]), pitches=t(batch["pitches"]),
-                                     energies=t(batch["energies"]), sids=t(batch.get("sids")), lids=t(batch.get("lids")))
+        if (self.graph_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
+                and batch.get("lids") is None and self.train_args.gradient_accumulate_batches is None):
+            gen_outputs = self._graphed_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
+        else:
+            gen_outputs = self.generator(x=t(batch["x"]), x_lengths=t(batch["x_lengths"]), mel=t(batch["mel"]),
+                                         mel_lengths=t(batch["mel_lengths"]), pitches=t(batch["pitches"]),
+                                         energies=t(batch["energies"]), sids=t(batch.get("sids")), lids=t(batch.get("lids")))
         wav = batch["wav"]
         if isinstance(wav, np.ndarray):
             wav = torch.from_numpy(wav)
@@ -152,6 +160,23 @@ class OptiSpeech(nn.Module):
         rows = wav.contiguous().view(B, -1, hop)
         gen_outputs["wav"] = K.gather_rows(rows, gen_outputs["start_idx"], seg).view(B, seg * hop)
         return gen_outputs
+
+    def _graphed_generator(self, tensors):
+        """generator.forward through the two graphed segments (captured on the first call with this batch signature)."""
+        from .. import ops, precision
+        from ..graphs import GeneratorSegments
+        key = (tuple((tuple(v.shape), str(v.dtype)) for v in tensors), precision.get_precision(), self.generator.segment_rand01 is not None)
+        segs = self._gen_segments.get(key)
+        if segs is None:
+            if len(self._gen_segments) >= 4:
+                self._gen_segments.pop(next(iter(self._gen_segments)))
+            self.optimizers()                                  # the arenas must exist: captured kernels write the gradient arena
+            segs = self._gen_segments[key] = GeneratorSegments(self, tensors)
+        segs.push_seed()
+        loss, align, dur, pit, ene, segment, start_idx = segs.am(*tensors)
+        wav_hat = ops.run_on_side_stream("vocoder", lambda: segs.voc(segment)[0], [segment])
+        return {"wav_hat": wav_hat, "start_idx": start_idx, "segment_size": segs.segment_size, "loss": loss,
+                "align_loss": align.detach(), "duration_loss": dur.detach(), "pitch_loss": pit.detach(), "energy_loss": ene.detach()}
 
     def training_step(self, batch, batch_idx=0, **kwargs):
         """base_lightning_module.py:78-126.

@@ -23,7 +23,9 @@ def _run(mode, steps=3):
         sch.warmup = 4
         sch.opt.lr = sch.base_lr * (1.0 / 4)
         sch.last_step = 1
-    if mode != "eager":
+    if mode == "hybrid":                                          # acoustic model + vocoder as graphed segments inside the eager step
+        m.graph_segments = True
+    elif mode != "eager":
         m.graph_steps = True
         m.graph_warmup_steps = 1
         m.graph_force_segments = mode == "segments"
@@ -38,16 +40,19 @@ def _run(mode, steps=3):
     return per_step, {k: v.detach().clone() for k, v in m.state_dict().items()}, host, m
 
 
-@pytest.mark.parametrize("mode", ["graph", "segments"])
+@pytest.mark.parametrize("mode", ["graph", "segments", "hybrid"])
 def test_graphed_step_matches_eager(mode):
     from optispeech_amd import precision
     precision.set_precision("bf16")
     try:
         la, sa, ha, _ = _run("eager")
         lb, sb, hb, m = _run(mode)
-        assert len(m._step_graphs) == 1
-        sg = next(iter(m._step_graphs.values()))
-        assert len(sg.graphs) == (1 if mode == "graph" else 5)
+        if mode == "hybrid":
+            assert len(m._gen_segments) == 1 and not m._step_graphs
+        else:
+            assert len(m._step_graphs) == 1
+            sg = next(iter(m._step_graphs.values()))
+            assert len(sg.graphs) == (1 if mode == "graph" else 5)
         assert ha == hb, (ha, hb)                                 # step counts, schedule position, lr, seed: same bookkeeping
         # every step of the graph run is a replay (the capture's warm-up is rolled back)
         for i, (x, y) in enumerate(zip(la, lb)):
