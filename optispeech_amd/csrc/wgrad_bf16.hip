@@ -764,3 +764,61 @@ extern "C" int osp_pack_bf16(const float* w, const float* kscale, void* out, int
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+
+// Many weight packs in one launch (the ConvNeXt blocks of a backbone need 3-4 bf16 copies each per optimiser step: W1, W2,
+// W1^T and gamma * W2^T; one osp_pack_bf16 launch apiece was 48-64 launches per step).  desc_host: count rows of 10 int64
+// {w, kscale (0 = none), out, N, taps, K, sN, sT, sK, reserved}; a workgroup finds its item in a prefix table of 32x32 tiles.
+#define PACK_MULTI_MAX 32
+struct PackMulti { const float* w[PACK_MULTI_MAX]; const float* ks[PACK_MULTI_MAX]; unsigned short* out[PACK_MULTI_MAX];
+                   int N[PACK_MULTI_MAX], taps[PACK_MULTI_MAX], K[PACK_MULTI_MAX], tk[PACK_MULTI_MAX], tn[PACK_MULTI_MAX];
+                   long long sN[PACK_MULTI_MAX], sT[PACK_MULTI_MAX], sK[PACK_MULTI_MAX]; int first[PACK_MULTI_MAX + 1]; int count; };
+__global__ __launch_bounds__(256) void pack_bf16_multi_kernel(PackMulti d) {
+    __shared__ float tile[32][33];
+    int it = 0;
+    for (int i = 1; i < d.count; ++i) it = (int)blockIdx.x >= d.first[i] ? i : it;
+    int b = blockIdx.x - d.first[it];
+    const int kt = b % d.tk[it]; b /= d.tk[it];
+    const int nt = b % d.tn[it], tap = b / d.tn[it];
+    const int N = d.N[it], K = d.K[it], taps = d.taps[it];
+    const long long sN = d.sN[it], sK = d.sK[it];
+    const float* src = d.w[it] + (long long)tap * d.sT[it];
+    const float* kscale = d.ks[it];
+    const int n0 = nt * 32, k0 = kt * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool along_n = (sN < 0 ? -sN : sN) < (sK < 0 ? -sK : sK);
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = along_n ? n0 + tx : n0 + r, k = along_n ? k0 + r : k0 + tx;
+        const float v = (n < N && k < K) ? src[(long long)n * sN + (long long)k * sK] * (kscale ? kscale[k] : 1.f) : 0.f;
+        if (along_n) tile[r][tx] = v; else tile[tx][r] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) d.out[it][((long long)n * taps + tap) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][r]);
+    }
+}
+extern "C" int osp_pack_bf16_multi(const int64_t* desc_host, int64_t count, hipStream_t stream) {
+    OSP_CHECK_ARG(desc_host && count > 0, "bad args");
+    for (int64_t lo = 0; lo < count; lo += PACK_MULTI_MAX) {
+        PackMulti d;
+        const int64_t hi = lo + PACK_MULTI_MAX < count ? lo + PACK_MULTI_MAX : count;
+        int blocks = 0;
+        d.count = (int)(hi - lo);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t* r = desc_host + 10 * i;
+            const int k = (int)(i - lo);
+            d.w[k] = (const float*)(intptr_t)r[0]; d.ks[k] = (const float*)(intptr_t)r[1]; d.out[k] = (unsigned short*)(intptr_t)r[2];
+            d.N[k] = (int)r[3]; d.taps[k] = (int)r[4]; d.K[k] = (int)r[5]; d.sN[k] = r[6]; d.sT[k] = r[7]; d.sK[k] = r[8];
+            OSP_CHECK_ARG(d.w[k] && d.out[k] && d.N[k] > 0 && d.taps[k] > 0 && d.K[k] > 0, "bad descriptor");
+            d.tk[k] = (d.K[k] + 31) / 32; d.tn[k] = (d.N[k] + 31) / 32;
+            d.first[k] = blocks;
+            blocks += d.tk[k] * d.tn[k] * d.taps[k];
+        }
+        d.first[d.count] = blocks;
+        hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d);
+    }
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

@@ -428,6 +428,50 @@ def param_bf16(p, transposed=False):
     return cache[1][transposed]
 
 
+def param_bf16_many(requests):
+    """Fill the per-parameter bf16 pack cache (param_bf16 / the gamma-scaled transposed pack of the block backward) for a list of
+    requests in ONE launch: requests = [(param (N, K), transposed: bool, kscale tensor or None)].  Entries that are already
+    valid for the current optimiser epoch are skipped."""
+    import numpy as np
+    from . import values
+    rows, fills = [], []
+    for p, transposed, kscale in requests:
+        stamp = (values.param_epoch(), p._version, p.data_ptr())
+        cache = getattr(p, "_osp_bf16", None)
+        if cache is None or cache[0] != stamp:
+            cache = (stamp, {})
+            p._osp_bf16 = cache
+        key = transposed if kscale is None else ("t_scaled", kscale.data_ptr(), kscale._version)
+        if key in cache[1]:
+            continue
+        N, Kd = p.shape
+        if transposed or kscale is not None:                     # out[k_dim = N index ... ] : (Kd rows, N reduction) = W^T
+            out = torch.empty((Kd, N), device=p.device, dtype=torch.bfloat16)
+            rows.append([p.data_ptr(), 0 if kscale is None else kscale.data_ptr(), out.data_ptr(), Kd, 1, N, 1, 0, Kd, 0])
+        else:
+            out = torch.empty((N, Kd), device=p.device, dtype=torch.bfloat16)
+            rows.append([p.data_ptr(), 0, out.data_ptr(), N, 1, Kd, Kd, 0, 1, 0])
+        fills.append((cache[1], key, out))
+    if not rows:
+        return
+    d = np.asarray(rows, dtype=np.int64)
+    call("osp_pack_bf16_multi", d.ctypes.data, len(rows))
+    for dct, key, out in fills:
+        dct[key] = out
+
+
+def param_bf16_scaled_t(p, kscale):
+    """gamma-scaled transposed pack of a (C, I) weight: out[i, c] = p[c, i] * kscale[c] (cached per optimiser epoch)."""
+    from . import values
+    stamp = (values.param_epoch(), p._version, p.data_ptr())
+    cache = getattr(p, "_osp_bf16", None)
+    key = ("t_scaled", kscale.data_ptr(), kscale._version)
+    if cache is not None and cache[0] == stamp and key in cache[1]:
+        return cache[1][key]
+    param_bf16_many([(p, True, kscale)])
+    return p._osp_bf16[1][key]
+
+
 def cast_bf16(x):
     y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
     call("osp_cast_bf16", x.contiguous(), y, x.numel())

@@ -8,7 +8,8 @@ from typing import Optional
 import torch
 from torch import nn
 
-from .. import ops, rng
+from .. import kernels as K
+from .. import ops, precision, rng
 from .base import RefSchemaModule, conv_to_native, conv_to_ref, dw_to_native, dw_to_ref
 
 
@@ -85,6 +86,18 @@ class ConvNeXtBackbone(nn.Module):
 
     def forward(self, x, padding_mask=None):
         rm = row_mask(padding_mask)
+        if precision.is_bf16() and x.is_cuda:
+            # every bf16 weight copy the blocks of this backbone will ask for in this optimiser epoch (forward: W1, W2; backward:
+            # W1^T and gamma * W2^T), packed by ONE launch instead of 3-4 per block
+            need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            req = []
+            for blk in self.convnext:
+                if blk.intermediate_dim % 64 == 0 and blk.dim % 64 == 0:
+                    req += [(blk.pwconv1_weight, False, None), (blk.pwconv2_weight, False, None)]
+                    if need_bwd:
+                        req += [(blk.pwconv1_weight, True, None), (blk.pwconv2_weight, True, blk.gamma)]
+            if req:
+                K.param_bf16_many(req)
         for blk in self.convnext:
             x = blk(x, rm)
         return self.final_layer_norm(x)

@@ -77,7 +77,7 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         # du[m,k] = rowf[m] * sum_n dy[m,n] * gamma[n] W2[n,k] * gelu'(u[m,k])
         if ctx.lowp:
             # gamma is folded into the transposed bf16 weight pack (kscale), the row factor into the bf16 copy of dy
-            du = K.conv_gemm_bf16(dy2, K.pack_bf16(W2.detach(), I, 1, C, (1, 0, I), kscale=gamma.detach()), I, M=M, Trows=M, Tin=M,
+            du = K.conv_gemm_bf16(dy2, K.param_bf16_scaled_t(W2, gamma), I, M=M, Trows=M, Tin=M,
                                   cin=C, epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u, out_bf16=True)
             if _want(W2):
                 dys = K.cast_bf16_rows(dy2, rowf)
