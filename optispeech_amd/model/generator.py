@@ -121,13 +121,18 @@ class OptiSpeechGenerator(nn.Module):
         duration_loss, pitch_loss, energy_loss = ops.VarianceLossFn.apply(
             duration_hat, pitch_hat, energy_hat, durations, p_avg, e_avg, x_lengths)        # :165-173
         ops.join_side_stream()                                                              # the CTC recursion ran alongside
-        align_loss = forwardsum_loss + bin_loss                                             # :175
-        loss = (align_loss * c.lambda_align + duration_loss * c.lambda_duration + pitch_loss * c.lambda_pitch
-                + energy_loss * c.lambda_energy)                                            # :176-181
+        align_loss = forwardsum_loss.detach() + bin_loss.detach()                           # :175 (logged value)
+        if forwardsum_loss.is_cuda:
+            # :176-181 as one node: lambda_align * (forwardsum + bin) + lambda_d * dur + lambda_p * pitch + lambda_e * energy
+            loss = ops.weighted_sum([forwardsum_loss, bin_loss, duration_loss, pitch_loss, energy_loss],
+                                    [c.lambda_align, c.lambda_align, c.lambda_duration, c.lambda_pitch, c.lambda_energy])
+        else:
+            loss = ((forwardsum_loss + bin_loss) * c.lambda_align + duration_loss * c.lambda_duration + pitch_loss * c.lambda_pitch
+                    + energy_loss * c.lambda_energy)
         # NB: the reference moves the sub-losses to the CPU here (4 device syncs); we keep them on the device and
         # let the caller fetch all scalars with one copy.
         return {"wav_hat": wav_hat, "start_idx": start_idx, "segment_size": segment_size, "loss": loss,
-                "align_loss": align_loss.detach(), "duration_loss": duration_loss.detach(),
+                "align_loss": align_loss, "duration_loss": duration_loss.detach(),
                 "pitch_loss": pitch_loss.detach(), "energy_loss": energy_loss.detach(),
                 "_aux": {"log_p_attn": log_p_attn, "durations": durations, "path": path, "p_avg": p_avg,
                          "e_avg": e_avg, "duration_hat": duration_hat, "pitch_hat": pitch_hat,

@@ -47,10 +47,10 @@ class ConvNeXtBlock(RefSchemaModule):
         for w in (self.dwconv_weight, self.pwconv1_weight, self.pwconv2_weight):
             nn.init.trunc_normal_(w, std=0.02)                                   # convnext.py:87-90
 
-    def forward(self, x, rowmask=None):
-        """x (B,T,C) channels-last; rowmask (B*T,) keep mask applied after the residual (convnext.py:99-101)."""
-        rowscale = None
-        if self.training and self.drop_prob > 0.0:                              # DropPath, convnext.py:121-129
+    def forward(self, x, rowmask=None, rowscale=None):
+        """x (B,T,C) channels-last; rowmask (B*T,) keep mask applied after the residual (convnext.py:99-101); rowscale (B*T,):
+        this block's DropPath factors when the backbone drew them for all blocks at once (None = draw here)."""
+        if rowscale is None and self.training and self.drop_prob > 0.0:         # DropPath, convnext.py:121-129
             B, T, _ = x.shape
             keep = 1.0 - self.drop_prob
             r = torch.empty((B, 1), device=x.device, dtype=torch.float32).bernoulli_(keep) / keep
@@ -98,9 +98,23 @@ class ConvNeXtBackbone(nn.Module):
                         req += [(blk.pwconv1_weight, True, None), (blk.pwconv2_weight, True, blk.gamma)]
             if req:
                 K.param_bf16_many(req)
-        for blk in self.convnext:
-            x = blk(x, rm)
+        scales = self._drop_path_scales(x) if self.training else None
+        for i, blk in enumerate(self.convnext):
+            x = blk(x, rm, None if scales is None else scales[i])
         return self.final_layer_norm(x)
+
+    def _drop_path_scales(self, x):
+        """DropPath factors of ALL blocks from one uniform draw (convnext.py:121-129 draws bernoulli(keep) / keep per block and
+        utterance): (L, B*T) rows, or None when no block drops.  Five launches per backbone instead of three per block."""
+        if not any(b.drop_prob > 0.0 for b in self.convnext):
+            return None
+        B, T, _ = x.shape
+        keep = getattr(self, "_keep", None)
+        if keep is None or keep.device != x.device:
+            keep = self._keep = torch.tensor([1.0 - b.drop_prob for b in self.convnext], dtype=torch.float32, device=x.device)[:, None]
+        u = torch.rand((len(self.convnext), B), device=x.device)
+        sc = (u < keep).to(torch.float32) / keep                              # (L, B): 1/keep with probability keep, else 0
+        return sc[:, :, None].expand(-1, B, T).reshape(len(self.convnext), B * T)
 
 
 # =================================================================================================== text embedding

@@ -499,3 +499,34 @@ def _named_stream(key, device):
     if k not in _named:
         _named[k] = torch.cuda.Stream(device=device)
     return _named[k]
+
+
+# ------------------------------------------------------------------------------------------------ scalar loss assembly
+class WeightedSumFn(torch.autograd.Function):
+    """sum_i coeff_i * term_i over device scalars in ONE autograd node: forward = a stack and a dot product, backward = one
+    multiply (the gradients of the terms are views of it).  The loss assemblies (generator/__init__.py:175-181,
+    vocoder/wavenext/disc/__init__.py:105-111) were ~8 tiny launches forward and as many backward each."""
+
+    @staticmethod
+    def forward(ctx, coeffs, *terms):
+        st = torch.stack([t.reshape(()).float() for t in terms])
+        ctx.save_for_backward(coeffs)
+        return torch.dot(st, coeffs)
+
+    @staticmethod
+    def backward(ctx, g):
+        (coeffs,) = ctx.saved_tensors
+        gs = g * coeffs
+        return (None,) + tuple(gs.unbind(0))
+
+
+_COEFF_CACHE = {}
+
+
+def weighted_sum(terms, coeffs):
+    """terms: device scalars, coeffs: python floats (cached as a device vector)."""
+    key = (tuple(float(c) for c in coeffs), str(terms[0].device))
+    ct = _COEFF_CACHE.get(key)
+    if ct is None:
+        ct = _COEFF_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=terms[0].device)
+    return WeightedSumFn.apply(ct, *terms)
