@@ -241,7 +241,9 @@ class ConvStackFn(torch.autograd.Function):
             packs.append(item)                                  # (wn, wt, inv)
         g = _stack_backward(x, acts, packs, ctx.params, spec, slope, need_x, need_w, (d1, d2, d3, d4, d5), ds)
         if need_x and ctx.u0:                                    # gradient of the whole input: zeros for the no-grad head
-            full = torch.zeros((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+            # the head rows belong to the real waves, which carry no gradient: whatever stands there is narrowed away by the
+            # backward of the torch.cat that built the batch (per-sample ops only in between), so they are not zero-filled
+            full = torch.empty((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
             full[ctx.u0:] = g
             g = full
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)

@@ -286,24 +286,28 @@ def _fused_losses(t):
     return precision.is_bf16() and t.is_cuda and _FUSED_LOSSES
 
 
-def _hinge_g(outs):                                            # GeneratorLoss, disc/loss.py:16-32
+def _hinge_g(outs, raw=False):                                 # GeneratorLoss, disc/loss.py:16-32
+    """raw=True (fused mode only): the un-normalised sum; the caller folds 1 / len(outs) into its weighted sum."""
     if _fused_losses(outs[0]):
-        return HingeSumFn.apply((-1.0,) * len(outs), *outs) / len(outs)
+        s = HingeSumFn.apply((-1.0,) * len(outs), *outs)
+        return s if raw else s / len(outs)
     return sum(torch.mean(torch.clamp(1 - o, min=0)) for o in outs) / len(outs)
 
 
-def _hinge_d(real, fake):                                      # DiscriminatorLoss, disc/loss.py:40-65
+def _hinge_d(real, fake, raw=False):                           # DiscriminatorLoss, disc/loss.py:40-65
     if _fused_losses(real[0]):
-        return HingeSumFn.apply((-1.0,) * len(real) + (1.0,) * len(fake), *real, *fake) / len(real)
+        s = HingeSumFn.apply((-1.0,) * len(real) + (1.0,) * len(fake), *real, *fake)
+        return s if raw else s / len(real)
     return sum(torch.mean(torch.clamp(1 - r, min=0)) + torch.mean(torch.clamp(1 + g, min=0))
                for r, g in zip(real, fake)) / len(real)
 
 
-def _feature_matching(fr, fg):                                 # FeatureMatchingLoss, disc/loss.py:71-85
+def _feature_matching(fr, fg, raw=False):                      # FeatureMatchingLoss, disc/loss.py:71-85
     if _fused_losses(fg[0][0]):
         tg = [a.detach() for dr in fr for a in dr]
         ys = [b for dg in fg for b in dg]
-        return FeatureMatchSumFn.apply(len(ys), *tg, *ys) / len(fr)
+        s = FeatureMatchSumFn.apply(len(ys), *tg, *ys)
+        return s if raw else s / len(fr)
     tot = 0
     for dr, dg in zip(fr, fg):
         for a, b in zip(dr, dg):
@@ -350,6 +354,13 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         r_mp, g_mp, _, _ = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True, pre=pre, replay=replay)
         r_mr, g_mr, _, _ = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True, pre=pre, replay=replay)
         join_streams()
+        if _fused_losses(r_mp[0]):
+            # the 1 / #sub-discriminators of each family and lambda_mrd are coefficients of ONE weighted-sum node
+            from ..ops import weighted_sum
+            s_mp, s_mr = _hinge_d(r_mp, g_mp, raw=True), _hinge_d(r_mr, g_mr, raw=True)
+            n_mp, n_mr = len(r_mp), len(r_mr)
+            loss = weighted_sum([s_mp, s_mr], [1.0 / n_mp, self.loss_coeffs.lambda_mrd / n_mr])
+            return loss, dict(loss_mp=s_mp.detach() / n_mp, loss_mrd=s_mr.detach() / n_mr)
         loss_mp, loss_mrd = _hinge_d(r_mp, g_mp), _hinge_d(r_mr, g_mr)
         loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd
         return loss, dict(loss_mp=loss_mp.detach(), loss_mrd=loss_mrd.detach())
@@ -365,9 +376,18 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
             mel_loss = self._get_mel_loss(wav, wav_hat)
             mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
         join_streams()
+        lam = self.loss_coeffs.lambda_mrd
+        if _fused_losses(g_mp[0]):
+            from ..ops import weighted_sum
+            n_mp, n_mr = len(g_mp), len(g_mr)
+            s = [_hinge_g(g_mp, raw=True), _hinge_g(g_mr, raw=True), _feature_matching(fr_mp, fg_mp, raw=True),
+                 _feature_matching(fr_mr, fg_mr, raw=True)]
+            loss = weighted_sum(s + [mel_loss, mr_stft_loss], [1.0 / n_mp, lam / n_mr, 1.0 / n_mp, lam / n_mr, 1.0, 1.0])
+            logs = dict(loss_gen_mp=s[0].detach() / n_mp, loss_gen_mrd=s[1].detach() / n_mr, loss_fm_mp=s[2].detach() / n_mp,
+                        loss_fm_mrd=s[3].detach() / n_mr, mel_loss=mel_loss.detach(), mr_stft_loss=mr_stft_loss.detach())
+            return loss, logs
         loss_gen_mp, loss_gen_mrd = _hinge_g(g_mp), _hinge_g(g_mr)
         loss_fm_mp, loss_fm_mrd = _feature_matching(fr_mp, fg_mp), _feature_matching(fr_mr, fg_mr)
-        lam = self.loss_coeffs.lambda_mrd
         if loss_gen_mp.is_cuda:
             from ..ops import weighted_sum
             loss = weighted_sum([loss_gen_mp, loss_gen_mrd, loss_fm_mp, loss_fm_mrd, mel_loss, mr_stft_loss], [1.0, lam, 1.0, lam, 1.0, 1.0])

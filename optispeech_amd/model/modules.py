@@ -47,7 +47,7 @@ class ConvNeXtBlock(RefSchemaModule):
         for w in (self.dwconv_weight, self.pwconv1_weight, self.pwconv2_weight):
             nn.init.trunc_normal_(w, std=0.02)                                   # convnext.py:87-90
 
-    def forward(self, x, rowmask=None, rowscale=None):
+    def forward(self, x, rowmask=None, rowscale=None, rowf=None):
         """x (B,T,C) channels-last; rowmask (B*T,) keep mask applied after the residual (convnext.py:99-101); rowscale (B*T,):
         this block's DropPath factors when the backbone drew them for all blocks at once (None = draw here)."""
         if rowscale is None and self.training and self.drop_prob > 0.0:         # DropPath, convnext.py:121-129
@@ -57,7 +57,7 @@ class ConvNeXtBlock(RefSchemaModule):
             rowscale = r.expand(B, T).reshape(-1).contiguous()
         return ops.ConvNeXtBlockFn.apply(x, self.dwconv_weight, self.dwconv_bias, self.norm_weight, self.norm_bias,
                                          self.pwconv1_weight, self.pwconv1_bias, self.pwconv2_weight,
-                                         self.pwconv2_bias, self.gamma, rowmask, rowscale)
+                                         self.pwconv2_bias, self.gamma, rowmask, rowscale, rowf)
 
 
 class FinalNorm(RefSchemaModule):
@@ -99,8 +99,9 @@ class ConvNeXtBackbone(nn.Module):
             if req:
                 K.param_bf16_many(req)
         scales = self._drop_path_scales(x) if self.training else None
+        rowfs = scales * rm[None] if (scales is not None and rm is not None) else None     # (L, B*T): mask x DropPath, one launch
         for i, blk in enumerate(self.convnext):
-            x = blk(x, rm, None if scales is None else scales[i])
+            x = blk(x, rm, None if scales is None else scales[i], None if rowfs is None else rowfs[i])
         return self.final_layer_norm(x)
 
     def _drop_path_scales(self, x):

@@ -29,7 +29,7 @@ class ConvNeXtBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, dw, dwb, lnw, lnb, W1, b1, W2, b2, gamma, rowmask, rowscale):
+    def forward(ctx, x, dw, dwb, lnw, lnb, W1, b1, W2, b2, gamma, rowmask, rowscale, rowf_pre=None):
         B, T, C = x.shape
         I = W1.shape[0]
         M = B * T
@@ -56,7 +56,9 @@ class ConvNeXtBlockFn(torch.autograd.Function):
             y = K.conv_gemm(g, W2, C, epi=K.EPI_SCALE_RES_MASK, bias=b2, gamma=gamma, res=x.view(M, C),
                             rowmask=rowmask, rowscale=rowscale, aux_out=z)
         if save:
-            if rowmask is not None and rowscale is not None:
+            if rowf_pre is not None:
+                rowf = rowf_pre                                  # rowmask * rowscale, computed for all blocks of the backbone at once
+            elif rowmask is not None and rowscale is not None:
                 rowf = rowmask * rowscale
             else:
                 rowf = rowmask if rowmask is not None else rowscale
@@ -101,7 +103,7 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         wd = _want(dw)
         dx = K.dwconv7_bwd(dc.view(B, T, C), x, dw, dy2.view(B, T, C), rowmask, gsink(dw) if wd else None,
                            gsink(dwb) if wd else None)
-        return (dx,) + (None,) * 11
+        return (dx,) + (None,) * 12
 
 
 class LayerNormFn(torch.autograd.Function):
