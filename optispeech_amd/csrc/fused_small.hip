@@ -431,3 +431,23 @@ extern "C" int osp_spectral_loss_bwd(const float* x, const float* y, int64_t n, 
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ random segment starts
+// get_random_segments (utils/segments.py:12-38, caller generator/__init__.py:147-153): with num_frames = float(len - 4),
+//   max_start = clamp(num_frames - segment_size, min = 0);  start = long(rand01 * max_start)        (all in f32, as upstream)
+__global__ void segment_starts_kernel(const float* __restrict__ r01, const int64_t* __restrict__ lens, int B, float lead, float seg,
+                                      int64_t* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float max_start = fmaxf((float)(lens[b] - (int64_t)lead) - seg, 0.f);
+    out[b] = (int64_t)(r01[b] * max_start);
+}
+extern "C" int osp_segment_starts(const float* r01, const int64_t* lens, int64_t B, int64_t lead, int64_t segment_size, int64_t* out,
+                                  hipStream_t stream) {
+    OSP_CHECK_ARG(r01 && lens && out && B > 0 && segment_size >= 0, "bad args");
+    hipLaunchKernelGGL(segment_starts_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, stream, r01, lens, (int)B, (float)lead,
+                       (float)segment_size, out);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

@@ -250,6 +250,15 @@ def gather_rows(src, start, S, mult=1):
     return out
 
 
+def segment_starts(r01, lengths, segment_size, lead=4):
+    """long(r01 * clamp(float(len - lead) - segment_size, 0)) per utterance (utils/segments.py:29-34), one launch."""
+    _f32(r01)
+    _lens(lengths)
+    out = torch.empty_like(lengths)
+    call("osp_segment_starts", r01.contiguous(), lengths, lengths.numel(), int(lead), int(segment_size), out)
+    return out
+
+
 def expand_by_duration(x, dur, Tout):
     _f32(x)
     _lens(dur)

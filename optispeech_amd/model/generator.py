@@ -110,10 +110,14 @@ class OptiSpeechGenerator(nn.Module):
             y = self.decoder(y.detach(), target_padding_mask)
 
         segment_size = min(self.segment_size, y.shape[1])                                   # :147
-        num_frames = (mel_lengths - 4).to(torch.float32)                                    # :148
-        max_start = (num_frames - segment_size).clamp_(min=0)                               # utils/segments.py:29-31
         r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=y.device)
-        start_idx = (r.to(y.device) * max_start).to(torch.long)                             # utils/segments.py:32-34
+        if y.is_cuda:
+            # :148 + utils/segments.py:29-34 in one launch: long(r * clamp(float(len - 4) - segment_size, 0))
+            start_idx = K.segment_starts(r.to(device=y.device, dtype=torch.float32), mel_lengths, segment_size)
+        else:
+            num_frames = (mel_lengths - 4).to(torch.float32)                                # :148
+            max_start = (num_frames - segment_size).clamp_(min=0)                           # utils/segments.py:29-31
+            start_idx = (r.to(y.device) * max_start).to(torch.long)                         # utils/segments.py:32-34
         segment = K.gather_rows(y.detach(), start_idx, segment_size)                        # :149-153, detach :161
         wav_hat = vocoder_hook(segment) if vocoder_hook is not None else None
 

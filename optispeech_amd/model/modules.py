@@ -17,7 +17,17 @@ def row_mask(padding_mask):
     """(B,T) bool True=pad  ->  (B*T,) float keep mask (1 - padding_mask.float(), convnext.py:95)."""
     if padding_mask is None:
         return None
-    return (~padding_mask).to(torch.float32).reshape(-1).contiguous()
+    # one mask tensor is handed to several modules of a forward (encoder, three predictors, two embeds ...): convert it once and
+    # keep the result on the tensor object (it dies with the mask; a bool mask is never written in place on the path)
+    ver = -1 if padding_mask.is_inference() else padding_mask._version        # inference tensors keep no version counter
+    hit = getattr(padding_mask, "_osp_rowmask", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, (~padding_mask).to(torch.float32).reshape(-1).contiguous())
+        try:
+            padding_mask._osp_rowmask = hit
+        except (AttributeError, RuntimeError):
+            pass
+    return hit[1]
 
 
 class ConvNeXtBlock(RefSchemaModule):

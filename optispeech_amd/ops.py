@@ -362,7 +362,7 @@ class AlignLossFn(torch.autograd.Function):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             loss_item, grad = K.forwardsum_ctc(lp, x_len, y_len, want_grad=need)
-            fs = loss_item.sum() / B
+            fs = loss_item.mean()
         for t in (lp, x_len, y_len):
             t.record_stream(side)
         for t in (fs, grad):
@@ -371,7 +371,7 @@ class AlignLossFn(torch.autograd.Function):
         _pending_side.append(side.record_event())
         if need:
             ctx.save_for_backward(grad, path, y_len)
-        return fs, bin_item.sum() / B
+        return fs, bin_item.mean()
 
     @staticmethod
     def backward(ctx, g_fs, g_bin):

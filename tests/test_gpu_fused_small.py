@@ -131,3 +131,15 @@ def test_convnext_backbone_bf16_mode_vs_f32_mode(C, I, L):
     assert rel(yb, ya) < 1e-2 and rel(dxb, dxa) < 2e-2, (rel(yb, ya), rel(dxb, dxa))
     for n in ga:
         assert rel(gb[n], ga[n]) < 3e-2, (n, rel(gb[n], ga[n]))
+
+
+def test_segment_starts_matches_upstream_formula():
+    # utils/segments.py:29-34 with the caller's num_frames = float(len - 4) (generator/__init__.py:148)
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(3, 900, (37,), generator=g).cuda()
+    r = torch.rand(37, generator=g).cuda()
+    for seg in (0, 16, 64, 1000):
+        got = K.segment_starts(r, lens, seg)
+        want = (r * ((lens - 4).to(torch.float32) - seg).clamp_(min=0)).to(torch.long)
+        assert torch.equal(got, want)
