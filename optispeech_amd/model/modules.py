@@ -19,7 +19,10 @@ def row_mask(padding_mask):
         return None
     # one mask tensor is handed to several modules of a forward (encoder, three predictors, two embeds ...): convert it once and
     # keep the result on the tensor object (it dies with the mask; a bool mask is never written in place on the path)
-    ver = -1 if padding_mask.is_inference() else padding_mask._version        # inference tensors keep no version counter
+    # inference tensors keep no version counter; a conversion done eagerly (a graph's warm-up) must not satisfy a capture, or the
+    # replayed graph would keep reading the warm-up's mask
+    ver = (-1 if padding_mask.is_inference() else padding_mask._version,
+           padding_mask.is_cuda and torch.cuda.is_current_stream_capturing())
     hit = getattr(padding_mask, "_osp_rowmask", None)
     if hit is None or hit[0] != ver:
         hit = (ver, (~padding_mask).to(torch.float32).reshape(-1).contiguous())
