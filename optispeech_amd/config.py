@@ -86,6 +86,8 @@ def make_generator(c: ModelConfig):
     from .model.generator import OptiSpeechGenerator
     from .model.modules import (ConvNeXtBackbone, DurationPredictor, EnergyPredictor, PitchPredictor, TextEmbedding)
     from .model.vocoder import WaveNeXt
+    from . import rng
+    rng.reset_streams()                   # dropout / DropPath stream ids depend on the construction order inside this model only
 
     def pred(cls, spec, **kw):
         return partial(cls, num_layers=spec[0], intermediate_dim=spec[1], kernel_size=spec[2], dropout=spec[3],

@@ -451,3 +451,41 @@ extern "C" int osp_segment_starts(const float* r01, const int64_t* lens, int64_t
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ DropPath row factors
+// DropPath of every block of a ConvNeXt backbone (generator/modules/convnext.py:121-129: bernoulli(keep) / keep per block and
+// utterance) from the package's counter-based RNG -- Philox key (seed, stream), counter = block * B + utterance -- so that a step
+// replayed from a hipGraph draws fresh factors (seed in device memory) without torch's generator:
+//   scale[l, b*T + t] = 0 with probability p_l, else 1 / (1 - p_l);     rowf[l, m] = scale[l, m] * rowmask[m]
+#define DROP_PATH_MAXL 64
+struct DropPathP { float p[DROP_PATH_MAXL]; };
+__global__ __launch_bounds__(256) void drop_path_rows_kernel(const DropPathP dp, const float* __restrict__ rowmask, uint64_t seed,
+                                                             const int64_t* __restrict__ seed_dev, uint32_t stream, float* __restrict__ scale,
+                                                             float* __restrict__ rowf, int B, int T) {
+    if (seed_dev) seed += (uint64_t)*seed_dev;
+    const int l = blockIdx.y;
+    const int64_t BT = (int64_t)B * T;
+    const float p = dp.p[l];
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < BT; m += (int64_t)gridDim.x * 256) {
+        const int b = (int)(m / T);
+        const float f = p > 0.f ? dropout_factor(seed, stream, (uint64_t)l * B + b, p) : 1.f;
+        scale[l * BT + m] = f;
+        if (rowf) rowf[l * BT + m] = f * rowmask[m];
+    }
+}
+extern "C" int osp_drop_path_rows(const float* drop_p_host, const float* rowmask, int64_t L, int64_t B, int64_t T, int64_t seed,
+                                  const int64_t* seed_dev, int64_t stream_id, float* scale, float* rowf, hipStream_t stream) {
+    OSP_CHECK_ARG(drop_p_host && scale && L > 0 && L <= DROP_PATH_MAXL && B > 0 && T > 0, "bad args");
+    OSP_CHECK_ARG((rowf != nullptr) == (rowmask != nullptr), "rowf needs rowmask (and vice versa)");
+    DropPathP dp;
+    for (int64_t l = 0; l < L; ++l) {
+        OSP_CHECK_ARG(drop_p_host[l] >= 0.f && drop_p_host[l] < 1.f, "drop probability outside [0, 1)");
+        dp.p[l] = drop_p_host[l];
+    }
+    const int64_t blocks = cdiv(B * T, 256);
+    hipLaunchKernelGGL(drop_path_rows_kernel, dim3((unsigned)(blocks < 64 ? blocks : 64), (unsigned)L), dim3(256), 0, stream, dp, rowmask,
+                       (uint64_t)seed, seed_dev, (uint32_t)stream_id, scale, rowf, (int)B, (int)T);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

@@ -440,6 +440,19 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
+    // small problems (the generator's own GEMMs: a few hundred 64x64 tiles, K <= ~1300) are latency-bound: deep LDS-DMA ring
+    // on 64x64 tiles.  f32 A operands take it up to a larger size: their alternative is the register-staged kernel, which
+    // converts right behind each load (no overlap at all).  OSP_GEMM_SMALL = 0 turns the path off (A/B runs).
+    static int use_small = -1;
+    static int64_t small_max = 160, small_max32 = 260;
+    if (use_small < 0) {
+        const char* e = getenv("OSP_GEMM_SMALL"); use_small = (e && atoi(e) == 0) ? 0 : 1;
+        const char* t = getenv("OSP_GEMM_SMALL_MAX"); if (t) small_max = atoll(t);
+        const char* u = getenv("OSP_GEMM_SMALL_MAX32"); if (u) small_max32 = atoll(u);
+    }
+    if (use_small && p.nphase == 0 && fast && sBk == 1 && b_bf16 && (Cin % TBK == 0) && N > 64 &&
+        cdiv(M, 128) * cdiv(N, 128) * batch < (a_bf16 ? small_max : small_max32))
+        return osp_launch_gemm_small(p, batch, stream);
     // tile shape: 128x128 by default; 128x64 for narrow outputs; 64x64 when the big tiles cannot fill the 256 CUs
     int bm = 128, bn = 128;
     if (N <= 64) bn = 64;

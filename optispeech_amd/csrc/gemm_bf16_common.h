@@ -391,3 +391,6 @@ __device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
 
 // register-staged kernel family (gemm_bf16_reg.hip): tile (bm x bn), k-contiguous / k-strided B, fast / generic loaders
 int osp_launch_gemm_reg(const GemmB& p, dim3 grid, int bm, int bn, bool b_kcontig, bool fast, bool bk32, hipStream_t stream);
+// small-problem kernel (gemm_bf16_small.hip): 64x64 tiles, 2 waves, 3-4 stage LDS-DMA ring; bf16 or f32 A, bf16 k-contiguous B,
+// Cin % 64 == 0, 16-byte addressable rows, no per-row A scale, no fused dgrad phases
+int osp_launch_gemm_small(const GemmB& p, int64_t batch, hipStream_t stream);

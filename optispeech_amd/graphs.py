@@ -26,7 +26,7 @@ the values it sees in the reference's order (base_lightning_module.py:78-126), o
 """
 import torch
 
-from . import rng
+from . import rng, values
 
 
 def _shape_key(model, batch, train_d):
@@ -260,6 +260,10 @@ class GraphedSegment:
                 torch.autograd.backward(go, [torch.zeros_like(o) for o in go])
             del outs, go
             torch.cuda.synchronize(dev)
+            # derived weight packs cached by the warm-up (kernels.param_bf16 / _param_pack, weight-norm packs) must be re-made INSIDE
+            # the capture: the graph then refreshes them from the live weights on every replay, in its own pool -- a pack made
+            # eagerly would be read by the replays long after the next optimizer epoch has freed it
+            values.bump_param_epoch()
             self.gf = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.gf, stream=s, capture_error_mode="thread_local"):
                 outs = fn(*self.static_in)
@@ -270,6 +274,7 @@ class GraphedSegment:
             with torch.cuda.graph(self.gb, pool=self.gf.pool(), stream=s, capture_error_mode="thread_local"):
                 torch.autograd.backward([self.outs[i] for i in self.grad_idx], self.static_go)
             self.outs = tuple(o.detach() for o in self.outs)
+            values.bump_param_epoch()                          # and nothing eager keeps using a pack that lives in the graph's pool
         cur.wait_stream(s)
 
     def __call__(self, *inputs):

@@ -27,11 +27,13 @@ def _f32(*ts):
 
 def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, out=None, epi=EPI_NONE, bias=None,
               gamma=None, res=None, rowmask=None, rowscale=None, aux_out=None, aux_in=None, a_rowscale=None,
-              accumulate=False, batch=1, batch_strides=(0, 0, 0, 0), ldc=None, lda=None):
+              accumulate=False, batch=1, batch_strides=(0, 0, 0, 0), ldc=None, lda=None, w_param=None):
     """C[m, n] = epi(sum_{j,c} A[m + j - pad, c] * W(n, j, c)).
 
     a: (M, Cin) view (row stride lda), M = utterances * T.  w: weight tensor; ``w_strides`` =
     (stride_n, stride_tap, stride_k) in elements; default is the native (N, taps, Cin) layout.
+    w_param: the leaf Parameter ``w`` is a view of -- its bf16 pack (performance mode) is then kept on the Parameter for the
+    current optimizer epoch instead of being re-made (k-strided views) or converted in the kernel's loader (contiguous ones).
     """
     _f32(a, w, bias, gamma, res, rowmask, rowscale, aux_out, aux_in, a_rowscale, out)
     M = a.shape[-2]
@@ -51,7 +53,10 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
             if t is not None:
                 ld_aux_ = t.stride(-2)
         w_bf16 = 0
-        if batch == 1 and w_strides[2] != 1:
+        if batch == 1 and w_param is not None:
+            # bf16 k-contiguous pack, cached per optimizer epoch (forward and flipped-tap dgrad views are separate entries)
+            w, w_bf16, w_strides = _param_pack(w_param, w, n_out, taps, cin, w_strides), 1, (taps * cin, cin, 1)
+        elif batch == 1 and w_strides[2] != 1:
             # k-strided (transposed / flipped) weights: one pack launch into the k-contiguous bf16 layout
             wp = torch.empty((n_out, taps, cin), device=a.device, dtype=torch.bfloat16)
             call("osp_pack_bf16", w, None, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
@@ -71,6 +76,24 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
          n_out, out, ldc, epi, bias, gamma, res, ldr, rowmask, rowscale, aux_out, aux_in, ld_aux, batch,
          batch_strides[0], batch_strides[1], batch_strides[2], batch_strides[3], bool(accumulate))
     return out
+
+
+def _param_pack(p, w, n_out, taps, cin, w_strides):
+    """(n_out, taps, cin) bf16 pack of the view ``w`` of Parameter ``p`` (element strides ``w_strides``), cached on ``p`` with the
+    invalidation rule of param_bf16: optimizer epoch, in-place version, storage address."""
+    from . import values
+    stamp = (values.param_epoch(), p._version, p.data_ptr())
+    cache = getattr(p, "_osp_packs", None)
+    if cache is None or cache[0] != stamp:
+        cache = (stamp, {})
+        p._osp_packs = cache
+    key = (w.data_ptr() - p.data_ptr(), n_out, taps, cin, tuple(w_strides))
+    wp = cache[1].get(key)
+    if wp is None:
+        wp = torch.empty((n_out, taps, cin), device=w.device, dtype=torch.bfloat16)
+        call("osp_pack_bf16", w, None, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
+        cache[1][key] = wp
+    return wp
 
 
 _WGRAD_BF16_MIN_M = int(__import__('os').environ.get('OSP_WGRAD_BF16_MIN_M', '2048'))
@@ -248,6 +271,20 @@ def gather_rows(src, start, S, mult=1):
     out = torch.empty((B, S, C), device=src.device, dtype=torch.float32)
     call("osp_gather_rows", src, start, mult, out, B, T, S, C)
     return out
+
+
+def drop_path_rows(drop_p, rowmask, B, T, seed, stream_id, device):
+    """DropPath factors of L blocks in one launch: scale (L, B*T) = 0 w.p. drop_p[l] else 1/(1-drop_p[l]) per (block, utterance),
+    and rowf = scale * rowmask (None without a mask).  Philox key (seed, stream_id): graph-replay safe (device seed)."""
+    L = len(drop_p)
+    scale = torch.empty((L, B * T), device=device, dtype=torch.float32)
+    rowf = torch.empty((L, B * T), device=device, dtype=torch.float32) if rowmask is not None else None
+    if rowmask is not None:
+        _f32(rowmask)
+    hs, ds = _seed(seed)
+    p = _host_f32(drop_p)
+    call("osp_drop_path_rows", p.ctypes.data, rowmask, L, B, T, hs, ds, int(stream_id), scale, rowf)
+    return scale, rowf
 
 
 def segment_starts(r01, lengths, segment_size, lead=4):

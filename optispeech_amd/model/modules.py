@@ -96,6 +96,7 @@ class ConvNeXtBackbone(nn.Module):
         rates = [v.item() for v in torch.linspace(0, drop_path, num_layers)]      # convnext.py:72
         self.convnext = nn.ModuleList([ConvNeXtBlock(dim, intermediate_dim, r, layer_scale_init_value) for r in rates])
         self.final_layer_norm = FinalNorm(dim, 1e-6)
+        self._drop_stream = rng.new_stream()                 # Philox stream of this backbone's DropPath draws
 
     def forward(self, x, padding_mask=None):
         rm = row_mask(padding_mask)
@@ -111,24 +112,24 @@ class ConvNeXtBackbone(nn.Module):
                         req += [(blk.pwconv1_weight, True, None), (blk.pwconv2_weight, True, blk.gamma)]
             if req:
                 K.param_bf16_many(req)
-        scales = self._drop_path_scales(x) if self.training else None
-        rowfs = scales * rm[None] if (scales is not None and rm is not None) else None     # (L, B*T): mask x DropPath, one launch
+        scales, rowfs = self._drop_path_scales(x, rm) if self.training else (None, None)
         for i, blk in enumerate(self.convnext):
             x = blk(x, rm, None if scales is None else scales[i], None if rowfs is None else rowfs[i])
         return self.final_layer_norm(x)
 
-    def _drop_path_scales(self, x):
-        """DropPath factors of ALL blocks from one uniform draw (convnext.py:121-129 draws bernoulli(keep) / keep per block and
-        utterance): (L, B*T) rows, or None when no block drops.  Five launches per backbone instead of three per block."""
-        if not any(b.drop_prob > 0.0 for b in self.convnext):
-            return None
+    def _drop_path_scales(self, x, rm):
+        """DropPath factors of ALL blocks (convnext.py:121-129 draws bernoulli(keep) / keep per block and utterance) and their
+        product with the padding mask, from the package's counter-based RNG in ONE launch: (scale (L, B*T), rowf (L, B*T) or None);
+        (None, None) when no block drops."""
+        drops = [b.drop_prob for b in self.convnext]
+        if not any(p > 0.0 for p in drops):
+            return None, None
         B, T, _ = x.shape
-        keep = getattr(self, "_keep", None)
-        if keep is None or keep.device != x.device:
-            keep = self._keep = torch.tensor([1.0 - b.drop_prob for b in self.convnext], dtype=torch.float32, device=x.device)[:, None]
-        u = torch.rand((len(self.convnext), B), device=x.device)
-        sc = (u < keep).to(torch.float32) / keep                              # (L, B): 1/keep with probability keep, else 0
-        return sc[:, :, None].expand(-1, B, T).reshape(len(self.convnext), B * T)
+        if x.is_cuda:
+            return K.drop_path_rows(drops, rm, B, T, rng.seed(), self._drop_stream, x.device)
+        keep = torch.tensor([1.0 - p for p in drops], dtype=torch.float32)[:, None]
+        sc = ((torch.rand((len(drops), B)) < keep).to(torch.float32) / keep)[:, :, None].expand(-1, B, T).reshape(len(drops), B * T)
+        return sc, (sc * rm[None] if rm is not None else None)
 
 
 # =================================================================================================== text embedding

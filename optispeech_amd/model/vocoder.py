@@ -8,7 +8,11 @@ from .. import ops
 from .base import RefSchemaModule, conv_to_native, conv_to_ref
 from .modules import ConvNeXtBackbone, FinalNorm, row_mask
 
-_PAD = 4   # the head's 1026-wide hidden is stored padded to a multiple of 4 floats (16-byte rows for float4 loads)
+# the head's (n_fft + 2 = 1026)-wide hidden is stored padded with zeros to a multiple of 64 (1088): as the reduction dimension of
+# linear_2 and of linear_1's input gradient it then is a whole number of 64-deep MFMA k-slabs with 16-byte rows (the LDS-DMA
+# kernels); a 1028-wide hidden took the element-wise generic loader (145 us per GEMM instead of ~15).  The pad weights / biases
+# are zero, receive exactly zero gradients (their inputs / upstream gradients are zero) and never enter a state dict.
+_PAD = 64
 
 
 def _pad_rows(w, n):
@@ -27,7 +31,7 @@ class _Embed(RefSchemaModule):
 
 
 class _Linear1(RefSchemaModule):
-    """linear_1 (dim -> n_fft + 2) stored with zero rows up to a multiple of 4 outputs."""
+    """linear_1 (dim -> n_fft + 2) stored with zero rows up to a multiple of _PAD outputs."""
 
     def __init__(self, cin, cout):
         super().__init__()
@@ -45,7 +49,7 @@ class _Linear1(RefSchemaModule):
 
 
 class _Linear2(RefSchemaModule):
-    """linear_2 (n_fft + 2 -> hop, no bias) stored with zero columns up to a multiple of 4 inputs."""
+    """linear_2 (n_fft + 2 -> hop, no bias) stored with zero columns up to a multiple of _PAD inputs."""
 
     def __init__(self, cin, cout):
         super().__init__()

@@ -77,12 +77,15 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         if _want(gamma):
             K.colsum_prod(dy2, z, rowf, gsink(gamma))            # dgamma[c] += sum_m rowf[m] dy[m,c] z[m,c]   (one launch)
         # du[m,k] = rowf[m] * sum_n dy[m,n] * gamma[n] W2[n,k] * gelu'(u[m,k])
-        if ctx.lowp:
-            # gamma is folded into the transposed bf16 weight pack (kscale), the row factor into the bf16 copy of dy
-            du = K.conv_gemm_bf16(dy2, K.param_bf16_scaled_t(W2, gamma), I, M=M, Trows=M, Tin=M,
-                                  cin=C, epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u, out_bf16=True)
+        # performance mode is decided HERE: a block whose forward ran in exact f32 (index-critical path, f32 u / g / h saved)
+        # still takes the bf16 MFMA kernels for its gradients -- those feed no index
+        if ctx.lowp or (_precision.is_bf16() and dy.is_cuda and I % 64 == 0 and C % 64 == 0):
+            # gamma is folded into the transposed bf16 weight pack (kscale), the row factor into the bf16 copy of dy, which is
+            # the A operand of both the input-gradient GEMM (direct-to-LDS kernels) and the weight-gradient GEMM
+            dys = K.cast_bf16_rows(dy2, rowf)
+            du = K.conv_gemm_bf16(dys, K.param_bf16_scaled_t(W2, gamma), I, M=M, Trows=M, Tin=M,
+                                  cin=C, epi=K.EPI_GELU_BWD, aux_in=u, out_bf16=True)
             if _want(W2):
-                dys = K.cast_bf16_rows(dy2, rowf)
                 K.conv_wgrad_bf16(dys, g, gsink(W2), gsink(b2) if _want(b2) else None, M=M, Trows=M, Tin=M, n=C, cin=I,
                                   oscale=gamma)
             dh = K.conv_gemm_bf16(du, K.param_bf16(W1, transposed=True), C, M=M, Trows=M, Tin=M, cin=I)
@@ -152,7 +155,7 @@ class ConvLinearFn(torch.autograd.Function):
         x = x.contiguous()
         epi = K.EPI_RELU if act == "relu" else (K.EPI_MASK if rowmask is not None else K.EPI_NONE)
         assert not (act == "relu" and rowmask is not None)
-        y = K.conv_gemm(x.view(B * T, Cin), w, cout, T=T, taps=taps, pad=pad, bias=b, epi=epi, rowmask=rowmask)
+        y = K.conv_gemm(x.view(B * T, Cin), w, cout, T=T, taps=taps, pad=pad, bias=b, epi=epi, rowmask=rowmask, w_param=w)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, y if act == "relu" else None, rowmask)
             ctx.params = (w, b)
@@ -173,7 +176,7 @@ class ConvLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             base = w.detach().view(Cout, taps, Cin)[:, taps - 1:, :]          # pointer to the last tap
             dx = K.conv_gemm(g, base, Cin, T=T, taps=taps, pad=taps - 1 - pad, cin=Cout,
-                             w_strides=(1, -Cin, taps * Cin), a_rowscale=rowmask).view(B, T, Cin)
+                             w_strides=(1, -Cin, taps * Cin), a_rowscale=rowmask, w_param=w).view(B, T, Cin)
         if _want(w):
             K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad,
                          arow=rowmask)
@@ -193,7 +196,7 @@ class PredictorLayerFn(torch.autograd.Function):
         Cout = w.shape[0]
         pad = (taps - 1) // 2
         x = x.contiguous()
-        r = K.conv_gemm(x.view(B * T, Cin), w, Cout, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_RELU)
+        r = K.conv_gemm(x.view(B * T, Cin), w, Cout, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_RELU, w_param=w)
         save = any(ctx.needs_input_grad)
         y, mean, rstd = K.layernorm_fwd(r, lnw, lnb, 1e-12, save=save, drop_p=drop_p, seed=seed, stream_id=stream_id)
         if save:
@@ -216,7 +219,7 @@ class PredictorLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             base = w.detach()[:, taps - 1:, :]
             dx = K.conv_gemm(g, base, Cin, T=T, taps=taps, pad=taps - 1 - pad, cin=Cout,
-                             w_strides=(1, -Cin, taps * Cin)).view(B, T, Cin)
+                             w_strides=(1, -Cin, taps * Cin), w_param=w).view(B, T, Cin)
         if _want(w):
             K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad)
         return (dx,) + (None,) * 8

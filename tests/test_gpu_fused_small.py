@@ -100,7 +100,7 @@ def test_convnext_backbone_bf16_mode_vs_f32_mode(C, I, L):
     """The bf16 block (bf16 I-wide intermediates, gamma folded into the dgrad weight pack, fused layer-scale gradient, row factor
     folded into the bf16 copy of dy) against the exact-f32 block on the same weights, ragged mask and drop-path draws: output and
     every gradient within bf16 operand tolerance."""
-    from optispeech_amd import precision
+    from optispeech_amd import precision, rng
     from optispeech_amd.model.modules import ConvNeXtBackbone
     B, T = 3, 160
     lens = torch.tensor([160, 97, 33], device=DEV)
@@ -112,6 +112,8 @@ def test_convnext_backbone_bf16_mode_vs_f32_mode(C, I, L):
         for mode in ("f32", "bf16"):
             precision.set_precision(mode)
             torch.manual_seed(5)
+            rng.reset_streams()                                   # same Philox stream id for the backbone's DropPath in both modes
+            rng.manual_seed(11, 0)
             m = ConvNeXtBackbone(C, I, L, drop_path=0.3).to(DEV).train()
             with torch.no_grad():
                 for n, p in m.named_parameters():
@@ -143,3 +145,31 @@ def test_segment_starts_matches_upstream_formula():
         got = K.segment_starts(r, lens, seg)
         want = (r * ((lens - 4).to(torch.float32) - seg).clamp_(min=0)).to(torch.long)
         assert torch.equal(got, want)
+
+
+def test_drop_path_rows_distribution_and_mask():
+    # convnext.py:121-129: bernoulli(keep) / keep per (block, utterance), constant over the frames of an utterance
+    from optispeech_amd import kernels as K
+    L, B, T = 6, 64, 37
+    drops = [0.0, 0.1, 0.25, 0.5, 0.0, 0.9]
+    rm = (torch.rand(B * T, generator=torch.Generator().manual_seed(1)) > 0.2).float().cuda()
+    sc, rf = K.drop_path_rows(drops, rm, B, T, 1234, 7, rm.device)
+    sc2, rf2 = K.drop_path_rows(drops, rm, B, T, 1234, 7, rm.device)
+    assert torch.equal(sc, sc2) and torch.equal(rf, rf2)                    # counter-based: same key, same draw
+    sc3, _ = K.drop_path_rows(drops, rm, B, T, 1235, 7, rm.device)
+    assert not torch.equal(sc, sc3)
+    assert torch.equal(rf, sc * rm[None])
+    s3 = sc.view(L, B, T)
+    assert torch.equal(s3, s3[:, :, :1].expand(-1, -1, T))                  # one factor per utterance
+    for l, p in enumerate(drops):
+        vals = s3[l, :, 0]
+        if p == 0.0:
+            assert torch.all(vals == 1.0)
+        else:
+            keep = 1.0 - p
+            assert torch.all((vals == 0) | ((vals * keep - 1.0).abs() < 1e-5))
+    # frequencies over many utterances
+    scb, none = K.drop_path_rows([0.3], None, 20000, 1, 99, 3, rm.device)
+    assert none is None
+    frac = (scb == 0).float().mean().item()
+    assert abs(frac - 0.3) < 0.02, frac

@@ -48,3 +48,12 @@ qs = {}
 for s, e, k, wg, q in ev:
     qs[q] = qs.get(q, 0) + (e - s)
 print("busy time per queue (ms):", {q: round(v / 1e6, 1) for q, v in sorted(qs.items(), key=lambda kv: -kv[1])})
+# context of the largest idle gaps: the kernels that end just before and start just after
+ends = sorted((e, k) for s, e, k, *_ in ev)
+starts = sorted((s, k) for s, e, k, *_ in ev)
+import bisect
+print("largest gaps: [last kernels to finish] -> gap -> [first kernels to start]")
+for g, at in gaps[:6]:
+    i = bisect.bisect_right(ends, (at, "~")) 
+    j = bisect.bisect_left(starts, (at + g, ""))
+    print(f"  {g/1e3:7.1f} us  after {[k for _, k in ends[max(0, i-3):i]]}  before {[k for _, k in starts[j:j+3]]}")
