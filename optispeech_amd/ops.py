@@ -21,6 +21,61 @@ def _want(p):
     return p is not None and p.requires_grad
 
 
+# ------------------------------------------------------------------------------------------------ weight gradients off the chain
+# The generator's backward is one dependent chain of SMALL kernels (50-600 workgroups on 256 CUs): input gradient of block n ->
+# block n-1 -> ...  The weight / bias gradients hang off that chain -- nothing downstream reads them before the optimizer -- so
+# they are issued on a side stream and fill the CUs the chain leaves idle.  Ordering: the side stream waits for the calling
+# stream at every hand-over (the operands were just produced there); the engine's end-of-backward callback makes the stream
+# that called backward() wait for the side streams, so whoever reads .grad afterwards (optimizer, all-reduce, a test) is
+# ordered after them exactly as with inline launches.  Operands stay referenced until that join (the caching allocator would
+# otherwise hand their memory to the next kernel of the calling stream while the side stream still reads it).
+import os as _os
+
+_WG = {"on": _os.environ.get("OSP_WGRAD_STREAM", "1") != "0", "sides": {}, "used": [], "keep": [], "queued": False}
+
+
+def _join_wgrad():
+    cur = torch.cuda.current_stream()
+    for side in _WG["used"]:
+        cur.wait_stream(side)
+    _WG["used"], _WG["keep"], _WG["queued"] = [], [], False
+
+
+class side_wgrad:
+    """``with side_wgrad(t0, t1, ...):`` -- the enclosed launches (weight-gradient kernels reading t0, t1, ...) go to the side
+    stream of the current stream.  Outside a backward pass (no end-of-backward hook available) it is a no-op."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.prev = None
+
+    def __enter__(self):
+        if not _WG["on"] or not self.tensors or not self.tensors[0].is_cuda:
+            return self
+        if not _WG["queued"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad)
+            except RuntimeError:                                   # not inside backward(): stay inline
+                return self
+            _WG["queued"] = True
+        cur = torch.cuda.current_stream()
+        side = _WG["sides"].get(cur)
+        if side is None:
+            side = _WG["sides"][cur] = torch.cuda.Stream(device=cur.device)
+        if side not in _WG["used"]:
+            _WG["used"].append(side)
+        _WG["keep"].extend(t for t in self.tensors if t is not None)
+        side.wait_stream(cur)
+        self.prev = cur
+        torch.cuda.set_stream(side)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_stream(self.prev)
+        return False
+
+
 class ConvNeXtBlockFn(torch.autograd.Function):
     """ConvNeXtBlock.forward + the backbone's per-block mask (generator/modules/convnext.py:34-47, :99-101).
 
@@ -75,7 +130,8 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         M = B * T
         dy2 = dy.contiguous().view(M, C)
         if _want(gamma):
-            K.colsum_prod(dy2, z, rowf, gsink(gamma))            # dgamma[c] += sum_m rowf[m] dy[m,c] z[m,c]   (one launch)
+            with side_wgrad(dy2, z, rowf):
+                K.colsum_prod(dy2, z, rowf, gsink(gamma))        # dgamma[c] += sum_m rowf[m] dy[m,c] z[m,c]   (one launch)
         # du[m,k] = rowf[m] * sum_n dy[m,n] * gamma[n] W2[n,k] * gelu'(u[m,k])
         # performance mode is decided HERE: a block whose forward ran in exact f32 (index-critical path, f32 u / g / h saved)
         # still takes the bf16 MFMA kernels for its gradients -- those feed no index
@@ -85,13 +141,14 @@ class ConvNeXtBlockFn(torch.autograd.Function):
             dys = K.cast_bf16_rows(dy2, rowf)
             du = K.conv_gemm_bf16(dys, K.param_bf16_scaled_t(W2, gamma), I, M=M, Trows=M, Tin=M,
                                   cin=C, epi=K.EPI_GELU_BWD, aux_in=u, out_bf16=True)
-            if _want(W2):
-                K.conv_wgrad_bf16(dys, g, gsink(W2), gsink(b2) if _want(b2) else None, M=M, Trows=M, Tin=M, n=C, cin=I,
-                                  oscale=gamma)
             dh = K.conv_gemm_bf16(du, K.param_bf16(W1, transposed=True), C, M=M, Trows=M, Tin=M, cin=I)
-            if _want(W1):
-                K.conv_wgrad_bf16(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None, M=M, Trows=M,
-                                  Tin=M, n=I, cin=C)
+            with side_wgrad(dys, g, du, h):
+                if _want(W2):
+                    K.conv_wgrad_bf16(dys, g, gsink(W2), gsink(b2) if _want(b2) else None, M=M, Trows=M, Tin=M, n=C, cin=I,
+                                      oscale=gamma)
+                if _want(W1):
+                    K.conv_wgrad_bf16(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None, M=M, Trows=M,
+                                      Tin=M, n=I, cin=C)
         else:
             W2g = W2 * gamma[:, None]
             du = K.conv_gemm(dy2, W2g, I, cin=C, w_strides=(1, 0, I), epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u)
@@ -178,8 +235,9 @@ class ConvLinearFn(torch.autograd.Function):
             dx = K.conv_gemm(g, base, Cin, T=T, taps=taps, pad=taps - 1 - pad, cin=Cout,
                              w_strides=(1, -Cin, taps * Cin), a_rowscale=rowmask, w_param=w).view(B, T, Cin)
         if _want(w):
-            K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad,
-                         arow=rowmask)
+            with side_wgrad(g, x, rowmask):
+                K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad,
+                             arow=rowmask)
         return (dx,) + (None,) * 7
 
 
@@ -221,7 +279,8 @@ class PredictorLayerFn(torch.autograd.Function):
             dx = K.conv_gemm(g, base, Cin, T=T, taps=taps, pad=taps - 1 - pad, cin=Cout,
                              w_strides=(1, -Cin, taps * Cin), w_param=w).view(B, T, Cin)
         if _want(w):
-            K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad)
+            with side_wgrad(g, x):
+                K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad)
         return (dx,) + (None,) * 8
 
 
