@@ -396,3 +396,147 @@ extern "C" int osp_dwconv7_bwd(const float* dc, const float* x, const float* dw,
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward + depthwise-conv backward of the ConvNeXt block in ONE pass (C <= 256: one 256-channel chunk per lane).
+//   dc[t]  = rstd[t] * (g - mean_C(g) - xhat[t] * mean_C(g * xhat[t])),  g = dh[t] * lnw          (LayerNorm backward, xhat saved)
+//   dx[t]  = dres[t] * rowmask[t] + sum_j w[j] * dc[t - j + 3]                                     (depthwise conv backward + residual)
+//   dlnw += sum_t dh[t] * xhat[t];  dlnb += sum_t dh[t];  ddw[j] += sum_t dc[t] * x[t + j - 3];  ddb += sum_t dc[t]
+// The unfused pair writes dc (M x C f32) to HBM and reads it back through a 7-row window: 2 x 4 bytes per element of the
+// 9 x 4 the pair moves (dh, xhat, dc | dc, x, dres, dx ...).  Here a wave owns a run of FR frames and rebuilds the dc rows of
+// its FR + 6 window from dh / xhat (the 6 halo rows are shared with the neighbouring runs: L2 hits, two extra wave reductions
+// each), so dc never leaves the registers.  Algorithmic HBM bytes per frame: (dh + xhat + x + dres) reads + dx write = 5 * C * 4.
+// Loads are requested in two bursts (dh + xhat rows, then x + dres rows) to stay under 256 VGPRs with the 7 + 3 parameter-
+// gradient accumulators live.
+template <int FR>
+__global__ __launch_bounds__(256, 2) void ln_dwconv7_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ xhat,
+                                                             const float* __restrict__ rstd, const float* __restrict__ lnw,
+                                                             const float* __restrict__ x, const float* __restrict__ dw,
+                                                             const float* __restrict__ dres, const float* __restrict__ dres_rowmask,
+                                                             float* __restrict__ dx, float* __restrict__ dlnw, float* __restrict__ dlnb,
+                                                             float* __restrict__ ddw, float* __restrict__ ddb, int B, int T, int C) {
+    __shared__ float red[4][10][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int runs_per_utt = (T + FR - 1) / FR, nruns = B * runs_per_utt;
+    const int ch = lane * 4;
+    const bool chan = ch < C;
+    const int chs = chan ? ch : 0;
+    const float invC = 1.0f / (float)C;
+    const float4 gw = chan ? *reinterpret_cast<const float4*>(lnw + chs) : f4zero();
+    float4 gwt[7], gb = f4zero(), aw = f4zero(), ab = f4zero();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) gwt[j] = f4zero();
+    // persistent workgroups (the grid is capped at two per CU): the parameter-gradient partials stay in registers over all the
+    // runs of a wave, so every channel takes one atomic per WORKGROUP, not per run.  Three load bursts per run, fenced against
+    // each other (the scheduler otherwise hoists all of them to the top and the kernel spills): dh + xhat -> dc window;
+    // dres + taps -> dx; x window -> tap gradients.
+    for (int run = blockIdx.x * 4 + wave; run < nruns; run += gridDim.x * 4) {
+        const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FR;
+        const int64_t base = (int64_t)b * T * C;
+        float4 dc[FR + 6];
+        {
+            float4 xh[FR + 6];
+            float rs[FR + 6];
+#pragma unroll
+            for (int r = 0; r < FR + 6; ++r) {
+                const int t = t0 + r - 3;
+                const bool in = t >= 0 && t < T;
+                const int64_t off = base + (int64_t)(in ? t : t0) * C + chs;
+                const float4 d = *reinterpret_cast<const float4*>(dh + off);
+                const float4 v = *reinterpret_cast<const float4*>(xhat + off);
+                rs[r] = in ? rstd[(int64_t)b * T + t] : 0.f;         // rows outside the utterance are the conv's zero padding
+                dc[r] = (in && chan) ? d : f4zero();
+                xh[r] = (in && chan) ? v : f4zero();
+            }
+#pragma unroll
+            for (int r = 0; r < FR + 6; ++r) {
+                const float4 d = dc[r], v = xh[r];
+                if (r >= 3 && r < FR + 3) {                          // owned frames (zero beyond T): LayerNorm parameter gradients
+                    aw = f4fma(d, v, aw);
+                    ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+                }
+                const float4 g = make_float4(d.x * gw.x, d.y * gw.y, d.z * gw.z, d.w * gw.w);
+                const float m1 = wave_sum(f4sum(g)) * invC;
+                const float m2 = wave_sum(g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w) * invC;
+                const float sc = rs[r];
+                dc[r] = chan ? make_float4(sc * (g.x - m1 - v.x * m2), sc * (g.y - m1 - v.y * m2), sc * (g.z - m1 - v.z * m2),
+                                           sc * (g.w - m1 - v.w * m2)) : f4zero();
+            }
+        }
+        asm volatile("" ::: "memory");
+        {
+            // input gradient: residual rows of the owned frames + the 7 taps (L1 / L2 resident)
+            float4 dr[FR], w[7];
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const int t = t0 + f;
+                const bool in = t < T;
+                const float4 v = dres ? *reinterpret_cast<const float4*>(dres + base + (int64_t)(in ? t : t0) * C + chs) : f4zero();
+                const float rm = (dres_rowmask && in) ? dres_rowmask[(int64_t)b * T + t] : 1.f;
+                dr[f] = (in && chan && dres) ? make_float4(v.x * rm, v.y * rm, v.z * rm, v.w * rm) : f4zero();
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) w[j] = *reinterpret_cast<const float4*>(dw + (int64_t)j * C + chs);
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const int t = t0 + f;
+                if (t < T && chan) {
+                    float4 a = dr[f];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a = f4fma(w[j], dc[f + 6 - j], a);      // dc[t - j + 3]
+                    *reinterpret_cast<float4*>(dx + base + (int64_t)t * C + ch) = a;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (ddw) {                                                    // kernel-uniform
+            // tap gradients: x rows of the window against dc of the owned frames
+            float4 xr[FR + 6];
+#pragma unroll
+            for (int r = 0; r < FR + 6; ++r) {
+                const int t = t0 + r - 3;
+                const bool in = t >= 0 && t < T;
+                const float4 v = *reinterpret_cast<const float4*>(x + base + (int64_t)(in ? t : t0) * C + chs);
+                xr[r] = (in && chan) ? v : f4zero();
+            }
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const float4 d0 = (t0 + f < T) ? dc[f + 3] : f4zero();            // dc[t]
+#pragma unroll
+                for (int j = 0; j < 7; ++j) gwt[j] = f4fma(d0, xr[f + j], gwt[j]);   // x[t + j - 3]
+                gb.x += d0.x; gb.y += d0.y; gb.z += d0.z; gb.w += d0.w;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    // parameter gradients: per-wave partials of all ten rows (7 taps, conv bias, LN weight, LN bias) -> LDS, one barrier, then one
+    // atomic per channel and workgroup
+    if (!ddw && !dlnw) return;                                          // kernel-uniform
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
+        *reinterpret_cast<float4*>(&red[wave][j][lane * 4]) = j < 7 ? gwt[j] : j == 7 ? gb : j == 8 ? aw : ab;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 10 * 256; i += 256) {
+        const int j = i >> 8, c = i & 255;
+        float* dst = j < 7 ? (ddw ? ddw + (int64_t)j * C : nullptr) : j == 7 ? ddb : j == 8 ? dlnw : dlnb;
+        if (dst && c < C) atomicAdd(dst + c, red[0][j][c] + red[1][j][c] + red[2][j][c] + red[3][j][c]);
+    }
+}
+
+extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const float* rstd, const float* lnw, const float* x,
+                                  const float* dw, const float* dres, const float* dres_rowmask, float* dx, float* dlnw, float* dlnb,
+                                  float* ddw, float* ddb, int64_t B, int64_t T, int64_t C, hipStream_t stream) {
+    OSP_CHECK_ARG(dh && xhat && rstd && lnw && x && dw && dx, "null operand");
+    OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr) && (ddw == nullptr) == (ddb == nullptr), "dlnw/dlnb and ddw/ddb come in pairs");
+    OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256, "C must be a multiple of 4, <= 256 (wider blocks: osp_layernorm_bwd + osp_dwconv7_bwd)");
+    static int fr = -1;
+    if (fr < 0) { const char* e = getenv("OSP_LNDW_FR"); fr = e ? atoi(e) : 4; }      // tools/lndw_probe.py at 32 x 800 x 256: FR 4 / 6 / 8 = 41.9 / 49.7 / 50.6 us (8 spills: 256-VGPR cap for two workgroups / CU)
+    static int maxwg = -1;
+    if (maxwg < 0) { const char* e = getenv("OSP_LNDW_WG"); maxwg = e ? atoi(e) : 512; }      // two workgroups per CU are resident (220 VGPRs)
+#define L(F) hipLaunchKernelGGL((ln_dwconv7_bwd_kernel<F>), dim3((unsigned)(cdiv(B * cdiv(T, F), 4) < maxwg ? cdiv(B * cdiv(T, F), 4) : maxwg)), dim3(256), 0, stream, dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, (int)B, (int)T, (int)C)
+    if (fr == 4) L(4); else if (fr == 6) L(6); else L(8);
+#undef L
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

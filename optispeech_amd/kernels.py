@@ -135,6 +135,16 @@ def dwconv7_bwd(dc, x, dw, dres, dres_rowmask, ddw, ddb):
     return dx
 
 
+def ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, ddw, ddb):
+    """LayerNorm backward + depthwise-conv backward of a ConvNeXt block in one pass (C <= 256); dlnw/dlnb/ddw/ddb accumulate."""
+    _f32(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, ddw, ddb)
+    B, T, C = x.shape
+    assert dh.is_contiguous() and xhat.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    call("osp_ln_dwconv7_bwd", dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, B, T, C)
+    return dx
+
+
 def layernorm_fwd(x, w, b, eps, *, save=True, rowmask=None, drop_p=0.0, seed=0, stream_id=0):
     _f32(x, w, b, rowmask)
     C = x.shape[-1]

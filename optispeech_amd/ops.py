@@ -76,6 +76,9 @@ class side_wgrad:
         return False
 
 
+_FUSED_LN_DW = _os.environ.get("OSP_FUSED_LN_DW", "1") != "0"
+
+
 class ConvNeXtBlockFn(torch.autograd.Function):
     """ConvNeXtBlock.forward + the backbone's per-block mask (generator/modules/convnext.py:34-47, :99-101).
 
@@ -157,10 +160,15 @@ class ConvNeXtBlockFn(torch.autograd.Function):
             dh = K.conv_gemm(du, W1, C, cin=I, w_strides=(1, 0, C))
             if _want(W1):
                 K.conv_wgrad(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None)
-        wl = _want(lnw)
+        wl, wd = _want(lnw), _want(dw)
+        if C <= 256 and dy.is_cuda and _FUSED_LN_DW:
+            # one pass: the LayerNorm input gradient dc never goes to HBM (csrc/convnext.hip: ln_dwconv7_bwd_kernel)
+            dx = K.ln_dwconv7_bwd(dh, xhat.view(M, C), rstd.view(M), lnw, x, dw, dy2.view(B, T, C), rowmask,
+                                  gsink(lnw) if wl else None, gsink(lnb) if wl else None, gsink(dw) if wd else None,
+                                  gsink(dwb) if wd else None)
+            return (dx,) + (None,) * 12
         dc = K.layernorm_bwd(dh, xhat.view(M, C), None, rstd.view(M), lnw, gsink(lnw) if wl else None,
                              gsink(lnb) if wl else None)
-        wd = _want(dw)
         dx = K.dwconv7_bwd(dc.view(B, T, C), x, dw, dy2.view(B, T, C), rowmask, gsink(dw) if wd else None,
                            gsink(dwb) if wd else None)
         return (dx,) + (None,) * 12

@@ -173,3 +173,29 @@ def test_drop_path_rows_distribution_and_mask():
     assert none is None
     frac = (scb == 0).float().mean().item()
     assert abs(frac - 0.3) < 0.02, frac
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 37, 256), (2, 800, 256), (4, 8, 64), (1, 5, 200)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_fused_ln_dwconv7_backward_equals_the_two_kernel_path(B, T, C, with_res):
+    """osp_ln_dwconv7_bwd against osp_layernorm_bwd followed by osp_dwconv7_bwd (which test_gpu_kernels pins to the oracle):
+    same dx and same accumulated parameter gradients, ragged run lengths included (T % 8 != 0, T < window)."""
+    from optispeech_amd import kernels as K
+    M = B * T
+    dh, xhat = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    rstd = rnd(M, seed=3).abs() + 0.5
+    lnw, x, dw = rnd(C, seed=4), rnd(B, T, C, seed=5), rnd(7, C, seed=6)
+    dres = rnd(B, T, C, seed=7) if with_res else None
+    rm = (torch.rand(M, generator=torch.Generator().manual_seed(8)) > 0.3).float().to(DEV) if with_res else None
+    acc0 = [rnd(C, seed=9), rnd(C, seed=10), rnd(7, C, seed=11), rnd(C, seed=12)]      # gradients accumulate onto what is there
+    a = [t.clone() for t in acc0]
+    dc = K.layernorm_bwd(dh, xhat, None, rstd, lnw, a[0], a[1])
+    dx_ref = K.dwconv7_bwd(dc.view(B, T, C), x, dw, dres, rm, a[2], a[3])
+    b = [t.clone() for t in acc0]
+    dx = K.ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, rm, b[0], b[1], b[2], b[3])
+    torch.testing.assert_close(dx, dx_ref, rtol=1e-5, atol=1e-5)
+    for u, v in zip(b, a):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4 * max(1.0, float(M) ** 0.5))
+    # input gradient only (frozen parameters)
+    dx2 = K.ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, rm, None, None, None, None)
+    assert torch.equal(dx2, dx)
