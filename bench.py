@@ -245,6 +245,55 @@ def _selectors(precision):
     return select
 
 
+def hbm_kernel_rooflines(model, dev, reps=50):
+    """The A1a-class HBM-bound kernels north_star names, each at the decoder shape of the workload (32 x 800 frames x 256 channels;
+    AdamW at the generator arena's size): algorithmic bytes per launch / average launch duration vs 8 TB/s.  The duration is taken
+    over `reps` back-to-back launches between two HIP events on the launch stream: these kernels run 15-50 us, and an event pair
+    around every single launch (what the MFMA record uses for its 130 us kernels) adds ~8 us of launch latency to each.  The
+    rocprofv3 rows of the same kernels are in profiles/ (profiles/README.md)."""
+    from optispeech_amd import kernels as K
+    from optispeech_amd._lib import call
+    Bn, T, C = B, T_MEL, 256
+    M = Bn * T
+    g = torch.Generator(device=dev).manual_seed(7)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)                                    # noqa: E731
+    x, dw, dwb, lnw, lnb = rn(Bn, T, C), rn(7, C), rn(C), rn(C), rn(C)
+    dh, xhat, rstd, dres, rm = rn(M, C), rn(M, C), torch.rand(M, device=dev, generator=g) + 0.5, rn(Bn, T, C), torch.ones(M, device=dev)
+    acc = [torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(7, C, device=dev), torch.zeros(C, device=dev)]
+    n_adam = model.optimizers()[0].arena.numel
+    p, gr, m1, m2 = (torch.zeros(n_adam, device=dev) for _ in range(4))
+    gr.normal_(generator=g)
+    ss = torch.ones(1, device=dev, dtype=torch.float64)
+    cases = {
+        # x read; h (bf16: the consumer is the bf16 GEMM), xhat, rstd written -- the training-mode forward
+        "dwconv7_ln_fwd": (M * (C * (4 + 2 + 4) + 4), lambda: K.dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, 1e-6, True, h_bf16=True)),
+        # dh, xhat, x, dres read; dx written (+ rstd, row mask): LayerNorm backward + depthwise-conv backward in one pass
+        "ln_dwconv7_bwd": (M * (C * 5 * 4 + 8), lambda: K.ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, rm, acc[0], acc[1], acc[2], acc[3])),
+        # dy, xhat read; dx written (+ rstd): the stand-alone LayerNorm backward (final norms, predictors)
+        "layernorm_bwd": (M * (C * 3 * 4 + 4), lambda: K.layernorm_bwd(dh, xhat, None, rstd, lnw, acc[0], acc[1])),
+        # p, g, m, v read; p, m, v written: 28 bytes per parameter
+        "adamw_clip": (n_adam * 28, lambda: call("osp_adamw_clip", p, gr, m1, m2, n_adam, ss, None, None, 2e-4, 0.8, 0.99, 1e-8, 0.01, 7, 10.0, 1.0)),
+    }
+    out = {}
+    for key, (nbytes, fn) in cases.items():
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out[key] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": us, "launches_timed": reps,
+                    "shape": f"{Bn} x {T} x {C}" if key != "adamw_clip" else f"{n_adam} parameters (generator arena)"}
+    out["how"] = f"{reps} back-to-back launches of each kernel between two HIP events on the launch stream, after the timed region"
+    return out
+
+
 def main():
     a = parse()
     from optispeech_amd import dp, precision, rng
@@ -400,14 +449,7 @@ def main():
             roof["l2_hit_rate"] = pj.get("l2_hit_rate")
             roof["traffic_unit"] = "bytes/launch, read from profiles/" + PMC_SUMMARY + " (separate --pmc pass: TCC_EA0 read x 128 B + write x 64 B)"
         # HBM-bound kernels north_star names (A1a class): algorithmic bytes / measured time vs the 8 TB/s peak
-        hbm = {}
-        for key in ("dwconv7_ln_fwd", "layernorm_bwd", "adamw_clip"):
-            if key in ksum and ksum[key][1] > 0:
-                byt, ms, n = ksum[key]
-                gbs = byt / (ms * 1e-3) / 1e9
-                hbm[key] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                            "algorithmic_bytes_per_launch": byt / n, "avg_launch_us": ms / n * 1e3, "launches_timed": n}
-        roof["hbm_kernels"] = hbm
+        roof["hbm_kernels"] = hbm_kernel_rooflines(model, dev) if a.precision == "bf16" else {}
         cpu = None
         if not a.no_cpu_baseline:
             if a.cpu_full:
