@@ -71,12 +71,19 @@ class ModelConfig:
 
 
 def _backbones(c):
-    """(encoder, decoder) partials: ConvNeXt (configs[1]) or the Transformer variant (configs[4])."""
+    """(encoder, decoder) partials: ConvNeXt (configs[1]), the Transformer variant (configs[4]) or the LightSpeech
+    separable-conv pair."""
     if c.backbone == "transformer":
         from .model.transformer import Transformer
         tf = partial(Transformer, attention_heads=c.tf_heads, linear_units=c.tf_units, num_blocks=c.tf_blocks,
                      dropout_rate=c.tf_dropout, positional_dropout_rate=c.tf_dropout, attention_dropout_rate=c.tf_dropout)
         return tf, tf
+    if c.backbone == "lightspeech":
+        # configs/model/generator/{encoder,decoder}/lightspeech_transformer.yaml
+        from .model.lightspeech import LightSpeechTransformerDecoder, LightSpeechTransformerEncoder
+        return (partial(LightSpeechTransformerEncoder, kernel_sizes=[5, 25, 13, 9], activation="relu", dropout=0.2),
+                partial(LightSpeechTransformerDecoder, kernel_sizes=[17, 21, 9, 13], activation="relu", dropout=0.2,
+                        max_source_positions=2000))
     from .model.modules import ConvNeXtBackbone
     return (partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers, drop_path=c.enc_drop_path),
             partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers, drop_path=c.dec_drop_path))

@@ -145,6 +145,35 @@ def ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, d
     return dx
 
 
+def dwconv_fwd(x, w, bias=None, rowmask=None, flip=False):
+    """Depthwise conv of odd width K on channels-last frames: x (B,T,C), w (K,C) tap-major; flip=True is the input gradient
+    (x = dy, the row mask then multiplies the input rows).  One read and one write of the activations."""
+    _f32(x, w, bias, rowmask)
+    B, T, C = x.shape
+    assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == C
+    y = torch.empty_like(x)
+    call("osp_dwconv_fwd", x, w, bias, rowmask, y, B, T, C, w.shape[0], int(bool(flip)))
+    return y
+
+
+def dwconv_wgrad(dy, x, dw, db=None, rowmask=None):
+    """dw (K,C) += sum_{b,t} dy * rowmask * x[t + j - K/2];  db += sum dy * rowmask."""
+    _f32(dy, x, dw, db, rowmask)
+    B, T, C = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+    call("osp_dwconv_wgrad", dy, x, rowmask, dw, db, B, T, C, dw.shape[0])
+
+
+def dropout_add(x, p, seed, stream_id, res=None):
+    """res + x * keep (keep = 0 w.p. p else 1/(1-p), Philox key (seed, stream_id), counter = element index / 4)."""
+    _f32(x, res)
+    assert x.is_contiguous() and x.numel() % 4 == 0 and (res is None or res.is_contiguous())
+    y = torch.empty_like(x)
+    hs, ds = _seed(seed)
+    call("osp_dropout_add", x, res, y, x.numel(), float(p), hs, ds, int(stream_id))
+    return y
+
+
 def layernorm_fwd(x, w, b, eps, *, save=True, rowmask=None, drop_p=0.0, seed=0, stream_id=0):
     _f32(x, w, b, rowmask)
     C = x.shape[-1]

@@ -8,6 +8,7 @@ import torch
 
 from . import kernels as K
 from . import precision as _precision
+from . import rng as _rng
 
 
 def gsink(p):
@@ -247,6 +248,59 @@ class ConvLinearFn(torch.autograd.Function):
                 K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad,
                              arow=rowmask)
         return (dx,) + (None,) * 7
+
+
+class DepthwiseConvFn(torch.autograd.Function):
+    """y = depthwise_conv_K(x) (+ bias) on channels-last frames (nn.Conv1d(C, C, K, padding=K//2, groups=C) call sites:
+    ConvSeparable modules/layers.py:455-477).  x (B,T,C); w (K,C) tap-major parameter; bias (C,) or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        y = K.dwconv_fwd(x, w, bias)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x)
+            ctx.params = (w, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, bias = ctx.params
+        dy = dy.contiguous()
+        dx = K.dwconv_fwd(dy, w, None, None, flip=True) if ctx.needs_input_grad[0] else None
+        if _want(w):
+            with side_wgrad(dy, x):
+                K.dwconv_wgrad(dy, x, gsink(w), gsink(bias) if _want(bias) else None)
+        return dx, None, None
+
+
+def depthwise_conv(x, w, bias=None):
+    return DepthwiseConvFn.apply(x, w, bias)
+
+
+class DropoutAddFn(torch.autograd.Function):
+    """res + dropout(x)  (F.dropout + residual sites of the separable-conv / Conformer layers); res may be None."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, seed, stream_id):
+        ctx.cfg = (p, seed, stream_id)
+        ctx.has_res = res is not None
+        return K.dropout_add(x.contiguous(), p, seed, stream_id, None if res is None else res.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, stream_id = ctx.cfg
+        dy = dy.contiguous()
+        dx = K.dropout_add(dy, p, seed, stream_id) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.has_res and ctx.needs_input_grad[1] else None), None, None, None
+
+
+def dropout_add(x, p, training, stream_id, res=None):
+    """res + F.dropout(x, p, training) with the package's counter-based RNG."""
+    if not training or p <= 0.0:
+        return x if res is None else x + res
+    return DropoutAddFn.apply(x, res, float(p), _rng.seed(), stream_id)
 
 
 def conv_linear(x, w, b, cout, taps=1, pad=0, act=None, rowmask=None):

@@ -80,6 +80,9 @@ REPLACES = {
     "osp_spectral_loss_sums": "SpectralConvergenceLoss + LogSTFTMagnitudeLoss reductions (torch.norm / F.l1_loss of log magnitudes) and the mel L1: disc/loss.py:107-120,231-270",
     "osp_spectral_loss_bwd": "autograd of the same with respect to the predicted magnitudes",
     "osp_pack_bf16_multi": "no reference counterpart: osp_pack_bf16 for a list of weights in one launch",
+    "osp_dwconv_fwd": "depthwise nn.Conv1d(groups = C, odd k) and its input gradient (flip = 1): ConvSeparable modules/layers.py:455-477, _conformer/convolution.py",
+    "osp_dwconv_wgrad": "autograd weight / bias gradient of the same depthwise Conv1d",
+    "osp_dropout_add": "F.dropout (+ residual add) call sites of the separable-conv layers: modules/layers.py:497-503; backward = the same kernel on the gradient",
     "osp_ln_dwconv7_bwd": "autograd of LayerNorm + depthwise Conv1d(k=7) of ConvNeXtBlock in one pass: generator/modules/convnext.py:36-38 (C <= 256)",
     "osp_drop_path_rows": "DropPath factors of all blocks of a ConvNeXt backbone: generator/modules/convnext.py:121-129 (drop_p_host: plain host array)",
     "osp_segment_starts": "get_random_segments start indices: utils/segments.py:12-38 (caller generator/__init__.py:147-153)",
