@@ -71,8 +71,8 @@ class ModelConfig:
 
 
 def _backbones(c):
-    """(encoder, decoder) partials: ConvNeXt (configs[1]), the Transformer variant (configs[4]) or the LightSpeech
-    separable-conv pair."""
+    """(encoder, decoder) partials: ConvNeXt (configs[1]), the Transformer variant (configs[4]), the LightSpeech
+    separable-conv pair or the LeanSpeech LSTM + ConvGLU blocks."""
     if c.backbone == "transformer":
         from .model.transformer import Transformer
         tf = partial(Transformer, attention_heads=c.tf_heads, linear_units=c.tf_units, num_blocks=c.tf_blocks,
@@ -84,6 +84,11 @@ def _backbones(c):
         return (partial(LightSpeechTransformerEncoder, kernel_sizes=[5, 25, 13, 9], activation="relu", dropout=0.2),
                 partial(LightSpeechTransformerDecoder, kernel_sizes=[17, 21, 9, 13], activation="relu", dropout=0.2,
                         max_source_positions=2000))
+    if c.backbone == "leanspeech":
+        # configs/model/generator/{encoder,decoder}/leanspeech.yaml
+        from .model.leanspeech import LeanSpeechBackbone
+        ls = partial(LeanSpeechBackbone, kernel_size=9, num_layers=4, drop_path=0.2)
+        return ls, ls
     from .model.modules import ConvNeXtBackbone
     return (partial(ConvNeXtBackbone, intermediate_dim=c.enc_inter, num_layers=c.enc_layers, drop_path=c.enc_drop_path),
             partial(ConvNeXtBackbone, intermediate_dim=c.dec_inter, num_layers=c.dec_layers, drop_path=c.dec_drop_path))

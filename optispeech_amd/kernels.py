@@ -145,6 +145,67 @@ def ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, d
     return dx
 
 
+def _lstm_chunks(B, H):
+    """Utterances per launch: whole teams resident (B * H/32 <= 256 workgroups), whole XCD rounds (multiple of 8)."""
+    per = max(8, (256 // (H // 32)) // 8 * 8)
+    return [(lo, min(lo + per, B)) for lo in range(0, B, per)]
+
+
+def _pad8(t):
+    """Pad the leading (utterance) dimension to a multiple of 8 with zeros (the teams of one XCD round)."""
+    B = t.shape[0]
+    if B % 8 == 0:
+        return t
+    return torch.cat([t, t.new_zeros((8 - B % 8,) + tuple(t.shape[1:]))], 0)
+
+
+def lstm_fwd(gx, whh, save=True):
+    """LSTM recurrence over gx (B, T, 4H) = x W_ih^T + b_ih + b_hh with W_hh (4H, H), zero initial state.
+    -> hs (B, T, H), gates (B, T, 4H) post-activation (i, f, g, o), cs (B, T, H)   (gates / cs None unless ``save``)."""
+    _f32(gx, whh)
+    B, T, G4 = gx.shape
+    H = G4 // 4
+    assert whh.shape == (G4, H) and whh.is_contiguous() and gx.is_contiguous()
+    hs = torch.empty((B, T, H), device=gx.device, dtype=torch.float32)
+    gates = torch.empty((B, T, G4), device=gx.device, dtype=torch.float32) if save else None
+    cs = torch.empty((B, T, H), device=gx.device, dtype=torch.float32) if save else None
+    for lo, hi in _lstm_chunks(B, H):
+        n = hi - lo
+        g = _pad8(gx[lo:hi])
+        nb = g.shape[0]
+        padded = nb != n
+        h_ = torch.empty((nb, T, H), device=gx.device, dtype=torch.float32) if padded else hs[lo:hi]
+        ga = (torch.empty((nb, T, G4), device=gx.device, dtype=torch.float32) if padded else gates[lo:hi]) if save else None
+        c_ = (torch.empty((nb, T, H), device=gx.device, dtype=torch.float32) if padded else cs[lo:hi]) if save else None
+        hx = torch.empty((nb, 2, H), device=gx.device, dtype=torch.float32)
+        flags = torch.zeros((nb, H // 32), device=gx.device, dtype=torch.int32)
+        call("osp_lstm_fwd", g, whh, h_, ga, c_, hx, flags, nb, T, H)
+        if padded:
+            hs[lo:hi] = h_[:n]
+            if save:
+                gates[lo:hi] = ga[:n]
+                cs[lo:hi] = c_[:n]
+    return hs, gates, cs
+
+
+def lstm_bwd(dhs, gates, cs, whh):
+    """Gradient w.r.t. the gate pre-activations of every step: dg (B, T, 4H)."""
+    _f32(dhs, gates, cs, whh)
+    B, T, H = dhs.shape
+    assert dhs.is_contiguous() and gates.is_contiguous() and cs.is_contiguous()
+    dg = torch.empty((B, T, 4 * H), device=dhs.device, dtype=torch.float32)
+    for lo, hi in _lstm_chunks(B, H):
+        n = hi - lo
+        d_, g_, c_ = _pad8(dhs[lo:hi]), _pad8(gates[lo:hi]), _pad8(cs[lo:hi])
+        nb = d_.shape[0]
+        out = torch.empty((nb, T, 4 * H), device=dhs.device, dtype=torch.float32) if nb != n else dg[lo:hi]
+        flags = torch.zeros((nb, H // 32), device=dhs.device, dtype=torch.int32)
+        call("osp_lstm_bwd", d_, g_, c_, whh, out, flags, nb, T, H)
+        if nb != n:
+            dg[lo:hi] = out[:n]
+    return dg
+
+
 def dwconv_fwd(x, w, bias=None, rowmask=None, flip=False):
     """Depthwise conv of odd width K on channels-last frames: x (B,T,C), w (K,C) tap-major; flip=True is the input gradient
     (x = dy, the row mask then multiplies the input rows).  One read and one write of the activations."""

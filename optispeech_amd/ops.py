@@ -250,6 +250,47 @@ class ConvLinearFn(torch.autograd.Function):
         return (dx,) + (None,) * 7
 
 
+class LSTMFn(torch.autograd.Function):
+    """hs = nn.LSTM(H, H, num_layers=1, batch_first=True)(x)[0] with zero initial state (leanspeech.py:49-60).
+
+    x (B, T, H); w_ih, w_hh (4H, H), b_ih, b_hh (4H,): torch's parameters (gate order i, f, g, o).  Input projection, input
+    gradient and the three weight gradients are GEMMs of the conv-GEMM family; the recurrence runs in csrc/lstm.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        B, T, H = x.shape
+        x = x.contiguous()
+        save = any(ctx.needs_input_grad)
+        gx = K.conv_gemm(x.view(B * T, H), w_ih, 4 * H, bias=b_ih + b_hh).view(B, T, 4 * H)
+        hs, gates, cs = K.lstm_fwd(gx, w_hh.detach().contiguous(), save=save)
+        if save:
+            ctx.save_for_backward(x, hs, gates, cs)
+            ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        x, hs, gates, cs = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        B, T, H = x.shape
+        dg = K.lstm_bwd(dhs.contiguous(), gates, cs, w_hh.detach().contiguous())
+        dg2 = dg.view(B * T, 4 * H)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv_gemm(dg2, w_ih.detach(), H, cin=4 * H, w_strides=(1, 0, H)).view(B, T, H)      # dg @ W_ih
+        h_prev = torch.cat([hs.new_zeros((B, 1, H)), hs[:, :-1]], 1).contiguous()                      # h_{t-1}, zero initial state
+        with side_wgrad(dg2, x, h_prev):
+            if _want(w_ih):
+                K.conv_wgrad(dg2, x.view(B * T, H), gsink(w_ih), gsink(b_ih) if _want(b_ih) else None)
+            if _want(w_hh):
+                K.conv_wgrad(dg2, h_prev.view(B * T, H), gsink(w_hh), gsink(b_hh) if _want(b_hh) else None)
+        return dx, None, None, None, None
+
+
+def lstm(x, w_ih, w_hh, b_ih, b_hh):
+    return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh)
+
+
 class DepthwiseConvFn(torch.autograd.Function):
     """y = depthwise_conv_K(x) (+ bias) on channels-last frames (nn.Conv1d(C, C, K, padding=K//2, groups=C) call sites:
     ConvSeparable modules/layers.py:455-477).  x (B,T,C); w (K,C) tap-major parameter; bias (C,) or None."""

@@ -160,3 +160,64 @@ def test_lightspeech_generator_train_step_and_synthesise_run():
         assert wav.shape[0] == 2 and torch.isfinite(wav).all()
     finally:
         precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 5, 64), (8, 50, 128), (5, 1, 64), (40, 23, 256), (32, 64, 256)])
+def test_lstm_matches_torch_lstm(B, T, H):
+    """csrc/lstm.hip (team-of-workgroups recurrence) + the GEMMs around it against torch.nn.LSTM on the CPU: outputs, input
+    gradient and all four parameter gradients; batch sizes that need zero padding (B % 8 != 0) and chunking (B * H/32 > 256)."""
+    from optispeech_amd import ops, precision
+    precision.set_precision("f32")
+    torch.manual_seed(B * 1000 + T)
+    ref = torch.nn.LSTM(H, H, num_layers=1, batch_first=True).double()
+    x = torch.randn(B, T, H, dtype=torch.float64, requires_grad=True)
+    g = torch.randn(B, T, H, dtype=torch.float64)
+    yr, _ = ref(x)
+    (yr * g).sum().backward()
+    ps = [torch.nn.Parameter(getattr(ref, n).detach().float().to(DEV)) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    y = ops.lstm(xd, *ps)
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=2e-4, atol=2e-5)
+    (y * g.float().to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-20)).item()      # noqa: E731
+    assert rel(xd.grad, x.grad) < 1e-3
+    for p, n in zip(ps, ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")):
+        assert rel(p.grad, getattr(ref, n).grad) < 1e-3, n
+
+
+def test_leanspeech_backbone_vs_reference_golden(golden):
+    from optispeech_amd import precision
+    from optispeech_amd.model.leanspeech import LeanSpeechBackbone
+    precision.set_precision("f32")
+    g = golden("leanspeech")
+    m = LeanSpeechBackbone(dim=64, kernel_size=9, num_layers=2, drop_path=0.2).to(DEV).eval()
+    _load(m, g)
+    _check(m, g)
+
+
+def test_leanspeech_generator_train_step_runs():
+    """ModelConfig(backbone="leanspeech"): one GAN training step at the BASELINE width (H = 256: 8 workgroups per utterance),
+    finite losses, the recurrent weights of both backbones move."""
+    from optispeech_amd import precision, rng
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    precision.set_precision("bf16")
+    try:
+        torch.manual_seed(2)
+        rng.manual_seed(2, 0)
+        cfg = ModelConfig(backbone="leanspeech")
+        m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
+        batch = synthetic_batch(2, 24, 96, cfg, seed=5, device=DEV)
+        m.optimizers()
+        for sch in m.lr_schedulers():
+            sch.warmup = 0
+            sch.opt.lr = sch.base_lr
+        w_e, w_d = m.generator.encoder.layers[0].w_hh, m.generator.decoder.layers[3].w_hh
+        before = (w_e.detach().clone(), w_d.detach().clone())
+        m.training_step(batch, 0)
+        logs = m.fetch_logs()
+        assert all(np.isfinite(v) for v in logs.values()), logs
+        torch.cuda.synchronize()
+        assert not torch.equal(w_e.detach(), before[0]) and not torch.equal(w_d.detach(), before[1])
+    finally:
+        precision.set_precision("f32")

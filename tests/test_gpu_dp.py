@@ -99,7 +99,9 @@ def _worker(rank, world, port, graph, q):
             got = o.arena.grad.detach() / world
             err = ((got - mean).norm() / mean.norm()).item()
             msgs.append(f"{name}: |sum/world - mean of single-rank grads| / |mean| = {err:.2e}")
-            ok = ok and err < 2e-4
+            # two runs of the SAME step differ by the f32-atomic order of the split-K weight gradients (observed up to 2.5e-4 on the
+            # discriminator arena); a missing / doubled contribution would show as O(1)
+            ok = ok and err < 6e-4
         # replicas identical after the update: compare every rank's arenas bit for bit
         for o in (og, od):
             mine = o.arena.data.detach().clone()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden fixtures for the other backbones by RUNNING THE REFERENCE modules here.
 
-    python tools/make_golden_backbones.py        # writes tests/golden/lightspeech_{enc,dec}.npz
+    python tools/make_golden_backbones.py        # writes tests/golden/lightspeech_{enc,dec}.npz, leanspeech.npz
 
 optispeech.model.generator.modules.LightSpeechTransformerEncoder / ...Decoder (modules/lightspeech_transformer.py:14-96,
 EncSepConvLayer / ConvSeparable modules/layers.py:455-506) are instantiated in eval mode (dropout off) at a reduced width with
@@ -21,6 +21,7 @@ sys.path.insert(0, "/root/reference")
 from tools.make_golden import install_stubs  # noqa: E402
 
 install_stubs()
+from optispeech.model.generator.modules.leanspeech import LeanSpeechBackbone  # noqa: E402
 from optispeech.model.generator.modules.lightspeech_transformer import (LightSpeechTransformerDecoder,  # noqa: E402
                                                                         LightSpeechTransformerEncoder)
 
@@ -52,3 +53,6 @@ run("lightspeech_enc", LightSpeechTransformerEncoder(dim=64, kernel_sizes=[5, 25
 torch.manual_seed(23)
 run("lightspeech_dec", LightSpeechTransformerDecoder(dim=64, kernel_sizes=[17, 21, 9, 13], activation="relu", dropout=0.2,
                                                      max_source_positions=2000).eval(), 24)
+torch.manual_seed(25)
+# LeanSpeechBackbone (modules/leanspeech.py:14-97; configs/model/generator/encoder/leanspeech.yaml: kernel_size 9, drop_path 0.2), 2 layers
+run("leanspeech", LeanSpeechBackbone(dim=64, kernel_size=9, num_layers=2, drop_path=0.2).eval(), 26)
