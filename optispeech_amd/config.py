@@ -72,7 +72,7 @@ class ModelConfig:
 
 def _backbones(c):
     """(encoder, decoder) partials: ConvNeXt (configs[1]), the Transformer variant (configs[4]), the LightSpeech
-    separable-conv pair or the LeanSpeech LSTM + ConvGLU blocks."""
+    separable-conv pair, the Conformer or the LeanSpeech LSTM + ConvGLU blocks."""
     if c.backbone == "transformer":
         from .model.transformer import Transformer
         tf = partial(Transformer, attention_heads=c.tf_heads, linear_units=c.tf_units, num_blocks=c.tf_blocks,
@@ -84,6 +84,12 @@ def _backbones(c):
         return (partial(LightSpeechTransformerEncoder, kernel_sizes=[5, 25, 13, 9], activation="relu", dropout=0.2),
                 partial(LightSpeechTransformerDecoder, kernel_sizes=[17, 21, 9, 13], activation="relu", dropout=0.2,
                         max_source_positions=2000))
+    if c.backbone == "conformer":
+        # configs/model/generator/{encoder,decoder}/conformer.yaml
+        from .model.conformer import Conformer
+        kw = dict(attention_heads=2, linear_units=1024, num_blocks=4, dropout_rate=0.2, positional_dropout_rate=0.2,
+                  attention_dropout_rate=0.2)
+        return partial(Conformer, cnn_module_kernel=7, **kw), partial(Conformer, cnn_module_kernel=31, **kw)
     if c.backbone == "leanspeech":
         # configs/model/generator/{encoder,decoder}/leanspeech.yaml
         from .model.leanspeech import LeanSpeechBackbone

@@ -593,7 +593,9 @@ class AttentionFn(torch.autograd.Function):
     T = 800 -- a flash-style fused kernel is the round-2 item for this variant)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, klen, H, drop_p, seed, stream_id):
+    def forward(ctx, q, k, v, klen, H, drop_p, seed, stream_id, sbias=None):
+        """sbias (B * H, T, T) or None: added to Q K^T before the scaling (the relative-position term of
+        RelPositionMultiHeadedAttention, _transformer/attention.py:290-313); it receives the score gradient."""
         B, T, C = q.shape
         dk = C // H
         Z = B * H
@@ -601,9 +603,12 @@ class AttentionFn(torch.autograd.Function):
         qh, kh, vh = heads(q), heads(k), heads(v)
         scale = 1.0 / float(dk) ** 0.5
         S = K.conv_gemm(qh, kh, T, cin=dk, w_strides=(dk, 0, 1), batch=Z, batch_strides=(T * dk, T * dk, T * T, 0))
+        if sbias is not None:
+            S.add_(sbias.reshape(Z, T, T))
+        ctx.has_bias = sbias is not None
         P, Pd = K.attn_softmax_fwd(S, klen, B, H, T, T, scale, drop_p, seed, stream_id)
         O = K.conv_gemm(Pd, vh, dk, cin=T, w_strides=(1, 0, dk), batch=Z, batch_strides=(T * T, T * dk, T * dk, 0))
-        if any(ctx.needs_input_grad[:3]):
+        if any(ctx.needs_input_grad[:3]) or (sbias is not None and ctx.needs_input_grad[8]):
             ctx.save_for_backward(qh, kh, vh, P, Pd)
             ctx.cfg = (B, T, H, dk, scale, drop_p, seed, stream_id)
         return O.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, C)
@@ -622,7 +627,35 @@ class AttentionFn(torch.autograd.Function):
         dKh = torch.zeros((Z, T, dk), device=dout.device, dtype=torch.float32)
         K.conv_wgrad(dS, qh, dKh, None, batch=Z)                         # dK[t2, d] = sum_t1 dS[t1, t2] q[t1, d]
         back = lambda t: t.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, H * dk)              # noqa: E731
-        return back(dQ), back(dKh), back(dV), None, None, None, None, None
+        return back(dQ), back(dKh), back(dV), None, None, None, None, None, (dS if ctx.has_bias else None)
+
+
+class BatchedNTFn(torch.autograd.Function):
+    """C[z] = A[z] B[z]^T for z < Z on the conv-GEMM kernels: A (Z, M, K), B (Z, N, K) -> (Z, M, N), with both gradients
+    (torch.matmul(x, y.transpose(-2, -1)) call sites of the relative-position attention)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        Z, M, Kd = a.shape
+        N = b.shape[1]
+        c = K.conv_gemm(a, b, N, cin=Kd, w_strides=(Kd, 0, 1), batch=Z, batch_strides=(M * Kd, N * Kd, M * N, 0))
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        Z, M, Kd = a.shape
+        N = b.shape[1]
+        dc = dc.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:                                       # dA = dC B
+            da = K.conv_gemm(dc, b, Kd, cin=N, w_strides=(1, 0, Kd), batch=Z, batch_strides=(M * N, N * Kd, M * Kd, 0))
+        if ctx.needs_input_grad[1]:                                       # dB[n, k] = sum_m dC[m, n] A[m, k]
+            db = torch.zeros((Z, N, Kd), device=dc.device, dtype=torch.float32)
+            K.conv_wgrad(dc, a, db, None, batch=Z)
+        return da, db
 
 
 class JoinStreamAtBackwardEndFn(torch.autograd.Function):

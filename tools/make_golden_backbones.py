@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden fixtures for the other backbones by RUNNING THE REFERENCE modules here.
 
-    python tools/make_golden_backbones.py        # writes tests/golden/lightspeech_{enc,dec}.npz, leanspeech.npz
+    python tools/make_golden_backbones.py        # writes tests/golden/lightspeech_{enc,dec}.npz, leanspeech.npz, conformer.npz
 
 optispeech.model.generator.modules.LightSpeechTransformerEncoder / ...Decoder (modules/lightspeech_transformer.py:14-96,
 EncSepConvLayer / ConvSeparable modules/layers.py:455-506) are instantiated in eval mode (dropout off) at a reduced width with
@@ -21,6 +21,7 @@ sys.path.insert(0, "/root/reference")
 from tools.make_golden import install_stubs  # noqa: E402
 
 install_stubs()
+from optispeech.model.generator.modules.conformer import Conformer  # noqa: E402
 from optispeech.model.generator.modules.leanspeech import LeanSpeechBackbone  # noqa: E402
 from optispeech.model.generator.modules.lightspeech_transformer import (LightSpeechTransformerDecoder,  # noqa: E402
                                                                         LightSpeechTransformerEncoder)
@@ -31,6 +32,11 @@ def run(name, m, seed):
     with torch.no_grad():                           # move the parameters off their init pattern (biases are zero at init)
         for p in m.parameters():
             p.add_(torch.randn_like(p) * 0.05)
+        for n, b in m.named_buffers():              # BatchNorm running statistics off (0, 1): the eval path must use them
+            if n.endswith("running_mean"):
+                b.copy_(torch.randn_like(b) * 0.1)
+            elif n.endswith("running_var"):
+                b.copy_(torch.rand_like(b) + 0.5)
     B, T, C = 3, 41, 64
     lens = torch.tensor([41, 23, 6])
     x = torch.randn(B, T, C, requires_grad=True)
@@ -56,3 +62,10 @@ run("lightspeech_dec", LightSpeechTransformerDecoder(dim=64, kernel_sizes=[17, 2
 torch.manual_seed(25)
 # LeanSpeechBackbone (modules/leanspeech.py:14-97; configs/model/generator/encoder/leanspeech.yaml: kernel_size 9, drop_path 0.2), 2 layers
 run("leanspeech", LeanSpeechBackbone(dim=64, kernel_size=9, num_layers=2, drop_path=0.2).eval(), 26)
+torch.manual_seed(27)
+# Conformer (modules/conformer.py; configs/model/generator/encoder/conformer.yaml at a reduced width, 2 blocks)
+run("conformer", Conformer(dim=64, attention_heads=2, linear_units=96, num_blocks=2, dropout_rate=0.2, positional_dropout_rate=0.2,
+                           attention_dropout_rate=0.2, normalize_before=True, concat_after=False, positionwise_layer_type="conv1d",
+                           positionwise_conv_kernel_size=1, macaron_style=True, pos_enc_layer_type="rel_pos",
+                           selfattention_layer_type="rel_selfattn", activation_type="swish", use_cnn_module=True, cnn_module_kernel=7,
+                           zero_triu=False, init_type="xavier_uniform").eval(), 28)
