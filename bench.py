@@ -26,7 +26,7 @@ B, T_TEXT, T_MEL = 32, 128, 800
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r02_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/)
+PMC_SUMMARY = "r02b_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/)
 
 
 def parse():
@@ -420,7 +420,10 @@ def main():
         roof_peak = PEAK_BF16_MFMA_TFLOPS if a.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
         # the dominant kernel = whichever symbol of the direct-to-LDS conv-GEMM family spent more time in this run: the 8-wave
         # 256x256 kernel (long-K DiscriminatorP layers at full batch) or the 4-wave 128x128 one (everything else >= 160 tiles)
-        names = {"glds8": "conv_gemm_bf16_glds8_kernel (8 waves, 256x256 tiles: DiscriminatorP 512->1024 / 1024->1024 forward and dgrad at 2B waves)",
+        # symbol the dispatcher launches for the 8-wave tile: the early-issue variant unless OSP_GEMM_W8_EARLY=0 (csrc/gemm_bf16.hip)
+        sym8 = "glds8e" if os.environ.get("OSP_GEMM_W8_EARLY", "1") != "0" else "glds8"
+        symof = {"glds8": sym8, "glds": "glds"}
+        names = {"glds8": f"conv_gemm_bf16_{sym8}_kernel (8 waves, 256x256 tiles: DiscriminatorP 512->1024 / 1024->1024 forward and dgrad at 2B waves)",
                  "glds": "conv_gemm_bf16_glds_kernel (4 waves, 128x128 tiles: the remaining MPD / MRD conv-GEMM forward + fused-phase dgrad launches, N >= 128)"}
         dom = max(("glds8", "glds"), key=lambda k: ksum.get(k, (0.0, 0.0, 0))[1])
         roof_kernel = names[dom] if a.precision == "bf16" else "conv_gemm_f32 (decoder pwconv1/pwconv2, M=25600, 256<->1024)"
@@ -433,8 +436,8 @@ def main():
                 "algorithmic_flop_per_launch": flops / nlaunch if nlaunch else None,
                 "how": "HIP events on the launch stream around each selected launch, 3 serialised eager steps right after the timed region"}
         roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
-        roof["symbol"] = "conv_gemm_bf16_%s_kernel" % dom if a.precision == "bf16" else "conv_gemm_f32_kernel"
-        roof["other_mfma_kernels"] = {("conv_gemm_bf16_%s_kernel" % k): {"achieved": f / (ms * 1e-3) / 1e12, "frac": f / (ms * 1e-3) / 1e12 / roof_peak,
+        roof["symbol"] = "conv_gemm_bf16_%s_kernel" % symof[dom] if a.precision == "bf16" else "conv_gemm_f32_kernel"
+        roof["other_mfma_kernels"] = {("conv_gemm_bf16_%s_kernel" % symof[k]): {"achieved": f / (ms * 1e-3) / 1e12, "frac": f / (ms * 1e-3) / 1e12 / roof_peak,
                                                                          "avg_launch_us": ms / n * 1e3, "launches_timed": n,
                                                                          "algorithmic_flop_per_launch": f / n}
                                       for k, (f, ms, n) in other.items() if ms > 0}
