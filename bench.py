@@ -359,8 +359,11 @@ def main():
     ksum = timer.summary()
     # secondary figure: the acoustic-model-only step of the first `pretraining_steps` steps (no adversarial
     # losses, no discriminator phase: base_lightning_module.py:88,108-110,149-150); same batch, 3 warm-up + 10 timed steps
+    # The secondary figures, the CPU baseline and the inference timing are single-GPU extras (rank 0 at N = 1 only, as the
+    # measurement contract asks): a multi-GPU launch runs the timed region and the roofline pass and nothing else.
+    secondary = world == 1
     am_only = None
-    if not a.no_am_only:
+    if not a.no_am_only and secondary:
         keep, model.train_args.pretraining_steps = model.train_args.pretraining_steps, 1 << 60
         n0 = a.warmup + a.steps + 3
         for i in range(3):
@@ -378,7 +381,7 @@ def main():
     # waves with the same (not yet updated) discriminator weights (OptiSpeech.replay_disc_forward; bit-identical values, the
     # reference evaluates them twice).  Not the headline: `value` above recomputes that forward, as the reference does.
     replay = None
-    if not a.no_am_only and a.precision == "bf16":
+    if not a.no_am_only and a.precision == "bf16" and secondary:
         keep_r, model.replay_disc_forward = model.replay_disc_forward, True
         n1 = a.warmup + a.steps + 20
         for i in range(3):
@@ -395,7 +398,7 @@ def main():
     # secondary figure: the same step replayed from a captured hipGraph (one graph on one GPU, five segments with the RCCL
     # all-reduces between them under data parallelism): no Python / autograd / dispatch per step
     graph_fig = None
-    if not a.graph and not a.no_am_only and a.precision == "bf16":
+    if not a.graph and not a.no_am_only and a.precision == "bf16" and secondary:
         keep_g, keep_p = model.graph_steps, model.pipeline_steps
         model.graph_steps, model.pipeline_steps = True, False
         n2 = a.warmup + a.steps + 40
@@ -454,7 +457,7 @@ def main():
         # HBM-bound kernels north_star names (A1a class): algorithmic bytes / measured time vs the 8 TB/s peak
         roof["hbm_kernels"] = hbm_kernel_rooflines(model, dev) if a.precision == "bf16" else {}
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and secondary:
             if a.cpu_full:
                 cpu = cpu_baseline_sweep(B, 3, "8,32")
             else:
@@ -473,7 +476,7 @@ def main():
                           "lengths": "ragged" if a.ragged else "fixed"},
                "per_gpu": value / world, "host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "roofline": roof, "cpu_baseline": cpu,
                "am_only_step": am_only, "replay_disc_forward_step": replay, "graph_replay_step": graph_fig,
-               "synthesise": None if a.no_infer else synthesise_rtf(model, dev),
+               "synthesise": None if (a.no_infer or not secondary) else synthesise_rtf(model, dev),
                "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")}}
         print(json.dumps(out))
     if world > 1:
