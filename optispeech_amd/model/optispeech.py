@@ -474,6 +474,46 @@ class OptiSpeech(nn.Module):
                 b.copy_((to_native(eb) if to_native else eb).to(b.device))
 
 
+    def load_lightning_training_state(self, ckpt):
+        """Optimizer / schedule state of a reference (Lightning) ``.ckpt`` -> the fused AdamW arenas: ``optimizer_states`` (one
+        ``torch.optim.AdamW.state_dict()`` per optimizer, base_lightning_module.py:47-71: [generator, discriminator]) stores
+        ``exp_avg`` / ``exp_avg_sq`` / ``step`` by parameter INDEX in ``module.parameters()`` order, which is the order of the
+        checkpoint's own ``state_dict`` keys restricted to the parameters (pinned by tests/golden/ref_param_order.npz, produced from
+        the reference modules).  Moments are converted to the kernel-native layouts like the weights.  ``ckpt``: path or loaded dict.
+        Call after ``load_from_checkpoint(...).to(device)``."""
+        if not isinstance(ckpt, dict):
+            ckpt = torch.load(ckpt, map_location="cpu", pickle_module=_TolerantPickle, weights_only=False)
+        self.join()
+        self._step_graphs.clear()
+        sd_keys = list(ckpt["state_dict"].keys())
+        scheds = ckpt.get("lr_schedulers") or [None, None]
+        for i, (opt, sch, prefix) in enumerate(zip(self.optimizers(), self.lr_schedulers(), ("generator.", "discriminator."))):
+            ost = ckpt["optimizer_states"][i]
+            views = {key: (to_native, a, b) for key, _, to_native, a, b in self._moment_views(opt)}
+            pkeys = [k for k in sd_keys if k.startswith(prefix) and k in views]
+            ids = [pid for grp in ost["param_groups"] for pid in grp["params"]]
+            if len(ids) != len(pkeys) or len(pkeys) != len(views):
+                raise RuntimeError(f"optimizer {i}: checkpoint lists {len(ids)} parameters, its state_dict has {len(pkeys)} of this "
+                                   f"model's {len(views)} under {prefix!r}")
+            step = 0
+            for pid, key in zip(ids, pkeys):
+                st = ost["state"].get(pid)
+                to_native, a, b = views[key]
+                if st is None:                                # a parameter that never received a gradient
+                    a.zero_(); b.zero_()
+                    continue
+                ea, eb = st["exp_avg"].float(), st["exp_avg_sq"].float()
+                a.copy_((to_native(ea) if to_native else ea).to(a.device))
+                b.copy_((to_native(eb) if to_native else eb).to(b.device))
+                step = max(step, int(st["step"]))
+            opt.step_count = step
+            opt.lr = float(ost["param_groups"][0]["lr"])
+            if scheds[i] is not None and "last_epoch" in scheds[i]:
+                sch.last_step = int(scheds[i]["last_epoch"])
+        if "global_step" in ckpt:
+            self.global_step = int(ckpt["global_step"])
+
+
 class _Dummy:
     def __init__(self, *a, **k):
         pass

@@ -142,3 +142,89 @@ def test_hifigan_generator_state_dict_is_the_reference_schema(golden):
     assert sorted(sd) == sorted(g["keys"].tolist())                       # (order inside a module differs: buffers last here)
     for k in sd:
         assert tuple(sd[k].shape) == tuple(g["w_" + k].shape), k
+
+
+@pytest.mark.gpu
+def test_lightning_checkpoint_with_optimizer_state_resumes_like_torch_adamw(tmp_path, golden):
+    """A checkpoint in the layout Lightning writes for the reference module (state_dict in the reference key order,
+    ``optimizer_states`` = two torch AdamW state dicts indexed in ``module.parameters()`` order -- the order fixture was taken from
+    the reference modules --, ``lr_schedulers``, pickled hyper-parameters that reference classes this process cannot import):
+    ``load_from_checkpoint`` + ``load_lightning_training_state`` restore weights, both moment sets, step counts and learning rates,
+    and the NEXT update equals torch.optim.AdamW's next update on the reference-layout tensors."""
+    import functools
+    import sys
+    import types
+    from collections import OrderedDict
+    from optispeech_amd.config import make_optispeech
+    from optispeech_amd.model.optispeech import OptiSpeech
+    from tests.test_gpu_generator import _small_cfg
+    order = golden("ref_param_order")
+    dev = "cuda"
+    torch.manual_seed(3)
+    src = make_optispeech(_small_cfg(), batch_size=2, pretraining_steps=0).to(dev)
+    sd = src.state_dict()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    ref_params, opts = {}, []
+    for prefix, names in (("generator.", order["generator_params"]), ("discriminator.", order["discriminator_params"])):
+        ps = [torch.nn.Parameter(sd[prefix + str(k)].detach().clone().float()) for k in names]
+        ref_params[prefix] = ps
+        opt = torch.optim.AdamW(ps, lr=1.5e-4, betas=(0.8, 0.99), weight_decay=0.01, eps=1e-8)
+        for _ in range(2):                                                    # two steps: non-trivial moments, step = 2
+            for p in ps:
+                p.grad = torch.randn(p.shape, device=dev, generator=gen) * 0.01
+            opt.step()
+        opts.append(opt)
+    state = OrderedDict()
+    for prefix, keys, names in (("generator.", order["generator_state_keys"], order["generator_params"]),
+                                ("discriminator.", order["discriminator_state_keys"], order["discriminator_params"])):
+        upd = {str(k): p.detach().cpu() for k, p in zip(names, ref_params[prefix])}
+        for k in keys:
+            k = str(k)
+            if prefix + k in sd:                                              # MR-STFT windows etc. are not in our schema
+                state[prefix + k] = upd.get(k, sd[prefix + k].detach().cpu())
+    # hyper-parameters the way Hydra leaves them: partials of reference classes
+    fake = types.ModuleType("optispeech_ref_only_module")
+    fake.OptiSpeechGenerator = type("OptiSpeechGenerator", (), {"__module__": "optispeech_ref_only_module"})
+    sys.modules["optispeech_ref_only_module"] = fake
+    ckpt = {"epoch": 7, "global_step": 4, "pytorch-lightning_version": "2.2.1", "state_dict": state, "loops": {}, "callbacks": {},
+            "optimizer_states": [o.state_dict() for o in opts],
+            "lr_schedulers": [{"last_epoch": 2, "_step_count": 3, "base_lrs": [2e-4]}, {"last_epoch": 2, "_step_count": 3, "base_lrs": [2e-4]}],
+            "hyper_parameters": {"generator": functools.partial(fake.OptiSpeechGenerator)}}
+    path = tmp_path / "epoch=7.ckpt"
+    try:
+        torch.save(ckpt, path)
+    finally:
+        del sys.modules["optispeech_ref_only_module"]
+    m = OptiSpeech.load_from_checkpoint(str(path), config=_small_cfg(), strict=True).to(dev).train()
+    assert m.ckpt_loaded_epoch == 7
+    m.load_lightning_training_state(str(path))
+    og, od = m.optimizers()
+    assert (og.step_count, od.step_count, m.global_step) == (2, 2, 4) and abs(og.lr - 1.5e-4) < 1e-12
+    assert [s.last_step for s in m.lr_schedulers()] == [2, 2]
+    sd2 = m.state_dict()
+    for k, v in state.items():
+        assert torch.equal(sd2[k].cpu(), v), k
+    # moments, through the module's own layout mapping
+    for opt, topt, prefix, names in ((og, opts[0], "generator.", order["generator_params"]), (od, opts[1], "discriminator.", order["discriminator_params"])):
+        tstate = {prefix + str(k): topt.state[p] for k, p in zip(names, ref_params[prefix])}
+        for key, to_ref, _, a, b in m._moment_views(opt):
+            ea = to_ref(a) if to_ref else a
+            assert torch.allclose(ea, tstate[key]["exp_avg"], rtol=0, atol=0), key
+            eb = to_ref(b) if to_ref else b
+            assert torch.equal(eb, tstate[key]["exp_avg_sq"]), key
+    # the next update: same gradients on both sides (reference layout -> native through the mapping), no clipping
+    for opt, topt, prefix, names in ((og, opts[0], "generator.", order["generator_params"]), (od, opts[1], "discriminator.", order["discriminator_params"])):
+        gref = {prefix + str(k): torch.randn(p.shape, device=dev, generator=gen) * 0.01 for k, p in zip(names, ref_params[prefix])}
+        for k, p in zip(names, ref_params[prefix]):
+            p.grad = gref[prefix + str(k)]
+        topt.step()
+        opt.zero_grad()
+        for (key, _, to_native, _, _), p in zip(m._moment_views(opt), opt.arena.params):
+            g = gref[key]
+            p.grad.copy_(to_native(g) if to_native else g)
+        opt.step(max_norm=None)
+    torch.cuda.synchronize()
+    sd3 = m.state_dict()
+    for prefix, names in (("generator.", order["generator_params"]), ("discriminator.", order["discriminator_params"])):
+        for k, p in zip(names, ref_params[prefix]):
+            torch.testing.assert_close(sd3[prefix + str(k)], p.detach(), rtol=2e-6, atol=1e-8, msg=lambda m_: f"{prefix}{k}: {m_}")
