@@ -15,6 +15,27 @@
 #define FRAMES 8
 #define MAXCH 4   // chunks of 256 channels per lane => C <= 1024
 
+// streaming stores: the activations these kernels write are consumed by a LATER kernel, never re-read by this one -- a
+// non-temporal store keeps them from evicting the halo rows / taps the neighbouring waves still want from L2
+#ifndef OSP_NT_STORES
+#define OSP_NT_STORES 1
+#endif
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if OSP_NT_STORES
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
+#if OSP_NT_STORES
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -28,17 +49,21 @@ __device__ __forceinline__ float f4sum(float4 a) { return (a.x + a.y) + (a.z + a
 // decoder shape).  The 6 halo rows are shared with the neighbouring runs and come from L2; with FR = 16 the
 // request amplification is 22 / 16.  Everything after the loads runs out of registers: 7 FMAs per channel, two wave
 // reductions, one or two 1 KiB stores per frame.
+// launch bound: NCH = 1, FR = 8 needs 130 VGPRs unconstrained = 3 workgroups / CU = 768 resident, and the decoder shape has 800:
+// a second round of 32 workgroups ran alone at the end.  Capped at 128 VGPRs (4 / CU) the whole grid is one round.
 template <int NCH, int FR>
-__global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dw,
+__global__ __launch_bounds__(256, (NCH == 1 && FR <= 8) ? 4 : 1) void dwconv7_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dw,
                                                              const float* __restrict__ dwb, const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, float eps,
                                                              void* __restrict__ h, int h_bf16, float* __restrict__ xhat,
-                                                             float* __restrict__ rstd_out, int B, int T, int C) {
+                                                             float* __restrict__ rstd_out, int B, int T, int C, int runs_per_utt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int runs_per_utt = (T + FR - 1) / FR;
     const int run = blockIdx.x * 4 + wave;
     if (run >= B * runs_per_utt) return;
-    const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FR;
+    // run r of an utterance owns frames [r T / R, (r + 1) T / R): at most FR of them (the host picks R >= T / FR), ragged by one
+    // when R does not divide T -- R is chosen so that B * R fills whole rounds of resident waves (see the launcher)
+    const int b = run / runs_per_utt, rr = run - b * runs_per_utt;
+    const int t0 = (int)((int64_t)rr * T / runs_per_utt), t1 = (int)((int64_t)(rr + 1) * T / runs_per_utt);
     const float* xb = x + (int64_t)b * T * C;
     bool act[NCH];
     float4 rows[NCH][FR + 6];
@@ -68,7 +93,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __rest
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
         const int t = t0 + f;
-        if (t < T) {                                            // wave-uniform
+        if (t < t1) {                                           // wave-uniform
             float4 c[NCH];
             float s = 0.f;
 #pragma unroll
@@ -94,15 +119,15 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_kernel(const float* __rest
                 if (act[k]) {
                     const float4 n = make_float4(c[k].x * rstd, c[k].y * rstd, c[k].z * rstd, c[k].w * rstd);
                     const int ch = k * 256 + lane * 4;
-                    if (xhat) *reinterpret_cast<float4*>(xhat + row + ch) = n;
+                    if (xhat) st_stream(reinterpret_cast<float4*>(xhat + row + ch), n);
                     const float4 o = f4fma(n, gw[k], gb[k]);
                     if (h_bf16) {                               // the consumer is the bf16 GEMM: half the bytes, no cast launch later
                         typedef __bf16 v2 __attribute__((ext_vector_type(2)));
                         v2 p0, p1; p0[0] = (__bf16)o.x; p0[1] = (__bf16)o.y; p1[0] = (__bf16)o.z; p1[1] = (__bf16)o.w;
-                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(h) + row + ch) =
-                            make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1));
+                        st_stream(reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(h) + row + ch),
+                                  make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)));
                     } else {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(h) + row + ch) = o;
+                        st_stream(reinterpret_cast<float4*>(reinterpret_cast<float*>(h) + row + ch), o);
                     }
                 }
             if (rstd_out && lane == 0) rstd_out[(int64_t)b * T + t] = rstd;
@@ -117,8 +142,22 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
     OSP_CHECK_ARG(x && dw && dwb && lnw && lnb && h, "null operand");
     OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
     const int nch = (int)cdiv(C, 256);
-    // frames per wave: 8 (one or two 256-channel chunks; 16 halves the occupancy: 174 VGPRs), 4 beyond
-#define L(N, F) hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * cdiv(T, F), 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, (int)C)
+    // frames per wave: 8 (one or two 256-channel chunks; 16 halves the occupancy: 174 VGPRs), 4 beyond.
+    // Runs per utterance R >= ceil(T / FR).  The C <= 256 kernel keeps 4 workgroups = 16 waves per CU resident (4096 waves on the
+    // chip): when B * ceil(T / FR) is within reach of a whole number of such rounds, R is raised so that B * R IS one -- the
+    // decoder shape (32 x 800, FR 8) has 3200 runs = 800 workgroups = 3.1 per CU, i.e. the CUs holding four set the time; with
+    // R = 128 (runs of 6 or 7 frames) every CU holds exactly four (tools/lndw_probe.py: 15.0 -> 14.5 us).
+    auto pick_runs = [&](int fr) -> int {
+        const int64_t rmin = cdiv(T, fr);
+        static int balance = -1;
+        if (balance < 0) { const char* e = getenv("OSP_DWCONV_BALANCE"); balance = (e && atoi(e) == 0) ? 0 : 1; }
+        if (!balance || nch != 1) return (int)rmin;
+        const int64_t resident = 4096, total = B * rmin;
+        const int64_t rounds = cdiv(total, resident);
+        const int64_t r = (rounds * resident) / B;                       // largest R with B * R <= rounds * resident
+        return (int)((r >= rmin && r * 10 <= rmin * 13 && r <= T) ? r : rmin);   // at most 30 % more (shorter) runs
+    };
+#define L(N, F) do { const int R_ = pick_runs(F); hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * (int64_t)R_, 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, (int)C, R_); } while (0)
     static int fr1 = -1;
     if (fr1 < 0) { const char* e = getenv("OSP_DWCONV_FR"); fr1 = e ? atoi(e) : 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
     if (nch == 1) { if (fr1 == 8) L(1, 8); else if (fr1 == 4) L(1, 4); else L(1, 16); } else if (nch == 2) L(2, 8); else if (nch == 3) L(3, 4); else L(4, 4);
@@ -175,7 +214,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                     o.w *= u32_to_unit(r.w) < drop_p ? 0.f : keep;
                 }
                 o.x *= rm; o.y *= rm; o.z *= rm; o.w *= rm;
-                *reinterpret_cast<float4*>(y + row * C + ch) = o;
+                st_stream(reinterpret_cast<float4*>(y + row * C + ch), o);
             }
         }
         if (lane == 0) {
@@ -223,49 +262,74 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int ch = k * 256 + lane * 4;
         gw[k] = ch < C ? *reinterpret_cast<const float4*>(w + ch) : f4zero();
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean ? mean[row] : 0.f, rs = rstd[row];
-        const float rm = rowmask ? rowmask[row] : 1.f;
-        float4 g[NCH], xh[NCH];
-        float s1 = 0.f, s2 = 0.f;
+    // two rows per trip, both requested before either is reduced: a wave otherwise exposes a full memory latency per row
+    // (one dependent load -> two wave reductions -> store chain at a time)
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t row0 = (int64_t)blockIdx.x * 4 + wave; row0 < rows; row0 += 2 * stride) {
+        float4 dv[2][NCH], xv_[2][NCH], rl[2][NCH];
+        float mu_[2], rs_[2], rm_[2];
+        bool live[2];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int ch = k * 256 + lane * 4;
-            if (ch < C) {
-                float4 d = *reinterpret_cast<const float4*>(dy + row * C + ch);
-                float4 xv = *reinterpret_cast<const float4*>(xin + row * C + ch);
-                if (mean) { xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs; }
-                if (drop_p > 0.f) {
-                    const uint64_t e = (uint64_t)row * C + ch;
-                    const uint4 r = philox4(seed, e >> 2, stream_id);
-                    const float keep = 1.0f / (1.0f - drop_p);
-                    d.x *= u32_to_unit(r.x) < drop_p ? 0.f : keep;
-                    d.y *= u32_to_unit(r.y) < drop_p ? 0.f : keep;
-                    d.z *= u32_to_unit(r.z) < drop_p ? 0.f : keep;
-                    d.w *= u32_to_unit(r.w) < drop_p ? 0.f : keep;
-                }
-                d.x *= rm; d.y *= rm; d.z *= rm; d.w *= rm;
-                aw[k] = f4fma(d, xv, aw[k]);
-                ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
-                d.x *= gw[k].x; d.y *= gw[k].y; d.z *= gw[k].z; d.w *= gw[k].w;
-                g[k] = d; xh[k] = xv;
-                s1 += f4sum(d);
-                s2 += d.x * xv.x + d.y * xv.y + d.z * xv.z + d.w * xv.w;
-            } else { g[k] = f4zero(); xh[k] = f4zero(); }
+        for (int q = 0; q < 2; ++q) {
+            const int64_t row = row0 + q * stride;
+            live[q] = row < rows;
+            const int64_t rsafe = live[q] ? row : row0;
+            mu_[q] = mean ? mean[rsafe] : 0.f; rs_[q] = rstd[rsafe]; rm_[q] = rowmask ? rowmask[rsafe] : 1.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = k * 256 + lane * 4;
+                const int cs = ch < C ? ch : 0;
+                dv[q][k] = *reinterpret_cast<const float4*>(dy + rsafe * C + cs);
+                xv_[q][k] = *reinterpret_cast<const float4*>(xin + rsafe * C + cs);
+                rl[q][k] = relu_src ? *reinterpret_cast<const float4*>(relu_src + rsafe * C + cs) : f4zero();
+            }
         }
-        const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int ch = k * 256 + lane * 4;
-            if (ch < C) {
-                float4 o = make_float4(rs * (g[k].x - m1 - xh[k].x * m2), rs * (g[k].y - m1 - xh[k].y * m2),
-                                       rs * (g[k].z - m1 - xh[k].z * m2), rs * (g[k].w - m1 - xh[k].w * m2));
-                if (relu_src) {
-                    const float4 r = *reinterpret_cast<const float4*>(relu_src + row * C + ch);
-                    o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
-                    o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+        for (int q = 0; q < 2; ++q) {
+            if (!live[q]) continue;                              // wave-uniform
+            const int64_t row = row0 + q * stride;
+            const float mu = mu_[q], rs = rs_[q], rm = rm_[q];
+            float4 g[NCH], xh[NCH];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = k * 256 + lane * 4;
+                if (ch < C) {
+                    float4 d = dv[q][k];
+                    float4 xv = xv_[q][k];
+                    if (mean) { xv.x = (xv.x - mu) * rs; xv.y = (xv.y - mu) * rs; xv.z = (xv.z - mu) * rs; xv.w = (xv.w - mu) * rs; }
+                    if (drop_p > 0.f) {
+                        const uint64_t e = (uint64_t)row * C + ch;
+                        const uint4 r = philox4(seed, e >> 2, stream_id);
+                        const float keep = 1.0f / (1.0f - drop_p);
+                        d.x *= u32_to_unit(r.x) < drop_p ? 0.f : keep;
+                        d.y *= u32_to_unit(r.y) < drop_p ? 0.f : keep;
+                        d.z *= u32_to_unit(r.z) < drop_p ? 0.f : keep;
+                        d.w *= u32_to_unit(r.w) < drop_p ? 0.f : keep;
+                    }
+                    d.x *= rm; d.y *= rm; d.z *= rm; d.w *= rm;
+                    aw[k] = f4fma(d, xv, aw[k]);
+                    ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
+                    d.x *= gw[k].x; d.y *= gw[k].y; d.z *= gw[k].z; d.w *= gw[k].w;
+                    g[k] = d; xh[k] = xv;
+                    s1 += f4sum(d);
+                    s2 += d.x * xv.x + d.y * xv.y + d.z * xv.z + d.w * xv.w;
+                } else { g[k] = f4zero(); xh[k] = f4zero(); }
+            }
+            const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = k * 256 + lane * 4;
+                if (ch < C) {
+                    float4 o = make_float4(rs * (g[k].x - m1 - xh[k].x * m2), rs * (g[k].y - m1 - xh[k].y * m2),
+                                           rs * (g[k].z - m1 - xh[k].z * m2), rs * (g[k].w - m1 - xh[k].w * m2));
+                    if (relu_src) {
+                        const float4 r = rl[q][k];
+                        o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f;
+                        o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+                    }
+                    st_stream(reinterpret_cast<float4*>(dx + row * C + ch), o);
                 }
-                *reinterpret_cast<float4*>(dx + row * C + ch) = o;
             }
         }
     }
@@ -293,7 +357,9 @@ extern "C" int osp_layernorm_bwd(const float* dy, const float* xin, const float*
     OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr), "dlnw/dlnb come together");
     OSP_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
     const int64_t blocks = cdiv(rows, 4 * FRAMES);   // FRAMES rows per wave => few atomics
-    dim3 grid((unsigned)(blocks < 1024 ? blocks : 1024));
+    static int64_t lnb_cap = 0;
+    if (!lnb_cap) { const char* e = getenv("OSP_LNBWD_WG"); lnb_cap = e ? atoll(e) : 256; }      // tools/lndw_probe.py at 32 x 800 x 256, two rows in flight: caps 256 / 512 / 1024 = 25.0 / 26.8 / 31.3 us (the device-scope atomics of the parameter gradients cost more than the lost latency hiding)
+    dim3 grid((unsigned)(blocks < lnb_cap ? blocks : lnb_cap));
     const int nch = (int)cdiv(C, 256);
 #define L(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), grid, dim3(256), 0, stream, dy, xin, mean, rstd, w, relu_src, rowmask, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, dx, dlnw, dlnb, rows, (int)C)
     if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
@@ -365,7 +431,7 @@ __global__ __launch_bounds__(256) void dwconv7_bwd_kernel(const float* __restric
                     gw[k][j] = f4fma(d0, wx[k][j], gw[k][j]);     // x[t + j - 3]
                 }
                 gb[k].x += d0.x; gb[k].y += d0.y; gb[k].z += d0.z; gb[k].w += d0.w;
-                *reinterpret_cast<float4*>(dx + off) = a;
+                st_stream(reinterpret_cast<float4*>(dx + off), a);
             }
         }
     if (!ddw) return;
@@ -409,14 +475,14 @@ extern "C" int osp_dwconv7_bwd(const float* dc, const float* x, const float* dw,
 // each), so dc never leaves the registers.  Algorithmic HBM bytes per frame: (dh + xhat + x + dres) reads + dx write = 5 * C * 4.
 // Loads are requested in two bursts (dh + xhat rows, then x + dres rows) to stay under 256 VGPRs with the 7 + 3 parameter-
 // gradient accumulators live.
-template <int FR>
-__global__ __launch_bounds__(256, 2) void ln_dwconv7_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ xhat,
+template <int FR, int NWV>
+__global__ __launch_bounds__(64 * NWV, 8 / NWV) void ln_dwconv7_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ xhat,
                                                              const float* __restrict__ rstd, const float* __restrict__ lnw,
                                                              const float* __restrict__ x, const float* __restrict__ dw,
                                                              const float* __restrict__ dres, const float* __restrict__ dres_rowmask,
                                                              float* __restrict__ dx, float* __restrict__ dlnw, float* __restrict__ dlnb,
                                                              float* __restrict__ ddw, float* __restrict__ ddb, int B, int T, int C) {
-    __shared__ float red[4][10][256];
+    __shared__ float red[NWV][10][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int runs_per_utt = (T + FR - 1) / FR, nruns = B * runs_per_utt;
     const int ch = lane * 4;
@@ -431,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void ln_dwconv7_bwd_kernel(const float* __r
     // runs of a wave, so every channel takes one atomic per WORKGROUP, not per run.  Three load bursts per run, fenced against
     // each other (the scheduler otherwise hoists all of them to the top and the kernel spills): dh + xhat -> dc window;
     // dres + taps -> dx; x window -> tap gradients.
-    for (int run = blockIdx.x * 4 + wave; run < nruns; run += gridDim.x * 4) {
+    for (int run = blockIdx.x * NWV + wave; run < nruns; run += gridDim.x * NWV) {
         const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FR;
         const int64_t base = (int64_t)b * T * C;
         float4 dc[FR + 6];
@@ -485,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void ln_dwconv7_bwd_kernel(const float* __r
                     float4 a = dr[f];
 #pragma unroll
                     for (int j = 0; j < 7; ++j) a = f4fma(w[j], dc[f + 6 - j], a);      // dc[t - j + 3]
-                    *reinterpret_cast<float4*>(dx + base + (int64_t)t * C + ch) = a;
+                    st_stream(reinterpret_cast<float4*>(dx + base + (int64_t)t * C + ch), a);
                 }
             }
         }
@@ -517,10 +583,15 @@ __global__ __launch_bounds__(256, 2) void ln_dwconv7_bwd_kernel(const float* __r
     for (int j = 0; j < 10; ++j)
         *reinterpret_cast<float4*>(&red[wave][j][lane * 4]) = j < 7 ? gwt[j] : j == 7 ? gb : j == 8 ? aw : ab;
     __syncthreads();
-    for (int i = threadIdx.x; i < 10 * 256; i += 256) {
+    for (int i = threadIdx.x; i < 10 * 256; i += 64 * NWV) {
         const int j = i >> 8, c = i & 255;
         float* dst = j < 7 ? (ddw ? ddw + (int64_t)j * C : nullptr) : j == 7 ? ddb : j == 8 ? dlnw : dlnb;
-        if (dst && c < C) atomicAdd(dst + c, red[0][j][c] + red[1][j][c] + red[2][j][c] + red[3][j][c]);
+        if (dst && c < C) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) sum += red[q][j][c];
+            atomicAdd(dst + c, sum);
+        }
     }
 }
 
@@ -532,10 +603,13 @@ extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const floa
     OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256, "C must be a multiple of 4, <= 256 (wider blocks: osp_layernorm_bwd + osp_dwconv7_bwd)");
     static int fr = -1;
     if (fr < 0) { const char* e = getenv("OSP_LNDW_FR"); fr = e ? atoi(e) : 4; }      // tools/lndw_probe.py at 32 x 800 x 256: FR 4 / 6 / 8 = 41.9 / 49.7 / 50.6 us (8 spills: 256-VGPR cap for two workgroups / CU)
-    static int maxwg = -1;
-    if (maxwg < 0) { const char* e = getenv("OSP_LNDW_WG"); maxwg = e ? atoi(e) : 512; }      // two workgroups per CU are resident (220 VGPRs)
-#define L(F) hipLaunchKernelGGL((ln_dwconv7_bwd_kernel<F>), dim3((unsigned)(cdiv(B * cdiv(T, F), 4) < maxwg ? cdiv(B * cdiv(T, F), 4) : maxwg)), dim3(256), 0, stream, dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, (int)B, (int)T, (int)C)
-    if (fr == 4) L(4); else if (fr == 6) L(6); else L(8);
+    // 256 VGPRs per thread: 8 waves per CU are resident, as one workgroup of 8 waves (256 workgroups: half the atomics per address)
+    // or two of 4 (OSP_LNDW_NWV=4)
+    static int nwv = -1, maxwg = -1;
+    if (nwv < 0) { const char* e = getenv("OSP_LNDW_NWV"); nwv = (e && atoi(e) == 4) ? 4 : 8; }
+    if (maxwg < 0) { const char* e = getenv("OSP_LNDW_WG"); maxwg = e ? atoi(e) : 2048 / nwv; }
+#define L(F, W) hipLaunchKernelGGL((ln_dwconv7_bwd_kernel<F, W>), dim3((unsigned)(cdiv(B * cdiv(T, F), W) < maxwg ? cdiv(B * cdiv(T, F), W) : maxwg)), dim3(64 * W), 0, stream, dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, (int)B, (int)T, (int)C)
+    if (nwv == 8) { if (fr == 8) L(8, 8); else L(4, 8); } else { if (fr == 8) L(8, 4); else L(4, 4); }
 #undef L
     OSP_LAUNCH_CHECK();
     return OSP_OK;

@@ -28,6 +28,7 @@ for (B, T, C) in [(32, 800, 256), (32, 128, 256)]:
     def fwd():
         return K.dwconv7_ln_fwd(x, dw, g[3], lnw, g[1], 1e-6, True, h_bf16=True)
     print(f"   fused without parameter gradients {timeit(fused_nograd):6.1f} us; forward (bf16 h, xhat saved) {timeit(fwd):6.1f} us")
+    print(f"   stand-alone layernorm_bwd {timeit(lambda: K.layernorm_bwd(dh, xhat, None, rstd, lnw, g[0], g[1])):6.1f} us")
     tp, tf = timeit(pair), timeit(fused)
     alg = 5 * M * C * 4
     print(f"{os.environ.get('TAG','')} B={B} T={T} C={C}: pair {tp:6.1f} us, fused {tf:6.1f} us = {alg/tf/1e3:6.0f} GB/s ({alg/tf/1e3/8000*100:4.1f} % of 8 TB/s; algorithmic {alg/1e6:.1f} MB)")
