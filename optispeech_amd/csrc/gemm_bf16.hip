@@ -404,6 +404,9 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
 // Kernel selection + launch for a filled parameter block.  With p.nphase > 0 (fused dgrad phases) the grid's z dimension
 // enumerates the phases and p.M is the largest phase (see GemmB::Phase); batch must then be 1.
 static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
+    static int nt_env = -1;
+    if (nt_env < 0) { const char* e = getenv("OSP_GEMM_NT"); nt_env = e ? atoi(e) : 0; }
+    p.nt_out = nt_env;
     const int64_t M = p.M, N = p.N, Cin = p.Cin, taps = p.taps, lda = p.lda, sBn = p.sBn, sBtap = p.sBtap, sBk = p.sBk,
                   sAb = p.sAb, sBb = p.sBb, a_bf16 = p.a_bf16, b_bf16 = p.b_bf16;
     const int64_t d2_9 = p.sBtap_h;

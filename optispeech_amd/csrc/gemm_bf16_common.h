@@ -45,6 +45,7 @@ struct GemmB {
     // 2-D (conv2d over channels-last (U,H,W,C)) extension; the 1-D case has Hin = 1, Wrows = Trows, KW = taps
     int Wrows, Hin, KW, a_step_h, a_tapstep_h, a_off_h, Wc, c_step_h, c_off_h; int64_t sBtap_h;
     int64_t sAb, sBb, sCb, sXb; int accumulate;
+    int nt_out;                                      // bf16 row stores of the epilogue as non-temporal (streaming) stores
     FastDiv fd_trows, fd_wrows;
     // output phases of a strided-conv dgrad fused into one launch (blockIdx.z = phase; batch must be 1): the fields a phase
     // overrides -- its row count / geometry, tap subset (count, KW, first-tap offsets into dy and into the weights) and the
@@ -65,6 +66,15 @@ __device__ __forceinline__ GemmB gemm_select_phase(const GemmB& pin) {
     return pp;
 }
 
+// 16-byte output row chunk; nt (kernel-uniform): the consumer is a later kernel, keep the operand panels in L2 instead
+__device__ __forceinline__ void st_rows(uint4* p, uint4 v, int nt) {
+    if (nt) {
+        __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+        __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+    } else {
+        *p = v;
+    }
+}
 __device__ __forceinline__ unsigned pk2(float a, float b) {
     bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
     return __builtin_bit_cast(unsigned, r);
@@ -237,8 +247,8 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_f(y[k]);
                 }
-                *reinterpret_cast<uint4*>(Cb + crow * pp.ldc + n) =
-                    make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7]));
+                st_rows(reinterpret_cast<uint4*>(Cb + crow * pp.ldc + n),
+                        make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7])), pp.nt_out);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -346,8 +356,8 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
             if (m < M && n < N) {
                 const int u = fd_div(m, fd_trows), t = m - u * Trows, th = fd_div(t, fd_wrows), tw = t - th * Wrows;
                 const int64_t crow = (int64_t)u * Tc + (int64_t)(th * c_step_h + c_off_h) * Wc + (int64_t)tw * c_step + c_off;
-                *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(Cb) + crow * ldc + n) =
-                    *reinterpret_cast<const uint4*>(stage + lrow * SP + cc * 8);
+                st_rows(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(Cb) + crow * ldc + n),
+                        *reinterpret_cast<const uint4*>(stage + lrow * SP + cc * 8), pp.nt_out);
             }
         }
     }
