@@ -725,6 +725,18 @@ def attn_softmax_fwd(S, klen, B, H, T1, T2, scale, drop_p=0.0, seed=0, stream_id
     return S, (Pd if Pd is not None else S)
 
 
+def attn_fused_fwd(q, k, v, klen, H):
+    """softmax(q k^T / sqrt(dk) over the valid keys) v per head, scores never written: q, k, v (B, T, H*dk) f32 -> (B, T, H*dk).
+    bf16 MFMA operands (performance mode only), no dropout, no gradient."""
+    _f32(q, k, v)
+    B, T, C = q.shape
+    dk = C // H
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and klen.dtype == torch.int64
+    o = torch.empty_like(q)
+    call("osp_attn_fused_fwd", q, k, v, klen, o, B, H, T, dk, 1.0 / float(dk) ** 0.5)
+    return o
+
+
 def attn_softmax_bwd(P, dPd, scale, drop_p=0.0, seed=0, stream_id=0):
     """in place: dPd (gradient w.r.t. the dropped probabilities) -> gradient w.r.t. the raw scores."""
     T2 = P.shape[-1]

@@ -78,6 +78,7 @@ class side_wgrad:
 
 
 _FUSED_LN_DW = _os.environ.get("OSP_FUSED_LN_DW", "1") != "0"
+_FUSED_ATTN = _os.environ.get("OSP_FUSED_ATTN", "1") != "0"
 
 
 class ConvNeXtBlockFn(torch.autograd.Function):
@@ -599,6 +600,10 @@ class AttentionFn(torch.autograd.Function):
         B, T, C = q.shape
         dk = C // H
         Z = B * H
+        if (_FUSED_ATTN and sbias is None and drop_p == 0.0 and not any(ctx.needs_input_grad) and q.is_cuda
+                and _precision.is_bf16() and dk in (32, 64, 128)):
+            # no-grad / inference: one flash-style kernel, the (B*H, T, T) scores never exist (csrc/attention.hip)
+            return K.attn_fused_fwd(q.contiguous(), k.contiguous(), v.contiguous(), klen, H)
         heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)      # noqa: E731
         qh, kh, vh = heads(q), heads(k), heads(v)
         scale = 1.0 / float(dk) ** 0.5

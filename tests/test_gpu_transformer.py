@@ -100,3 +100,44 @@ def test_transformer_generator_train_step_runs():
         assert wav.shape[0] == 2 and torch.isfinite(wav).all()
     finally:
         precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("B,T,H,dk", [(3, 37, 2, 32), (2, 130, 2, 64), (4, 800, 2, 128), (1, 5, 4, 32), (2, 257, 2, 128)])
+def test_fused_attention_forward_matches_the_unfused_path(B, T, H, dk):
+    """osp_attn_fused_fwd (flash-style: no (T x T) scores in HBM; bf16 operands) against softmax(q k^T / sqrt(dk)) v in f64 with
+    the key-padding mask of the reference (masked keys -> probability 0), ragged lengths, query blocks and key tiles that end inside
+    the sequence."""
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 100 + T)
+    C = H * dk
+    q, k, v = (torch.randn(B, T, C, generator=g).to(DEV) for _ in range(3))
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    klen = lens.to(DEV)
+    o = K.attn_fused_fwd(q, k, v, klen, H)
+    bf = lambda t: t.to(torch.bfloat16).double().cpu()                                            # noqa: E731
+    qh, kh, vh = (bf(t).view(B, T, H, dk).permute(0, 2, 1, 3) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) / dk ** 0.5
+    mask = torch.arange(T)[None, None, None, :] >= lens[:, None, None, None]
+    p = torch.softmax(s.masked_fill(mask, float("-inf")), -1).masked_fill(mask, 0.0)
+    want = (p @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
+    err = (o.double().cpu() - want).abs().max().item()
+    assert err < 2e-2, err                                                                         # probabilities are rounded to bf16 for the P V product
+    rel = ((o.double().cpu() - want).norm() / want.norm()).item()
+    assert rel < 5e-3, rel
+
+
+def test_attention_function_takes_the_fused_kernel_without_grad():
+    from optispeech_amd import ops, precision
+    precision.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(3)
+        q, k, v = (torch.randn(2, 96, 256, generator=g).to(DEV) for _ in range(3))
+        klen = torch.tensor([96, 40], device=DEV)
+        with torch.no_grad():
+            fused = ops.AttentionFn.apply(q, k, v, klen, 2, 0.0, 0, 0)
+        ref = ops.AttentionFn.apply(q.requires_grad_(True), k, v, klen, 2, 0.0, 0, 0)                  # unfused (saves probabilities)
+        assert ref.grad_fn is not None
+        torch.testing.assert_close(fused, ref.detach(), rtol=3e-2, atol=3e-2)
+    finally:
+        precision.set_precision("f32")
