@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import precision, spectral
 from ..disc_ops import (MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, FeatureMatchSumFn, HingeSumFn,
-                        L1MeanFn, wnorm_pack_many)
+                        L1MeanFn, SplitHalvesFn, wnorm_pack_many)
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -140,8 +140,7 @@ def _replay_scores(d, B):
     for conv in list(d.convs) + [d.conv_post]:
         args += [conv.weight_v, conv.weight_g, conv.bias]
     s = ConvStackReplayFn.apply(rec, *args)
-    o = s.reshape(2 * B, -1)
-    return o[:B], o[B:]
+    return SplitHalvesFn.apply(s.reshape(2 * B, -1), B)
 
 
 class _Multi(nn.Module):
@@ -179,7 +178,7 @@ class _Multi(nn.Module):
         for d in self.discriminators:
             if real_needs_grad:                              # discriminator phase: one batch of 2B waves per launch
                 o, fm = d(torch.cat([y, y_hat], 0))
-                r, g = o[:B], o[B:]
+                r, g = SplitHalvesFn.apply(o, B)
                 fr, fg = [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm]
             elif precision.is_bf16():
                 # generator phase: real (no gradient) and generated waves share every forward launch; the backward of the
@@ -211,7 +210,8 @@ class _Multi(nn.Module):
                     out = (rep[0], rep[1], [], [])
                 elif with_param_grads:                       # discriminator phase: one batch of 2B waves per launch
                     o, fm = d(x)
-                    out = (o[:B], o[B:], [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm])
+                    r_, g_ = SplitHalvesFn.apply(o, B)
+                    out = (r_, g_, [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm])
                 else:                                        # generator phase: no-grad head = the real waves
                     (r, fr), (g, fg) = d(x, nograd_head=B)
                     out = (r, g, fr, fg)

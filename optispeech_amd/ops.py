@@ -399,9 +399,10 @@ class VarianceEmbedFn(torch.autograd.Function):
         x = x.contiguous()
         v = values.contiguous().view(B * T, 1)
         if drop_p > 0.0:
+            # x + dropout(emb) in one launch; the backward regenerates the mask from the same Philox counter (element index)
             emb = K.conv_gemm(v, w, C, T=T, taps=taps, pad=pad, bias=b)
-            dm = dropout_mask((B * T, C), drop_p, seed, stream_id, x.device)
-            y = (x.view(B * T, C) + emb * dm) * rowmask[:, None]
+            y = K.dropout_add(emb, drop_p, seed, stream_id, res=x.view(B * T, C)) * rowmask[:, None]
+            dm = None
         else:
             dm = None
             y = K.conv_gemm(v, w, C, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_SCALE_RES_MASK, res=x.view(B * T, C),
@@ -410,6 +411,7 @@ class VarianceEmbedFn(torch.autograd.Function):
             ctx.save_for_backward(v, rowmask, dm)
             ctx.params = (w, b)
             ctx.cfg = (B, T, C, taps, pad)
+            ctx.drop = (drop_p, seed, stream_id)
         return y.view(B, T, C)
 
     @staticmethod
@@ -419,7 +421,8 @@ class VarianceEmbedFn(torch.autograd.Function):
         B, T, C, taps, pad = ctx.cfg
         g = dy.contiguous().view(B * T, C) * rowmask[:, None]
         dx = g.view(B, T, C) if ctx.needs_input_grad[0] else None
-        ge = g if dm is None else g * dm
+        drop_p, seed, stream_id = ctx.drop
+        ge = K.dropout_add(g, drop_p, seed, stream_id) if drop_p > 0.0 else g
         dval = None
         if ctx.needs_input_grad[1]:
             base = w.detach()[:, taps - 1:, :]

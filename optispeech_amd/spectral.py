@@ -29,8 +29,17 @@ def _padded_window(window, n_fft):
     wl = window.shape[0]
     if wl == n_fft:
         return window.contiguous()
-    left = (n_fft - wl) // 2
-    return F.pad(window, (left, n_fft - wl - left)).contiguous()
+    # the window is a constant buffer: pad it once per (tensor, version, n_fft), not on every STFT (a fill + a copy per call)
+    hit = getattr(window, "_osp_padded", None)
+    key = (n_fft, window._version, window.data_ptr())
+    if hit is None or hit[0] != key:
+        left = (n_fft - wl) // 2
+        hit = (key, F.pad(window.detach(), (left, n_fft - wl - left)).contiguous())
+        try:
+            window._osp_padded = hit
+        except (AttributeError, RuntimeError):
+            pass
+    return hit[1]
 
 
 class _StftMagFn(torch.autograd.Function):
