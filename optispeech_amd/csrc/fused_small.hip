@@ -489,3 +489,42 @@ extern "C" int osp_drop_path_rows(const float* drop_p_host, const float* rowmask
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ period folding (DiscriminatorP)
+// DiscriminatorP.forward (_discriminators.py:63-72): reflect-pad the wave on the right to a multiple of the period, view it as
+// (b, t / p, p) and hand every period column to the (k, 1) convs -- here as channels-last sequences (b * p, t / p):
+//   seq[b * p + w, h] = xpad[b, h * p + w],   xpad[b, i] = x[b, i] (i < T),  x[b, 2 T - 2 - i] (T <= i < Tp * p)
+// One launch instead of reflection_pad1d + a strided copy; the gradient (dx[i] = g(i) + g(2 T - 2 - i) where the mirror image lies in
+// the pad) is one launch instead of a fill + reflection_pad1d_backward + a strided copy + an add.
+__global__ __launch_bounds__(256) void period_fold_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int T, int p, int Tp,
+                                                          int backward) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        if (!backward) {                                       // e indexes seq: (b, w, h)
+            const int h = (int)(e % Tp);
+            const int64_t bw = e / Tp;
+            const int w = (int)(bw % p);
+            const int64_t b = bw / p;
+            const int i = h * p + w;
+            y[e] = x[b * T + (i < T ? i : 2 * T - 2 - i)];
+        } else {                                               // e indexes dx: (b, i);  x = dseq
+            const int i = (int)(e % T);
+            const int64_t b = e / T;
+            const float* g = x + b * (int64_t)p * Tp;
+            float v = g[(int64_t)(i % p) * Tp + i / p];
+            const int m = 2 * T - 2 - i;                        // mirror image of i in the pad, if any
+            if (m >= T && m < Tp * p) v += g[(int64_t)(m % p) * Tp + m / p];
+            y[e] = v;
+        }
+    }
+}
+extern "C" int osp_period_fold(const float* x, float* y, int64_t B, int64_t T, int64_t period, int64_t backward, hipStream_t stream) {
+    OSP_CHECK_ARG(x && y && B > 0 && T > 1 && period > 0 && period < T, "bad args");
+    const int64_t Tp = cdiv(T, period);
+    const int64_t n = backward ? B * T : B * period * Tp;
+    const int64_t blocks = cdiv(n, 256 * 4);
+    hipLaunchKernelGGL(period_fold_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, x, y, n, (int)T, (int)period,
+                       (int)Tp, (int)(backward != 0));
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

@@ -473,6 +473,21 @@ class FeatureMatchSumFn(torch.autograd.Function):
         return (None,) + (None,) * n + tuple(grads)
 
 
+class PeriodFoldFn(torch.autograd.Function):
+    """wave (B, T) -> (B * period, 1, ceil(T / period), 1) period-column sequences incl. the right reflect pad
+    (DiscriminatorP.forward, _discriminators.py:63-72): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, x, period):
+        ctx.period, ctx.T = period, x.shape[1]
+        y = K.period_fold(x.contiguous(), period)
+        return y.view(y.shape[0], 1, y.shape[1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.period_fold(dy.reshape(dy.shape[0], -1).contiguous().float(), ctx.period, backward=True, T=ctx.T), None
+
+
 class SplitHalvesFn(torch.autograd.Function):
     """(o[:B], o[B:]) of a score map computed on the concatenated (real, generated) batch.  Plain slicing costs two zero fills,
     two copies and an add per map in the backward (SliceBackward x 2 + accumulation); here the backward is one cat."""

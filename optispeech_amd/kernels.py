@@ -387,6 +387,21 @@ def drop_path_rows(drop_p, rowmask, B, T, seed, stream_id, device):
     return scale, rowf
 
 
+def period_fold(x, period, backward=False, T=None):
+    """forward: wave (B, T) -> period-column sequences (B * period, ceil(T / period)) with the reference's right reflect pad;
+    backward: gradient of those sequences -> (B, T)."""
+    _f32(x)
+    assert x.is_contiguous()
+    if not backward:
+        B, T = x.shape
+        y = torch.empty((B * period, -(-T // period)), device=x.device, dtype=torch.float32)
+    else:
+        B = x.shape[0] // period
+        y = torch.empty((B, T), device=x.device, dtype=torch.float32)
+    call("osp_period_fold", x, y, B, T, period, int(backward))
+    return y
+
+
 def segment_starts(r01, lengths, segment_size, lead=4):
     """long(r01 * clamp(float(len - lead) - segment_size, 0)) per utterance (utils/segments.py:29-34), one launch."""
     _f32(r01)

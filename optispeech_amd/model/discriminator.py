@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import precision, spectral
 from ..disc_ops import (MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, FeatureMatchSumFn, HingeSumFn,
-                        L1MeanFn, SplitHalvesFn, wnorm_pack_many)
+                        L1MeanFn, PeriodFoldFn, SplitHalvesFn, wnorm_pack_many)
 
 
 class BaseVocoderDiscriminator(nn.Module):
@@ -60,15 +60,11 @@ class DiscriminatorP(nn.Module):
     def forward(self, x, nograd_head=0):
         """nograd_head = B0 (bf16 mode only): the first B0 waves are a no-grad branch sharing the launches; returns
         ((score, fmap) of the head, (score, fmap) of the rest)."""
-        x = x.unsqueeze(1)
-        b, c, t = x.shape
-        if t % self.period != 0:
-            n_pad = self.period - (t % self.period)
-            x = F.pad(x, (0, n_pad), "reflect")
-            t = t + n_pad
-        if precision.is_bf16():
-            # channels-last sequences (B*period, T/period, 1): every period column is an independent 1-D signal
-            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)
+        if precision.is_bf16() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            # channels-last sequences (B*period, T/period, 1): every period column is an independent 1-D signal; reflect pad and
+            # folding in one launch (csrc/fused_small.hip: period_fold_kernel)
+            b = x.shape[0]
+            seq = PeriodFoldFn.apply(x, self.period)
             args = []
             for conv in list(self.convs) + [self.conv_post]:
                 args += [conv.weight_v, conv.weight_g, conv.bias]
@@ -79,6 +75,12 @@ class DiscriminatorP(nn.Module):
                 return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
             y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
             return s.view(b, -1), [y2, y3, y4, y5, s]
+        x = x.unsqueeze(1)
+        b, c, t = x.shape
+        if t % self.period != 0:
+            n_pad = self.period - (t % self.period)
+            x = F.pad(x, (0, n_pad), "reflect")
+            t = t + n_pad
         # f32 parity mode on the same kernels (split-bf16 products, disc_ops.ConvStackPreciseFn); feature maps come out
         # channels-last, which the (layout-agnostic) mean losses do not care about
         seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)

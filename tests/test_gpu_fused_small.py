@@ -199,3 +199,24 @@ def test_fused_ln_dwconv7_backward_equals_the_two_kernel_path(B, T, C, with_res)
     # input gradient only (frozen parameters)
     dx2 = K.ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, rm, None, None, None, None)
     assert torch.equal(dx2, dx)
+
+
+@pytest.mark.parametrize("period", [2, 3, 5, 7, 11])
+@pytest.mark.parametrize("B,T", [(4, 16384), (3, 1001), (2, 37)])
+def test_period_fold_matches_reflect_pad_and_view(period, B, T):
+    # DiscriminatorP.forward, _discriminators.py:63-72: right reflect pad to a multiple of the period, (b, t/p, p) view
+    import torch.nn.functional as F
+    from optispeech_amd.disc_ops import PeriodFoldFn
+    x = rnd(B, T, seed=period).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    xp = xr.unsqueeze(1)
+    if T % period:
+        xp = F.pad(xp, (0, period - T % period), "reflect")
+    tp = xp.shape[-1]
+    want = xp.view(B, tp // period, period).transpose(1, 2).reshape(B * period, 1, tp // period, 1)
+    got = PeriodFoldFn.apply(x, period)
+    assert torch.equal(got, want)
+    g = rnd(*want.shape, seed=99)
+    want.backward(g)
+    got.backward(g)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=0, atol=1e-6)

@@ -87,6 +87,7 @@ REPLACES = {
     "osp_dwconv_wgrad": "autograd weight / bias gradient of the same depthwise Conv1d",
     "osp_dropout_add": "F.dropout (+ residual add) call sites of the separable-conv layers: modules/layers.py:497-503; backward = the same kernel on the gradient",
     "osp_ln_dwconv7_bwd": "autograd of LayerNorm + depthwise Conv1d(k=7) of ConvNeXtBlock in one pass: generator/modules/convnext.py:36-38 (C <= 256)",
+    "osp_period_fold": "DiscriminatorP.forward reflect pad + (b, t/p, p) view as period-column sequences, and its gradient (backward = 1): vocoder/wavenext/disc/_discriminators.py:63-72",
     "osp_drop_path_rows": "DropPath factors of all blocks of a ConvNeXt backbone: generator/modules/convnext.py:121-129 (drop_p_host: plain host array)",
     "osp_segment_starts": "get_random_segments start indices: utils/segments.py:12-38 (caller generator/__init__.py:147-153)",
     "osp_last_error": "error text of the last failing call on this thread",
