@@ -78,22 +78,66 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
     return out
 
 
+_PACK_REG = {}          # (id(param), view key) -> (weakref(param), view key): every pack ever asked for through _param_pack
+
+
 def _param_pack(p, w, n_out, taps, cin, w_strides):
     """(n_out, taps, cin) bf16 pack of the view ``w`` of Parameter ``p`` (element strides ``w_strides``), cached on ``p`` with the
-    invalidation rule of param_bf16: optimizer epoch, in-place version, storage address."""
+    invalidation rule of param_bf16: optimizer epoch, in-place version, storage address.  A miss refreshes EVERY registered pack
+    that is stale (all of them after an optimizer step) in one multi launch instead of one launch per weight and view."""
+    import weakref
     from . import values
+    key = (w.data_ptr() - p.data_ptr(), n_out, taps, cin, tuple(w_strides))
+    rk = (id(p), key)
+    if rk not in _PACK_REG:
+        _PACK_REG[rk] = (weakref.ref(p), key)
     stamp = (values.param_epoch(), p._version, p.data_ptr())
     cache = getattr(p, "_osp_packs", None)
-    if cache is None or cache[0] != stamp:
-        cache = (stamp, {})
-        p._osp_packs = cache
-    key = (w.data_ptr() - p.data_ptr(), n_out, taps, cin, tuple(w_strides))
-    wp = cache[1].get(key)
-    if wp is None:
+    if cache is not None and cache[0] == stamp:
+        wp = cache[1].get(key)
+        if wp is not None:
+            return wp
+    if p.is_cuda and torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture: this view only, on the single-tensor kernel (the capture of the segmented step did not survive
+        # the batched launch here; the eager step is where the launch count matters)
+        if cache is None or cache[0] != stamp:
+            cache = (stamp, {})
+            p._osp_packs = cache
         wp = torch.empty((n_out, taps, cin), device=w.device, dtype=torch.bfloat16)
         call("osp_pack_bf16", w, None, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
         cache[1][key] = wp
-    return wp
+        return wp
+    import numpy as np
+    rows, fills, dead = [], [], []
+    epoch = values.param_epoch()
+    # only parameters of the SAME flat arena (= the same model's optimizer group) are refreshed together: a captured graph must
+    # not read another model's weights (they may be freed while the graph lives); a parameter outside any arena is packed alone
+    arena = getattr(p, "_osp_arena", (None,))[0]               # (FlatArena, offset) set by optim.FlatArena
+    for rk2, (ref, k2) in _PACK_REG.items():
+        q = ref()
+        if q is None:
+            dead.append(rk2)
+            continue
+        if q is not p and (arena is None or getattr(q, "_osp_arena", (None,))[0] is not arena):
+            continue
+        st = (epoch, q._version, q.data_ptr())
+        c2 = getattr(q, "_osp_packs", None)
+        if c2 is None or c2[0] != st:
+            c2 = (st, {})
+            q._osp_packs = c2
+        if k2 in c2[1]:
+            continue
+        off, n2, t2, c_in, strd = k2
+        out = torch.empty((n2, t2, c_in), device=q.device, dtype=torch.bfloat16)
+        rows.append([q.data_ptr() + off, 0, out.data_ptr(), n2, t2, c_in, strd[0], strd[1], strd[2], 0])
+        fills.append((c2[1], k2, out))
+    for rk2 in dead:
+        del _PACK_REG[rk2]
+    d = np.asarray(rows, dtype=np.int64)
+    call("osp_pack_bf16_multi", d.ctypes.data, len(rows))
+    for dct, k2, out in fills:
+        dct[k2] = out
+    return p._osp_packs[1][key]
 
 
 _WGRAD_BF16_MIN_M = int(__import__('os').environ.get('OSP_WGRAD_BF16_MIN_M', '2048'))

@@ -60,34 +60,33 @@ class DiscriminatorP(nn.Module):
     def forward(self, x, nograd_head=0):
         """nograd_head = B0 (bf16 mode only): the first B0 waves are a no-grad branch sharing the launches; returns
         ((score, fmap) of the head, (score, fmap) of the rest)."""
-        if precision.is_bf16() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
-            # channels-last sequences (B*period, T/period, 1): every period column is an independent 1-D signal; reflect pad and
-            # folding in one launch (csrc/fused_small.hip: period_fold_kernel)
-            b = x.shape[0]
+        b = x.shape[0]
+        if precision.is_bf16() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and _PERIOD_FOLD:
+            # reflect pad and period folding in one launch (csrc/fused_small.hip: period_fold_kernel)
             seq = PeriodFoldFn.apply(x, self.period)
-            args = []
-            for conv in list(self.convs) + [self.conv_post]:
-                args += [conv.weight_v, conv.weight_g, conv.bias]
-            if nograd_head:
-                self._holder = {}
-                o = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, (self.lrelu_slope, nograd_head * self.period, self._holder), *args)
-                (_, r2, r3, r4, r5, rs), (_, y2, y3, y4, y5, s) = o[:6], o[6:]
-                return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
-            y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
-            return s.view(b, -1), [y2, y3, y4, y5, s]
-        x = x.unsqueeze(1)
-        b, c, t = x.shape
-        if t % self.period != 0:
-            n_pad = self.period - (t % self.period)
-            x = F.pad(x, (0, n_pad), "reflect")
-            t = t + n_pad
-        # f32 parity mode on the same kernels (split-bf16 products, disc_ops.ConvStackPreciseFn); feature maps come out
-        # channels-last, which the (layout-agnostic) mean losses do not care about
-        seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1)
+        else:
+            x = x.unsqueeze(1)
+            b, c, t = x.shape
+            if t % self.period != 0:
+                n_pad = self.period - (t % self.period)
+                x = F.pad(x, (0, n_pad), "reflect")
+                t = t + n_pad
+            seq = x.view(b, t // self.period, self.period).transpose(1, 2).reshape(b * self.period, 1, t // self.period, 1).contiguous()
+        # channels-last sequences (B*period, T/period, 1): every period column is an independent 1-D signal
         args = []
         for conv in list(self.convs) + [self.conv_post]:
             args += [conv.weight_v, conv.weight_g, conv.bias]
-        y1, y2, y3, y4, y5, s = ConvStackPreciseFn.apply(seq.contiguous(), MPD_SPEC, self.lrelu_slope, *args)
+        if precision.is_bf16():
+            if nograd_head:
+                self._holder = {}
+                o = ConvStackFn.apply(seq, MPD_SPEC, (self.lrelu_slope, nograd_head * self.period, self._holder), *args)
+                (_, r2, r3, r4, r5, rs), (_, y2, y3, y4, y5, s) = o[:6], o[6:]
+                return (rs.reshape(nograd_head, -1), [r2, r3, r4, r5, rs]), (s.reshape(b - nograd_head, -1), [y2, y3, y4, y5, s])
+            y1, y2, y3, y4, y5, s = ConvStackFn.apply(seq, MPD_SPEC, self.lrelu_slope, *args)
+            return s.view(b, -1), [y2, y3, y4, y5, s]
+        # f32 parity mode on the same kernels (split-bf16 products, disc_ops.ConvStackPreciseFn); feature maps come out
+        # channels-last, which the (layout-agnostic) mean losses do not care about
+        y1, y2, y3, y4, y5, s = ConvStackPreciseFn.apply(seq, MPD_SPEC, self.lrelu_slope, *args)
         return s.view(b, -1), [y2, y3, y4, y5, s]
 
 
@@ -229,6 +228,7 @@ class _Multi(nn.Module):
 
 
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
+_PERIOD_FOLD = os.environ.get("OSP_PERIOD_FOLD", "1") != "0"
 #: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
 _FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"
 _STREAMS = {}

@@ -53,6 +53,10 @@ class side_wgrad:
     def __enter__(self):
         if not _WG["on"] or not self.tensors or not self.tensors[0].is_cuda:
             return self
+        if torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture the launches stay inline: the runtime executes a captured fork almost serially anyway
+            # (DESIGN.md section 10), and ending the capture of the segmented step with such a fork in it crashed the runtime
+            return self
         if not _WG["queued"]:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad)
