@@ -81,6 +81,9 @@ class _Lib:
         return f
 
     def call(self, name, *args):
+        if _RECORD[0] is not None:                     # ops.side_wgrad: the launch is deferred to the next flush onto the side stream
+            _RECORD[0].append((name, args))
+            return
         # hot path (~850 calls per training step): keep the per-argument work minimal.  ctypes converts ints / floats /
         # None through the header-derived argtypes; tensors are passed as their device address.
         idx = self._fidx.get(name)
@@ -95,7 +98,7 @@ class _Lib:
                                        "call torch.cuda.set_device() (or wrap the call in torch.cuda.device(...))")
                     break
         if idx is not None:
-            rc = self._fcall(idx, _raw_stream(dev), *args)
+            rc = self._fcall(idx, _STREAM_OVERRIDE[0] or _raw_stream(dev), *args)
             if rc != 0:
                 raise OspError(f"{name} failed ({rc}): {self.cdll.osp_last_error().decode()}")
             return
@@ -104,7 +107,7 @@ class _Lib:
         cargs = [a.data_ptr() if isinstance(a, T) else a for a in args]
         if _GUARD and any(isinstance(a, T) and not a.is_cuda for a in args):
             raise OspError(f"{name}: tensor argument is not on the GPU")
-        cargs.append(_raw_stream(dev))      # torch's current HIP stream (raw handle)
+        cargs.append(_STREAM_OVERRIDE[0] or _raw_stream(dev))      # torch's current HIP stream (raw handle)
         try:
             rc = f(*cargs)
         except ctypes.ArgumentError as e:
@@ -121,6 +124,11 @@ class _Lib:
 
 #: reject host tensors before launching (a host pointer would fault on the device); OSP_FAST_CALL=1 drops the check
 _GUARD = os.environ.get("OSP_FAST_CALL", "0") != "1"
+#: raw hipStream_t that replaces "torch's current stream" for the launches of a region (ops.side_wgrad: weight-gradient kernels on
+#: a side stream without switching torch's current stream -- no torch op runs inside such a region); None = off
+_STREAM_OVERRIDE = [None]
+#: list that collects (entry point, arguments) instead of launching (ops.side_wgrad defers weight-gradient launches); None = off
+_RECORD = [None]
 _raw_stream = torch._C._cuda_getCurrentRawStream
 _cur_device = torch._C._cuda_getDevice
 
