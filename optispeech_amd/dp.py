@@ -149,10 +149,15 @@ class GradReducer:
         self._covered.clear()
 
     def wait(self):
+        had = bool(self._pending)
         for w in self._pending:
             w.wait()
         self._pending.clear()
         self._covered.clear()
+        if had and self._drain_first:
+            # gloo on device tensors (single-GPU test aid): its copy back to the device runs on gloo's own stream; drain the device
+            # so that nothing of this step's side streams (weight-gradient stream, discriminator streams) can overtake it
+            torch.cuda.synchronize()
 
     def broadcast_from_rank0(self, tensors):
         """Make every replica start from rank 0's values (parameter arenas, buffers)."""
