@@ -110,6 +110,7 @@ class GradReducer:
             return
         if self._drain_first and flat_grad.is_cuda:
             torch.cuda.synchronize()
+            self._device_work = True
         n = flat_grad.numel()
         if self.native:
             from ._lib import call
@@ -154,7 +155,8 @@ class GradReducer:
             w.wait()
         self._pending.clear()
         self._covered.clear()
-        if had and self._drain_first:
+        if had and self._drain_first and getattr(self, "_device_work", False):
+            self._device_work = False
             # gloo on device tensors (single-GPU test aid): its copy back to the device runs on gloo's own stream; drain the device
             # so that nothing of this step's side streams (weight-gradient stream, discriminator streams) can overtake it
             torch.cuda.synchronize()
