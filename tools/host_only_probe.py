@@ -21,3 +21,12 @@ for rep in range(3):
     torch.cuda.synchronize()
     tt = time.perf_counter() - t0
     print(f"host enqueue {th/n*1e3:.2f} ms/step, wall {tt/n*1e3:.2f} ms/step (B=2: GPU work negligible)")
+import gc
+gc.collect(); gc.freeze(); gc.disable()
+for rep in range(3):
+    t0 = time.perf_counter(); n = 20
+    for i in range(n):
+        m.training_step(batch, 100 + i)
+    th = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    print(f"gc off: host enqueue {th/n*1e3:.2f} ms/step")
