@@ -109,8 +109,16 @@ class GradReducer:
         if not self.active:
             return
         if self._drain_first and flat_grad.is_cuda:
+            # gloo on device tensors = the single-GPU test aid (OSP_DP_BACKEND=gloo).  The buffer is staged through the host HERE,
+            # synchronously: gloo's own device path (private streams, worker threads) produced rare wrong slices (1e-3 of a
+            # sub-discriminator's gradients, replicas still identical) when the two ranks shared one GPU, while the same step is
+            # reproducible to 1e-7 run to run in one process (tools/determinism_probe.py, also under contention).
             torch.cuda.synchronize()
-            self._device_work = True
+            host = flat_grad.detach().to("cpu")
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.copy_(host)
+            torch.cuda.synchronize()
+            return
         n = flat_grad.numel()
         if self.native:
             from ._lib import call
@@ -150,16 +158,10 @@ class GradReducer:
         self._covered.clear()
 
     def wait(self):
-        had = bool(self._pending)
         for w in self._pending:
             w.wait()
         self._pending.clear()
         self._covered.clear()
-        if had and self._drain_first and getattr(self, "_device_work", False):
-            self._device_work = False
-            # gloo on device tensors (single-GPU test aid): its copy back to the device runs on gloo's own stream; drain the device
-            # so that nothing of this step's side streams (weight-gradient stream, discriminator streams) can overtake it
-            torch.cuda.synchronize()
 
     def broadcast_from_rank0(self, tensors):
         """Make every replica start from rank 0's values (parameter arenas, buffers)."""

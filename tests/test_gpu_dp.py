@@ -99,6 +99,10 @@ def _worker(rank, world, port, graph, q):
             got = o.arena.grad.detach() / world
             err = ((got - mean).norm() / mean.norm()).item()
             msgs.append(f"{name}: |sum/world - mean of single-rank grads| / |mean| = {err:.2e}")
+            if err >= 6e-4:                               # where: one contiguous slice (a collective / range problem) or scattered?
+                bad = ((got - mean).abs() > 1e-4 * mean.abs().max()).nonzero().flatten()
+                msgs.append(f"{name}: {bad.numel()} of {got.numel()} elements off, index range [{int(bad.min()) if bad.numel() else -1}, "
+                            f"{int(bad.max()) if bad.numel() else -1}], got/mean norm ratio {(got.norm() / mean.norm()).item():.6f}")
             # two runs of the SAME step differ by the f32-atomic order of the split-K weight gradients (observed up to 2.5e-4 on the
             # discriminator arena); a missing / doubled contribution would show as O(1)
             ok = ok and err < 6e-4
