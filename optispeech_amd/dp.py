@@ -120,6 +120,12 @@ class GradReducer:
             torch.cuda.synchronize()
             return
         n = flat_grad.numel()
+        if flat_grad.is_cuda:
+            # weight-gradient kernels of a running backward pass may still be queued on ops.side_wgrad's streams, which the
+            # calling stream only joins at the end of that pass: a gradient-ready collective issued from inside it waits here
+            from .ops import wgrad_side_streams
+            for s in wgrad_side_streams():
+                torch.cuda.current_stream().wait_stream(s)
         if self.native:
             from ._lib import call
             cs = _native["stream"]

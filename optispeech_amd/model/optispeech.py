@@ -56,6 +56,9 @@ def default_args(batch_size=32, feature_extractor=None):
     return train_args, data_args, inference_args
 
 
+_SYNC_AFTER_G = __import__("os").environ.get("OSP_SYNC_AFTER_G", "0") == "1"
+
+
 class OptiSpeech(nn.Module):
     def __init__(self, dim, generator, vocoder, discriminator, train_args, data_args, inference_args, optimizer=None,
                  scheduler=None):
@@ -246,6 +249,8 @@ class OptiSpeech(nn.Module):
             self.optimizers()[0].zero_grad()
         (st.loss_g / st.scale).backward()
         st.loss_g = None
+        if _SYNC_AFTER_G:                                  # diagnostic (tools/race2.sh): drain the device between the phases
+            torch.cuda.synchronize()
 
     def _stage_d(self, st, batch):
         for p in self._disc_params():

@@ -33,8 +33,29 @@ def _want(p):
 # otherwise hand their memory to the next kernel of the calling stream while the side stream still reads it).
 import os as _os
 
-_WG = {"on": _os.environ.get("OSP_WGRAD_STREAM", "1") != "0", "sides": {}, "used": [], "queued": False, "events": [], "ev": 0,
-       "pending": [], "regions": 0, "every": int(_os.environ.get("OSP_WGRAD_FLUSH", "1"))}
+_WG = {"on": _os.environ.get("OSP_WGRAD_STREAM", "1") != "0", "sides": {}, "used": [], "queued": False, "pending": [], "done": [],
+       "regions": 0, "every": int(_os.environ.get("OSP_WGRAD_FLUSH", "1"))}
+
+
+class _Side:
+    """The weight-gradient stream of one calling stream, with its own hand-over events.  An event is only ever re-recorded on
+    the SAME calling stream and only in a later backward pass (``pos`` restarts at the join): a global ring shared by all calling
+    streams re-recorded events of the vocoder stream on the main stream a few hand-overs later, and with two processes on one
+    GPU the vocoder's embed / head weight gradients then came out wrong (1e-3 .. 3e-1) in ~20 % of the runs of
+    tests/test_gpu_dp.py, never with inline launches or with a fresh event per hand-over."""
+    __slots__ = ("stream", "raw", "events", "pos")
+
+    def __init__(self, dev):
+        self.stream = torch.cuda.Stream(device=dev)
+        self.raw = self.stream.cuda_stream
+        self.events, self.pos = [], 0
+
+    def next_event(self):
+        if self.pos == len(self.events):
+            self.events.append(torch.cuda.Event())
+        ev = self.events[self.pos]
+        self.pos += 1
+        return ev
 
 
 def _flush_wgrad():
@@ -45,22 +66,16 @@ def _flush_wgrad():
         return
     dev = torch.cuda.current_device()
     raw = _lib._raw_stream(dev)
-    hit = _WG["sides"].get((dev, raw))
-    if hit is None:
-        side = torch.cuda.Stream(device=dev)
-        hit = _WG["sides"][(dev, raw)] = (side, side.cuda_stream)
-    side, side_raw = hit
+    side = _WG["sides"].get((dev, raw))
+    if side is None:
+        side = _WG["sides"][(dev, raw)] = _Side(dev)
     if side not in _WG["used"]:
         _WG["used"].append(side)
-    evs = _WG["events"]
-    if len(evs) < 32:
-        evs.append(torch.cuda.Event())
-    ev = evs[_WG["ev"] % len(evs)]
-    _WG["ev"] += 1
+    ev = side.next_event()
     ev.record()                                                    # on the current stream: everything the operands depend on
-    side.wait_event(ev)
+    side.stream.wait_event(ev)
     lib = _lib.lib()
-    _lib._STREAM_OVERRIDE[0] = side_raw
+    _lib._STREAM_OVERRIDE[0] = side.raw
     try:
         for name, args in pend:
             lib.call(name, *args)
@@ -68,7 +83,7 @@ def _flush_wgrad():
         _lib._STREAM_OVERRIDE[0] = None
     # the argument tuples held the operands alive until here; from now on the side stream's queue order does: the join below
     # makes the calling stream wait before anything can reuse their memory (the list is cleared only after that wait is queued)
-    _WG["done"] = _WG.get("done", []) + [pend]
+    _WG["done"].append(pend)
     _WG["pending"] = []
 
 
@@ -76,8 +91,15 @@ def _join_wgrad():
     _flush_wgrad()
     cur = torch.cuda.current_stream()
     for side in _WG["used"]:
-        cur.wait_stream(side)
+        cur.wait_stream(side.stream)
+        side.pos = 0
     _WG["used"], _WG["queued"], _WG["done"] = [], False, []
+
+
+def wgrad_side_streams():
+    """Side streams with weight-gradient work of the running backward pass in flight (dp.GradReducer orders a gradient-ready
+    collective behind them: the ready signal comes from the calling stream, which does not wait for them before the join)."""
+    return [s.stream for s in _WG["used"]]
 
 
 class side_wgrad:

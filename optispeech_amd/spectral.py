@@ -12,13 +12,23 @@ from ._lib import call
 _TW = {}
 
 
+def _publish(t):
+    """A table filled on the CURRENT stream is about to be cached for every stream (the sub-discriminators, the spectral losses
+    and the vocoder each run on their own): finish the fill before anyone can find it.  Once per table and process.  (Found as a
+    first-step-only 2e-3 error in one resolution discriminator's gradients when two processes shared a GPU: another stream read
+    the n_fft = 2048 twiddles while the kernel that writes them was still queued.)"""
+    if t.is_cuda and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 def _twiddles(n_fft, device):
     key = (n_fft, str(device))
     t = _TW.get(key)
     if t is None:
         t = torch.empty((n_fft, 2), device=device, dtype=torch.float32)
         call("osp_fft_twiddles", t, n_fft)
-        _TW[key] = t
+        _TW[key] = _publish(t)
     return t
 
 
@@ -34,7 +44,7 @@ def _padded_window(window, n_fft):
     key = (n_fft, window._version, window.data_ptr())
     if hit is None or hit[0] != key:
         left = (n_fft - wl) // 2
-        hit = (key, F.pad(window.detach(), (left, n_fft - wl - left)).contiguous())
+        hit = (key, _publish(F.pad(window.detach(), (left, n_fft - wl - left)).contiguous()))
         try:
             window._osp_padded = hit
         except (AttributeError, RuntimeError):
