@@ -305,6 +305,12 @@ def main():
     dev = torch.device("cuda", local)
     from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
 
+    if os.environ.get("OSP_GC_OFF", "0") == "1":              # experiment: no cyclic-GC passes inside the step loop
+        import gc
+        gc.collect()
+        gc.disable()
+    if os.environ.get("OSP_AUTOGRAD_ST", "0") == "1":         # experiment: backward on the calling thread (no device worker thread)
+        torch.autograd.set_multithreading_enabled(False)
     torch.manual_seed(1234)                                   # configs/train.yaml:53; same init on every rank
     rng.manual_seed(1234, rank)
     cfg = ModelConfig(backbone=a.backbone)
