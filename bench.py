@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-am-only", action="store_true", help="skip the acoustic-model-only (pre-training regime) step timing")
     ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
     ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=1, help="timed CPU-baseline steps (after one warm step)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm step); the default sample is ~12 s of CPU work")
     ap.add_argument("--cpu-threads", type=str, default="8,32",
                     help="thread counts tried for the CPU baseline (the best one is reported as `value`, the 8-thread figure beside it)")
     ap.add_argument("--cpu-full", action="store_true",

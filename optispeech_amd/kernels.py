@@ -43,7 +43,8 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
     if w_strides is None:
         w_strides = (taps * cin, cin, 1)
     if out is None:
-        shape = (batch, M, n_out) if batch > 1 else (M, n_out)
+        # a batched caller (3-D operand) gets a 3-D result also when its batch happens to be 1 (a batch of one utterance)
+        shape = (batch, M, n_out) if (batch > 1 or a.dim() == 3) else (M, n_out)
         out = torch.empty(shape, device=a.device, dtype=torch.float32)
     if _precision.is_bf16() and M * n_out * cin * taps >= (1 << 22) and n_out >= 32:
         # performance mode: same contraction on the bf16 MFMA kernel (f32 storage, converted while staging)

@@ -1,0 +1,128 @@
+"""Edge cases of the training forward against the CPU oracle (the cases the reference's own tests and code paths single out:
+tests/test_model.py runs batches of 1; generator/__init__.py:147 clamps the segment to the utterance; utils/segments.py:29-31
+clamps the start range at zero; ragged batches with one very short and one full-length utterance).  f32 mode, same weights and
+inputs on both sides; indices (MAS durations, segment starts) bit-exact, loss to 1e-4, waveform to 1e-3 of scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_weights(batch_size):
+    from oracle import schema as S
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_optispeech
+    precision.set_precision("f32")
+    c = S.SMALL
+    cfg = ModelConfig(dim=c.dim, enc_inter=c.enc_inter, dec_inter=c.dec_inter, dur=c.dur + (0.0,), pitch=c.pitch + (0.0,),
+                      energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers).no_dropout()
+    model = make_optispeech(cfg, batch_size=batch_size, pretraining_steps=0).to("cuda").train()
+    W = S.make_weights(S.generator_schema(S.SMALL), 77)
+    model.generator.load_state_dict({k[len("generator."):]: v for k, v in W.items()})
+    return cfg, model, W
+
+
+def _set_lengths(batch, x_len, m_len, hop):
+    """Re-mask a synthetic batch to the given text / mel lengths (the collate's zero padding)."""
+    x_len, m_len = torch.tensor(x_len), torch.tensor(m_len)
+    Tt, Tm = batch["x"].shape[1], batch["mel"].shape[2]
+    xv = torch.arange(Tt)[None] < x_len[:, None]
+    mv = torch.arange(Tm)[None] < m_len[:, None]
+    batch = dict(batch)
+    batch["x"] = torch.where(xv, batch["x"].clamp(min=1), torch.zeros_like(batch["x"]))
+    batch["mel"] = batch["mel"] * mv[:, None, :]
+    batch["pitches"], batch["energies"] = batch["pitches"] * mv, batch["energies"] * mv
+    batch["x_lengths"], batch["mel_lengths"], batch["wav_lengths"] = x_len, m_len, m_len * hop
+    return batch
+
+
+def _compare(model, W, batch, rand01):
+    from oracle import generator as OG
+    model.generator.segment_rand01 = rand01
+    want = OG.generator_forward({k: v.clone() for k, v in W.items()}, batch, rand01=rand01, keep=True)
+    dbatch = {k: (v.to("cuda") if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = model._process_batch(dbatch)
+    assert np.array_equal(out["_aux"]["durations"].cpu().numpy(), want["durations"].numpy()), "MAS durations differ"
+    assert np.array_equal(out["start_idx"].cpu().numpy(), want["start_idx"].numpy()), "segment starts differ"
+    assert out["wav_hat"].shape == want["wav_hat"].shape
+    got, ref = out["loss"].detach().item(), want["loss"].detach().item()
+    assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)
+    werr = ((out["wav_hat"].detach().cpu() - want["wav_hat"].detach()).abs().max() / want["wav_hat"].detach().abs().max()).item()
+    assert werr < 1e-3, werr
+    # and the whole GAN step runs on such a batch (discriminator STFTs need wav longer than n_fft / 2)
+    model.training_step(dbatch, 0)
+    logs = model.fetch_logs()
+    assert all(np.isfinite(v) for v in logs.values()), logs
+    return out, want
+
+
+def test_batch_of_one_utterance():
+    from optispeech_amd.config import synthetic_batch
+    cfg, model, W = _model_and_weights(1)
+    batch = synthetic_batch(1, 17, 90, cfg, seed=21, ragged=False)
+    _compare(model, W, batch, torch.tensor([0.55]))
+
+
+def test_utterances_shorter_than_the_segment():
+    """T_mel (40) < segment_size (64): the segment is the whole utterance (generator/__init__.py:147) and every start index
+    clamps to 0 (utils/segments.py:29-31); one utterance of the batch is shorter still."""
+    from oracle import schema as S
+    from optispeech_amd.config import synthetic_batch
+    cfg, model, W = _model_and_weights(2)
+    assert S.SMALL.segment_size > 40
+    batch = _set_lengths(synthetic_batch(2, 12, 40, cfg, seed=22), [12, 7], [40, 23], cfg.fe.hop_length)
+    out, want = _compare(model, W, batch, torch.tensor([0.9, 0.9]))
+    assert int(out["segment_size"]) == 40 and int(out["start_idx"].abs().sum()) == 0
+
+
+def test_one_tiny_and_one_full_length_utterance():
+    """Extreme raggedness: 3 tokens / 9 frames next to 30 tokens / 130 frames; the short one's start range (len - 4 - segment)
+    is negative and clamps to 0, the long one's does not."""
+    from optispeech_amd.config import synthetic_batch
+    cfg, model, W = _model_and_weights(2)
+    batch = _set_lengths(synthetic_batch(2, 30, 130, cfg, seed=23), [30, 3], [130, 9], cfg.fe.hop_length)
+    out, want = _compare(model, W, batch, torch.tensor([0.8, 0.8]))
+    s = out["start_idx"].cpu()
+    assert int(s[1]) == 0 and int(s[0]) > 0
+
+
+def test_text_as_long_as_the_mel():
+    """T_text == T_mel for one utterance: the only monotonic alignment gives every token exactly one frame."""
+    from optispeech_amd.config import synthetic_batch
+    cfg, model, W = _model_and_weights(2)
+    batch = _set_lengths(synthetic_batch(2, 70, 80, cfg, seed=24), [70, 25], [70, 80], cfg.fe.hop_length)
+    out, want = _compare(model, W, batch, torch.tensor([0.1, 0.6]))
+    d = out["_aux"]["durations"].cpu()
+    assert torch.equal(d[0, :70], torch.ones(70, dtype=d.dtype))
+
+
+@pytest.mark.parametrize("graph_decode", [False, True])
+def test_synthesise_one_sentence_vs_oracle(graph_decode):
+    """synthesise() on ONE sentence (the everyday inference call; generator/__init__.py:194-301): durations bit-exact, pitch /
+    energy / waveform to 1e-3, eager and with the decode replayed from hipGraphs."""
+    from oracle import generator as OG
+    from oracle import schema as S
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_generator
+    precision.set_precision("f32")
+    c = S.SMALL
+    cfg = ModelConfig(dim=c.dim, enc_inter=c.enc_inter, dec_inter=c.dec_inter, dur=c.dur + (0.0,), pitch=c.pitch + (0.0,),
+                      energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers).no_dropout()
+    gen = make_generator(cfg).to("cuda").eval()
+    W = S.make_weights(S.generator_schema(S.SMALL), 31)
+    W["generator.duration_predictor.linear.bias"].fill_(1.2)                 # durations of a few frames per token
+    gen.load_state_dict({k[len("generator."):]: v for k, v in W.items()})
+    gen.graph_decode = graph_decode
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(1, 159, (1, 19), generator=g)
+    x_len = torch.tensor([19])
+    want = OG.synthesise({k: v.clone() for k, v in W.items()}, x, x_len, d_factor=0.9, p_factor=1.3, e_factor=0.8)
+    for _ in range(2):                                                       # second call: the captured graphs are replayed
+        out = gen.synthesise(x.to("cuda"), x_len, d_factor=0.9, p_factor=1.3, e_factor=0.8)
+        assert np.array_equal(out["durations"].cpu().numpy(), want["durations"].numpy())
+        assert np.array_equal(out["wav_lengths"].cpu().numpy(), want["wav_lengths"].numpy())
+        for k in ("pitch", "energy", "wav"):
+            a, b = out[k].detach().float().cpu(), want[k].detach().float()
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            assert ((a - b).abs().max() / b.abs().max()).item() < 1e-3, k
