@@ -126,3 +126,37 @@ def test_synthesise_one_sentence_vs_oracle(graph_decode):
             a, b = out[k].detach().float().cpu(), want[k].detach().float()
             assert a.shape == b.shape, (k, a.shape, b.shape)
             assert ((a - b).abs().max() / b.abs().max()).item() < 1e-3, k
+
+
+@pytest.mark.parametrize("case", ["one", "short", "tiny+full"])
+def test_edge_batches_in_bf16_mode_keep_the_indices_exact(case):
+    """The benchmarked (bf16) mode on the same edge batches: everything the discrete alignment depends on runs in exact f32 in
+    every mode (precision.index_path), so MAS durations and segment starts stay bit-exact against the oracle; the acoustic
+    loss agrees to 2e-2 (bf16 products in the predictors / decoder), and the whole GAN step is finite."""
+    from oracle import generator as OG
+    from optispeech_amd import precision
+    from optispeech_amd.config import synthetic_batch
+    B = 1 if case == "one" else 2
+    cfg, model, W = _model_and_weights(B)
+    precision.set_precision("bf16")
+    try:
+        if case == "one":
+            batch, r = synthetic_batch(1, 17, 90, cfg, seed=21), torch.tensor([0.55])
+        elif case == "short":
+            batch, r = _set_lengths(synthetic_batch(2, 12, 40, cfg, seed=22), [12, 7], [40, 23], cfg.fe.hop_length), torch.tensor([0.9, 0.9])
+        else:
+            batch, r = _set_lengths(synthetic_batch(2, 30, 130, cfg, seed=23), [30, 3], [130, 9], cfg.fe.hop_length), torch.tensor([0.8, 0.8])
+        model.generator.segment_rand01 = r
+        want = OG.generator_forward({k: v.clone() for k, v in W.items()}, batch, rand01=r, keep=True)
+        dbatch = {k: (v.to("cuda") if torch.is_tensor(v) else v) for k, v in batch.items()}
+        out = model._process_batch(dbatch)
+        assert np.array_equal(out["_aux"]["durations"].cpu().numpy(), want["durations"].numpy())
+        assert np.array_equal(out["start_idx"].cpu().numpy(), want["start_idx"].numpy())
+        got, ref = out["loss"].detach().item(), want["loss"].detach().item()
+        assert abs(got - ref) <= 2e-2 * abs(ref), (got, ref)
+        model.training_step(dbatch, 0)
+        model.training_step(dbatch, 1)
+        logs = model.fetch_logs()
+        assert all(np.isfinite(v) for v in logs.values()), logs
+    finally:
+        precision.set_precision("f32")
