@@ -160,3 +160,42 @@ def test_edge_batches_in_bf16_mode_keep_the_indices_exact(case):
         assert all(np.isfinite(v) for v in logs.values()), logs
     finally:
         precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("precision_mode", ["f32", "bf16"])
+@pytest.mark.parametrize("backbone", ["convnext", "transformer", "lightspeech", "leanspeech", "conformer"])
+def test_every_backbone_handles_a_batch_of_one(backbone, precision_mode):
+    """One utterance per step and one sentence per synthesise() call through every backbone pair (full-size default config of
+    each): finite losses, a waveform of the predicted length; the row of a two-utterance batch equals the same utterance run
+    alone (batch rows are independent) for the acoustic-model outputs."""
+    from optispeech_amd import precision, rng
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    from optispeech_amd.values import InferenceInputs
+    precision.set_precision(precision_mode)
+    try:
+        torch.manual_seed(4)
+        rng.manual_seed(4, 0)
+        cfg = ModelConfig(backbone=backbone).no_dropout()
+        m = make_optispeech(cfg, batch_size=1, pretraining_steps=0).to("cuda").train()
+        batch = synthetic_batch(1, 21, 70, cfg, seed=6, device="cuda")
+        m.training_step(batch, 0)
+        logs = m.fetch_logs()
+        assert all(np.isfinite(v) for v in logs.values()), logs
+        m.eval()
+        x2 = torch.randint(1, 150, (2, 16))
+        xl2 = torch.tensor([16, 11])
+        x2 = x2 * (torch.arange(16)[None] < xl2[:, None])
+        dur = torch.full((2, 16), 3)
+        both = m.synthesise(InferenceInputs(clean_text="", x=x2, x_lengths=xl2, d_factor=1.0, p_factor=1.0, e_factor=1.0),
+                            durations_override=dur)
+        one = m.synthesise(InferenceInputs(clean_text="", x=x2[:1], x_lengths=xl2[:1], d_factor=1.0, p_factor=1.0, e_factor=1.0),
+                           durations_override=dur[:1])
+        w1, w2 = torch.as_tensor(one.wav).float().cpu(), torch.as_tensor(both.wav).float().cpu()
+        assert w1.shape[0] == 1 and torch.isfinite(w1).all()
+        n = int(torch.as_tensor(one.wav_lengths).reshape(-1)[0])
+        assert n == 16 * 3 * cfg.fe.hop_length
+        tol = 2e-3 if precision_mode == "f32" else 5e-2
+        err = ((w1[0, :n] - w2[0, :n]).abs().max() / w2[0, :n].abs().max()).item()
+        assert err < tol, err
+    finally:
+        precision.set_precision("f32")
