@@ -199,3 +199,47 @@ def test_every_backbone_handles_a_batch_of_one(backbone, precision_mode):
         assert err < tol, err
     finally:
         precision.set_precision("f32")
+
+
+def test_gradient_accumulate_batches_follows_the_reference_schedule():
+    """train_args.gradient_accumulate_batches = 2 (base_lightning_module.py:80-86): losses are divided by 2, the optimisers step
+    on every second batch only -- and, exactly as the reference does (:95-97, :115-117: ``zero_grad()`` sits immediately before
+    the backward of the APPLYING batch), the update consumes that batch's gradient / 2; what the first batch of the pair left
+    in ``.grad`` is cleared unseen.  Pinned here so that the quirk stays a decision, not an accident."""
+    from tests.test_gpu_dp import _batches, _build, _grads_of_one_step
+    from optispeech_amd import precision
+    precision.set_precision("f32")
+    cfg, ref = _build(7)
+    batches = _batches(cfg)
+    ref.optimizers()
+    singles = [_grads_of_one_step(ref, b, r01) for b, r01 in batches]
+    cfg, m = _build(7)
+    m.train_args.gradient_accumulate_batches = 2
+    og, od = m.optimizers()
+    w0 = [o.arena.data.clone() for o in (og, od)]
+    seen = {}
+    for name, o in (("g", og), ("d", od)):
+        def step(*a, _n=name, _o=o, _orig=o.step, **k):
+            seen.setdefault(_n, []).append(_o.arena.grad.detach().clone())
+            return _orig(*a, **k)
+        o.step = step
+    for sch in m.lr_schedulers():
+        sch.warmup = 0
+        sch.opt.lr = sch.base_lr
+    (b0, r0), (b1, r1) = batches
+    m.generator.segment_rand01 = r0
+    m.training_step(b0, 0)
+    torch.cuda.synchronize()
+    assert not seen and all(torch.equal(o.arena.data, w) for o, w in zip((og, od), w0)), "an optimiser stepped on batch 0 of 2"
+    assert m.global_step == 0
+    m.generator.segment_rand01 = r1
+    m.training_step(b1, 1)
+    torch.cuda.synchronize()
+    assert len(seen["g"]) == 1 and len(seen["d"]) == 1
+    for i, name in enumerate(("g", "d")):
+        want = singles[1][i] / 2
+        err = ((seen[name][0] - want).norm() / want.norm()).item()
+        assert err < 1e-5, (name, err)
+    assert all(not torch.equal(o.arena.data, w) for o, w in zip((og, od), w0))
+    logs = m.fetch_logs()
+    assert all(np.isfinite(v) for v in logs.values())
