@@ -193,7 +193,8 @@ class OptiSpeech(nn.Module):
         which removes the ~20 ms of Python / autograd / dispatch time per step that bound the eager step."""
         ta = self.train_args
         accum = ta.gradient_accumulate_batches
-        if self.graph_steps and accum is None and torch.is_tensor(batch.get("x")) and self.device.type == "cuda":
+        if (self.graph_steps and accum is None and torch.is_tensor(batch.get("x")) and self.device.type == "cuda"
+                and ta.cache_generator_outputs):
             from ..graphs import graphed_training_step
             return graphed_training_step(self, batch, batch_idx)
         st = self._new_step_state(batch_idx)
@@ -213,7 +214,14 @@ class OptiSpeech(nn.Module):
         # updated generator weights, not the discriminator's) overlaps this step's discriminator backward.  The
         # discriminator stream is joined before anything reads discriminator state again (training_step_g, fetch_logs,
         # state_dict, join()).
-        dctx = self._disc_phase_stream() if (st.train_d and self.pipeline_steps) else contextlib.nullcontext()
+        recompute = st.train_d and not ta.cache_generator_outputs
+        if recompute:
+            # cache_generator_outputs: false (base_lightning_module.py:111-113, :165-169): the discriminator phase re-runs the
+            # generator without a tape -- AFTER the generator update (:103), so that update is issued first and the phase
+            # cannot be pipelined behind the next step's generator forward
+            red_g.wait()
+            self._stage_opt_g(st)
+        dctx = self._disc_phase_stream() if (st.train_d and self.pipeline_steps and not recompute) else contextlib.nullcontext()
         if st.train_d:
             with dctx:
                 self._stage_d(st, batch)
@@ -221,8 +229,9 @@ class OptiSpeech(nn.Module):
                 # disc_ops._stack_backward): gradient-ready order, overlapping the other stacks' backward; this adds the rest
                 if st.apply:
                     red_d.start_rest(self.optimizers()[1].arena.grad)
-        red_g.wait()
-        self._stage_opt_g(st)
+        if not recompute:
+            red_g.wait()
+            self._stage_opt_g(st)
         if st.train_d:
             with dctx:
                 red_d.wait()
@@ -240,12 +249,13 @@ class OptiSpeech(nn.Module):
                                pre=None)
 
     def _stage_g_forward(self, st, batch):
+        cached = self.train_args.cache_generator_outputs      # (false: the discriminator phase draws its own segment)
         st.loss_g, (st.wav, st.wav_hat) = self.training_step_g(batch, st.train_d, st.logs,
-                                                               share_real=st.train_d and self.share_real_pass)
+                                                               share_real=st.train_d and self.share_real_pass and cached)
         # the discriminator-phase inputs are fixed from here on: stage them before the generator's backward is queued, so
         # that the discriminator-phase forward (side streams) overlaps that backward (this stream)
         st.pre = (self.discriminator.prepare_disc_inputs(st.wav, st.wav_hat.detach())
-                  if st.train_d and self._real_pass is None else None)
+                  if st.train_d and self._real_pass is None and cached else None)
 
     def _stage_g_backward(self, st):
         if st.apply:
@@ -259,7 +269,14 @@ class OptiSpeech(nn.Module):
     def _stage_d(self, st, batch):
         for p in self._disc_params():
             p.requires_grad_(True)
-        loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre, replay=self.replay_disc_forward)
+        if not self.train_args.cache_generator_outputs:
+            rng.advance()                                      # its own dropout / DropPath masks, as a second forward has
+            with torch.no_grad():                              # :165-169 -- a fresh forward (new segment draw, updated generator)
+                again = self._process_batch(batch)
+            st.wav, st.wav_hat, st.pre = again["wav"], again["wav_hat"], None
+            self._real_pass = None
+        loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre,
+                                      replay=self.replay_disc_forward and self.train_args.cache_generator_outputs)
         if st.apply:
             self.optimizers()[1].zero_grad()
         with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):

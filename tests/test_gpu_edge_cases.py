@@ -243,3 +243,50 @@ def test_gradient_accumulate_batches_follows_the_reference_schedule():
     assert all(not torch.equal(o.arena.data, w) for o, w in zip((og, od), w0))
     logs = m.fetch_logs()
     assert all(np.isfinite(v) for v in logs.values())
+
+
+def test_cache_generator_outputs_false_reruns_the_updated_generator():
+    """train_args.cache_generator_outputs = False (configs/model/optispeech.yaml:12; base_lightning_module.py:111-113,165-169 --
+    the branch of the reference that runs as committed): the discriminator phase sees a fresh no-grad forward of the generator
+    AFTER its update.  Checked by composition: the discriminator gradients of such a step equal those computed by hand from
+    the updated generator of an identical model."""
+    from tests.test_gpu_dp import _batches, _build
+    from optispeech_amd import precision
+    precision.set_precision("f32")
+    models = []
+    for cached in (False, True):
+        cfg, m = _build(7)
+        m.train_args.cache_generator_outputs = cached
+        og, od = m.optimizers()
+        for sch in m.lr_schedulers():
+            sch.warmup = 0
+            sch.opt.lr = sch.base_lr
+        got = {}
+        od.step = (lambda g_, o_: (lambda *a, **k: g_.__setitem__("d", o_.arena.grad.detach().clone())))(got, od)   # capture, no update
+        models.append((m, og, od, got))
+    batch, r01 = _batches(cfg)[0]
+    for m, og, od, got in models:
+        m.generator.segment_rand01 = r01
+        m.training_step(batch, 0)
+        torch.cuda.synchronize()
+    (a, oga, oda, gota), (b, ogb, odb, gotb) = models
+    # (not bit-identical: the split-K weight gradients accumulate with f32 atomics, whose order differs run to run)
+    dg = ((oga.arena.data - ogb.arena.data).norm() / ogb.arena.data.norm()).item()
+    assert dg < 1e-6, f"the generator update must not depend on the flag ({dg:.2e})"
+    # by hand on model b: its generator is updated, its discriminator is not
+    with torch.no_grad():
+        again = b._process_batch(batch)
+    for p in b._disc_params():
+        p.requires_grad_(True)
+    odb.zero_grad()
+    loss = b.training_step_d(batch, (again["wav"], again["wav_hat"].detach()), {})
+    loss.backward()
+    torch.cuda.synchronize()
+    want = odb.arena.grad.detach()
+    err = ((gota["d"] - want).norm() / want.norm()).item()
+    assert err < 2e-5, err
+    cached_err = ((gotb["d"] - want).norm() / want.norm()).item()
+    assert cached_err > 1e-3, "the cached and the re-run discriminator phases should see different generated waves"
+    la, lb = a.fetch_logs(), b.fetch_logs()
+    assert all(np.isfinite(v) for v in la.values())
+    assert abs(la["total_loss/generator"] - lb["total_loss/generator"]) <= 1e-6 * abs(lb["total_loss/generator"])
