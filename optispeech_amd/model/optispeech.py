@@ -356,6 +356,27 @@ class OptiSpeech(nn.Module):
         logs.update({f"discriminator/{k}": v for k, v in log_dict.items()})
         return loss
 
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0, **kwargs):
+        """base_lightning_module.py:195-254 without the third-party perceptual scores (periodicity / UTMOS / PESQ are outside the
+        hot path: their terms are the zeros the reference uses when the evaluate_* flags are off).  Returns the logged dict:
+        total_loss/val_am_loss, gen_subloss/val_*, total_loss/val_gen_adv_loss, gen_adv_loss/val_{mel_loss,mr_stft_loss},
+        total_loss/val_total -- one device->host copy for all of them."""
+        self.join()
+        gen_outputs = self._process_batch(batch)
+        wav, wav_hat = gen_outputs["wav"], gen_outputs["wav_hat"]
+        gen_adv_loss, log_dict = self.discriminator.forward_val(wav, wav_hat)
+        logs = {"total_loss/val_am_loss": gen_outputs["loss"], "gen_subloss/val_alighn_loss": gen_outputs["align_loss"],
+                "gen_subloss/val_duration_loss": gen_outputs["duration_loss"], "gen_subloss/val_pitch_loss": gen_outputs["pitch_loss"],
+                "gen_subloss/val_energy_loss": gen_outputs["energy_loss"], "total_loss/val_gen_adv_loss": gen_adv_loss}
+        logs.update({f"gen_adv_loss/val_{k}": v for k, v in log_dict.items()})
+        logs["total_loss/val_total"] = gen_outputs["loss"] + gen_adv_loss
+        keys = list(logs)
+        packed = torch.stack([logs[k].detach().float().reshape(()) for k in keys])
+        if self._reducers is not None:
+            self._reducers[0].mean_scalars(packed)
+        return dict(zip(keys, packed.cpu().tolist()))
+
     def fetch_logs(self):
         """All logged scalars with ONE device->host copy (and one packed all-reduce under data parallelism)."""
         if not self.last_logs:

@@ -290,3 +290,30 @@ def test_cache_generator_outputs_false_reruns_the_updated_generator():
     la, lb = a.fetch_logs(), b.fetch_logs()
     assert all(np.isfinite(v) for v in la.values())
     assert abs(la["total_loss/generator"] - lb["total_loss/generator"]) <= 1e-6 * abs(lb["total_loss/generator"])
+
+
+def test_validation_step_logs_the_reference_keys_and_matches_the_training_forward():
+    """validation_step (base_lightning_module.py:195-254, perceptual scores excluded): with dropout off the eval-mode forward is
+    the training forward, so its acoustic losses and the mel / multi-resolution STFT terms equal what the training step of
+    the same batch logs from the same weights."""
+    from tests.test_gpu_dp import _batches, _build
+    from optispeech_amd import precision
+    precision.set_precision("f32")
+    cfg, m = _build(7)
+    m.optimizers()
+    batch, r01 = _batches(cfg)[0]
+    m.generator.segment_rand01 = r01
+    val = m.eval().validation_step(batch, 0)
+    assert set(val) == {"total_loss/val_am_loss", "gen_subloss/val_alighn_loss", "gen_subloss/val_duration_loss",
+                        "gen_subloss/val_pitch_loss", "gen_subloss/val_energy_loss", "total_loss/val_gen_adv_loss",
+                        "gen_adv_loss/val_mel_loss", "gen_adv_loss/val_mr_stft_loss", "total_loss/val_total"}
+    m.train().training_step(batch, 0)
+    tr = m.fetch_logs()
+    close = lambda a, b: abs(a - b) <= 1e-5 * max(1.0, abs(b))          # noqa: E731
+    assert close(val["total_loss/val_am_loss"], tr["total_loss/train_am_loss"])
+    for k in ("alighn_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        assert close(val[f"gen_subloss/val_{k}"], tr[f"gen_subloss/train_{k}"]), k
+    for k in ("mel_loss", "mr_stft_loss"):
+        assert close(val[f"gen_adv_loss/val_{k}"], tr[f"gen_adv_loss/train_{k}"]), k
+    assert close(val["total_loss/val_gen_adv_loss"], val["gen_adv_loss/val_mel_loss"] + val["gen_adv_loss/val_mr_stft_loss"])
+    assert close(val["total_loss/val_total"], val["total_loss/val_am_loss"] + val["total_loss/val_gen_adv_loss"])
