@@ -81,10 +81,13 @@ __device__ __forceinline__ int reflect_index(int p, int T) {   // index into x o
     return p;
 }
 
-__global__ void stft_mag_fwd_kernel(const float* __restrict__ x, const float* __restrict__ window,
+// N is a template parameter (static LDS, stage loop unrolled at compile time).  (Tried as a remedy for the occasional wrong frames
+// seen when two PROCESSES share one GPU -- rocFFT behind torch.stft shows them too -- and it is not one: DESIGN.md section 7.)
+template <int N>
+__global__ __launch_bounds__(N / 4 < 64 ? 64 : N / 4) void stft_mag_fwd_kernel(const float* __restrict__ x, const float* __restrict__ window,
                                     const float2* __restrict__ tw, float clamp_min, float* __restrict__ mag, int T,
-                                    int N, int hop, int frames) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+                                    int hop, int frames) {
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * N];
     float2 *b0 = lds, *b1 = lds + N;
     const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x, Q = N >> 2;
     const float* xb = x + (int64_t)b * T;
@@ -106,10 +109,11 @@ __global__ void stft_mag_fwd_kernel(const float* __restrict__ x, const float* __
     }
 }
 
-__global__ void stft_mag_bwd_kernel(const float* __restrict__ x, const float* __restrict__ window,
+template <int N>
+__global__ __launch_bounds__(N / 4 < 64 ? 64 : N / 4) void stft_mag_bwd_kernel(const float* __restrict__ x, const float* __restrict__ window,
                                     const float2* __restrict__ tw, float clamp_min, const float* __restrict__ dmag,
-                                    float* __restrict__ dx, int T, int N, int hop, int frames) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+                                    float* __restrict__ dx, int T, int hop, int frames) {
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * N];
     float2 *b0 = lds, *b1 = lds + N;
     const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x, Q = N >> 2;
     const float* xb = x + (int64_t)b * T;
@@ -165,8 +169,14 @@ extern "C" int osp_stft_mag_fwd(const float* x, const float* window, const float
                                 int64_t B, int64_t T, int64_t N, int64_t hop, hipStream_t stream) {
     OSP_CHECK_ARG(stft_check(x, tw, B, T, N, hop) && mag, "bad STFT arguments");
     const int frames = (int)(1 + T / hop);
-    hipLaunchKernelGGL(stft_mag_fwd_kernel, dim3((unsigned)frames, (unsigned)B), dim3((unsigned)(N / 4)), (size_t)N * 16, stream,
-                       x, window, (const float2*)tw, clamp_min, mag, (int)T, (int)N, (int)hop, frames);
+#define OSP_STFT_FWD(NN) case NN: hipLaunchKernelGGL((stft_mag_fwd_kernel<NN>), dim3((unsigned)frames, (unsigned)B), dim3(NN / 4), 0, stream, \
+                       x, window, (const float2*)tw, clamp_min, mag, (int)T, (int)hop, frames); break
+    switch ((int)N) {
+        OSP_STFT_FWD(16); OSP_STFT_FWD(32); OSP_STFT_FWD(64); OSP_STFT_FWD(128); OSP_STFT_FWD(256); OSP_STFT_FWD(512);
+        OSP_STFT_FWD(1024); OSP_STFT_FWD(2048); OSP_STFT_FWD(4096);
+        default: OSP_CHECK_ARG(false, "n_fft must be a power of two in [16, 4096]");
+    }
+#undef OSP_STFT_FWD
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
@@ -176,8 +186,14 @@ extern "C" int osp_stft_mag_bwd(const float* x, const float* window, const float
                                 float* dx, int64_t B, int64_t T, int64_t N, int64_t hop, hipStream_t stream) {
     OSP_CHECK_ARG(stft_check(x, tw, B, T, N, hop) && dmag && dx, "bad STFT arguments");
     const int frames = (int)(1 + T / hop);
-    hipLaunchKernelGGL(stft_mag_bwd_kernel, dim3((unsigned)frames, (unsigned)B), dim3((unsigned)(N / 4)), (size_t)N * 16, stream,
-                       x, window, (const float2*)tw, clamp_min, dmag, dx, (int)T, (int)N, (int)hop, frames);
+#define OSP_STFT_BWD(NN) case NN: hipLaunchKernelGGL((stft_mag_bwd_kernel<NN>), dim3((unsigned)frames, (unsigned)B), dim3(NN / 4), 0, stream, \
+                       x, window, (const float2*)tw, clamp_min, dmag, dx, (int)T, (int)hop, frames); break
+    switch ((int)N) {
+        OSP_STFT_BWD(16); OSP_STFT_BWD(32); OSP_STFT_BWD(64); OSP_STFT_BWD(128); OSP_STFT_BWD(256); OSP_STFT_BWD(512);
+        OSP_STFT_BWD(1024); OSP_STFT_BWD(2048); OSP_STFT_BWD(4096);
+        default: OSP_CHECK_ARG(false, "n_fft must be a power of two in [16, 4096]");
+    }
+#undef OSP_STFT_BWD
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
