@@ -39,10 +39,10 @@ def test_state_dict_round_trip_cpu(tmp_path):
         assert ka == kb and torch.equal(va, vb), ka
 
 
-def _resume_fixture(pipeline=False):
+def _resume_fixture(pipeline=False, backbone="convnext"):
     from optispeech_amd import rng
     from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
-    cfg = ModelConfig()                                          # dropout / drop-path ON: the RNG position matters
+    cfg = ModelConfig(backbone=backbone)                         # dropout / drop-path ON: the RNG position matters
 
     def prep(m):
         m.optimizers()
@@ -71,8 +71,9 @@ def _mean_abs_diff(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline", [False, True])
-def test_save_checkpoint_resume_is_exact(tmp_path, pipeline):
+@pytest.mark.parametrize("pipeline,backbone", [(False, "convnext"), (True, "convnext"), (False, "transformer"), (False, "lightspeech"),
+                                               (False, "leanspeech"), (False, "conformer")])
+def test_save_checkpoint_resume_is_exact(tmp_path, pipeline, backbone):
     """train 4 steps == train 2 -> save_checkpoint -> load_from_checkpoint + load_training_state -> train 2 (weights, AdamW
     moments in the reference layout, schedule, dropout RNG position and stream ids all restored), WITH a negative control: the
     same resume without load_training_state must land measurably elsewhere.  pipeline=True saves while the discriminator phase
@@ -80,7 +81,7 @@ def test_save_checkpoint_resume_is_exact(tmp_path, pipeline):
     from optispeech_amd import precision
     from optispeech_amd.model import OptiSpeech
     precision.set_precision("f32")
-    cfg, fresh, prep, batch = _resume_fixture(pipeline)
+    cfg, fresh, prep, batch = _resume_fixture(pipeline, backbone)
     a = fresh()
     for i in range(2):
         a.training_step(batch, i)
