@@ -39,10 +39,9 @@ _WG = {"on": _os.environ.get("OSP_WGRAD_STREAM", "1") != "0", "sides": {}, "used
 
 class _Side:
     """The weight-gradient stream of one calling stream, with its own hand-over events.  An event is only ever re-recorded on
-    the SAME calling stream and only in a later backward pass (``pos`` restarts at the join): a global ring shared by all calling
-    streams re-recorded events of the vocoder stream on the main stream a few hand-overs later, and with two processes on one
-    GPU the vocoder's embed / head weight gradients then came out wrong (1e-3 .. 3e-1) in ~20 % of the runs of
-    tests/test_gpu_dp.py, never with inline launches or with a fresh event per hand-over."""
+    the SAME calling stream and only in a later backward pass (``pos`` restarts at the join), so a wait queued on the side stream
+    can never come to refer to a record made on another stream (an earlier version shared one ring of 32 events between all
+    calling streams and relied on hipStreamWaitEvent capturing the record at call time)."""
     __slots__ = ("stream", "raw", "events", "pos")
 
     def __init__(self, dev):
