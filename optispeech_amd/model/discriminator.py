@@ -390,11 +390,8 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
             return loss, logs
         loss_gen_mp, loss_gen_mrd = _hinge_g(g_mp), _hinge_g(g_mr)
         loss_fm_mp, loss_fm_mrd = _feature_matching(fr_mp, fg_mp), _feature_matching(fr_mr, fg_mr)
-        if loss_gen_mp.is_cuda:
-            from ..ops import weighted_sum
-            loss = weighted_sum([loss_gen_mp, loss_gen_mrd, loss_fm_mp, loss_fm_mrd, mel_loss, mr_stft_loss], [1.0, lam, 1.0, lam, 1.0, 1.0])
-        else:
-            loss = loss_gen_mp + loss_gen_mrd * lam + loss_fm_mp + loss_fm_mrd * lam + mel_loss + mr_stft_loss
+        from ..ops import weighted_sum
+        loss = weighted_sum([loss_gen_mp, loss_gen_mrd, loss_fm_mp, loss_fm_mrd, mel_loss, mr_stft_loss], [1.0, lam, 1.0, lam, 1.0, 1.0])
         logs = dict(loss_gen_mp=loss_gen_mp, loss_gen_mrd=loss_gen_mrd, loss_fm_mp=loss_fm_mp, loss_fm_mrd=loss_fm_mrd,
                     mel_loss=mel_loss, mr_stft_loss=mr_stft_loss)
         return loss, {k: v.detach() for k, v in logs.items()}

@@ -111,13 +111,8 @@ class OptiSpeechGenerator(nn.Module):
 
         segment_size = min(self.segment_size, y.shape[1])                                   # :147
         r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=y.device)
-        if y.is_cuda:
-            # :148 + utils/segments.py:29-34 in one launch: long(r * clamp(float(len - 4) - segment_size, 0))
-            start_idx = K.segment_starts(r.to(device=y.device, dtype=torch.float32), mel_lengths, segment_size)
-        else:
-            num_frames = (mel_lengths - 4).to(torch.float32)                                # :148
-            max_start = (num_frames - segment_size).clamp_(min=0)                           # utils/segments.py:29-31
-            start_idx = (r.to(y.device) * max_start).to(torch.long)                         # utils/segments.py:32-34
+        # :148 + utils/segments.py:29-34 in one launch: long(r * clamp(float(len - 4) - segment_size, 0))
+        start_idx = K.segment_starts(r.to(device=y.device, dtype=torch.float32), mel_lengths, segment_size)
         segment = K.gather_rows(y.detach(), start_idx, segment_size)                        # :149-153, detach :161
         wav_hat = vocoder_hook(segment) if vocoder_hook is not None else None
 
@@ -126,13 +121,9 @@ class OptiSpeechGenerator(nn.Module):
             duration_hat, pitch_hat, energy_hat, durations, p_avg, e_avg, x_lengths)        # :165-173
         ops.join_side_stream()                                                              # the CTC recursion ran alongside
         align_loss = forwardsum_loss.detach() + bin_loss.detach()                           # :175 (logged value)
-        if forwardsum_loss.is_cuda:
-            # :176-181 as one node: lambda_align * (forwardsum + bin) + lambda_d * dur + lambda_p * pitch + lambda_e * energy
-            loss = ops.weighted_sum([forwardsum_loss, bin_loss, duration_loss, pitch_loss, energy_loss],
-                                    [c.lambda_align, c.lambda_align, c.lambda_duration, c.lambda_pitch, c.lambda_energy])
-        else:
-            loss = ((forwardsum_loss + bin_loss) * c.lambda_align + duration_loss * c.lambda_duration + pitch_loss * c.lambda_pitch
-                    + energy_loss * c.lambda_energy)
+        # :176-181 as one node: lambda_align * (forwardsum + bin) + lambda_d * dur + lambda_p * pitch + lambda_e * energy
+        loss = ops.weighted_sum([forwardsum_loss, bin_loss, duration_loss, pitch_loss, energy_loss],
+                                [c.lambda_align, c.lambda_align, c.lambda_duration, c.lambda_pitch, c.lambda_energy])
         # NB: the reference moves the sub-losses to the CPU here (4 device syncs); we keep them on the device and
         # let the caller fetch all scalars with one copy.
         return {"wav_hat": wav_hat, "start_idx": start_idx, "segment_size": segment_size, "loss": loss,

@@ -125,11 +125,7 @@ class ConvNeXtBackbone(nn.Module):
         if not any(p > 0.0 for p in drops):
             return None, None
         B, T, _ = x.shape
-        if x.is_cuda:
-            return K.drop_path_rows(drops, rm, B, T, rng.seed(), self._drop_stream, x.device)
-        keep = torch.tensor([1.0 - p for p in drops], dtype=torch.float32)[:, None]
-        sc = ((torch.rand((len(drops), B)) < keep).to(torch.float32) / keep)[:, :, None].expand(-1, B, T).reshape(len(drops), B * T)
-        return sc, (sc * rm[None] if rm is not None else None)
+        return K.drop_path_rows(drops, rm, B, T, rng.seed(), self._drop_stream, x.device)
 
 
 # =================================================================================================== text embedding
