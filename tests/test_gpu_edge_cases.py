@@ -284,7 +284,9 @@ def test_cache_generator_outputs_false_reruns_the_updated_generator():
     torch.cuda.synchronize()
     want = odb.arena.grad.detach()
     err = ((gota["d"] - want).norm() / want.norm()).item()
-    assert err < 2e-5, err
+    # (the two generators differ at the 1e-7 level -- see above -- and Adam's first step turns a sign flip of a noise-level
+    # gradient element into a 2 * lr difference of that weight: measured 1e-6 .. 5e-5 on the discriminator gradients)
+    assert err < 3e-4, err
     cached_err = ((gotb["d"] - want).norm() / want.norm()).item()
     assert cached_err > 1e-3, "the cached and the re-run discriminator phases should see different generated waves"
     la, lb = a.fetch_logs(), b.fetch_logs()
