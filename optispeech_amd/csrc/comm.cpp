@@ -28,21 +28,30 @@ struct Rccl {
 } g_rccl;
 ncclComm_t g_comm = nullptr;
 int g_world = 0;
+int g_device = -1;                                      // the device the communicator was bound to (osp_comm_init)
 
 int load_rccl() {
     if (g_rccl.lib) return OSP_OK;
+    // resolve into a local table and publish it only when every symbol is there: a half-filled g_rccl with lib != null would
+    // let the next osp_comm_* call through this guard and into a null function pointer
+    Rccl t;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    char tried[512] = "";
     for (const char* n : names) {
-        g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.lib) break;
+        t.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (t.lib) break;
+        const char* e = dlerror();
+        size_t used = strlen(tried);
+        snprintf(tried + used, sizeof(tried) - used, "%s%s: %s", used ? "; " : "", n, e ? e : "?");
     }
-    if (!g_rccl.lib) { osp_set_error("osp_comm: cannot load librccl.so (%s)", dlerror()); return OSP_ERR_UNSUPPORTED; }
+    if (!t.lib) { osp_set_error("osp_comm: cannot load librccl (%s)", tried); return OSP_ERR_UNSUPPORTED; }
 #define SYM(field, name)                                                                    \
-    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name));       \
-    if (!g_rccl.field) { osp_set_error("osp_comm: librccl.so lacks %s", name); return OSP_ERR_UNSUPPORTED; }
+    t.field = reinterpret_cast<decltype(t.field)>(dlsym(t.lib, name));                      \
+    if (!t.field) { osp_set_error("osp_comm: librccl.so lacks %s", name); dlclose(t.lib); return OSP_ERR_UNSUPPORTED; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(AllReduce, "ncclAllReduce")
     SYM(CommDestroy, "ncclCommDestroy") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    g_rccl = t;
     return OSP_OK;
 }
 int check(ncclResult_t r, const char* what) {
@@ -67,7 +76,7 @@ extern "C" int osp_comm_init(int64_t rank, int64_t world, const void* id_host) {
     ncclUniqueId id;
     memcpy(&id, id_host, sizeof(id));
     rc = check(g_rccl.CommInitRank(&g_comm, (int)world, id, (int)rank), "ncclCommInitRank");
-    if (rc == OSP_OK) g_world = (int)world; else g_comm = nullptr;
+    if (rc == OSP_OK) { g_world = (int)world; (void)hipGetDevice(&g_device); } else g_comm = nullptr;
     return rc;
 }
 
@@ -76,12 +85,15 @@ extern "C" int64_t osp_comm_world() { return g_comm ? g_world : 0; }
 extern "C" int osp_allreduce_bucket(float* ptr, int64_t n, hipStream_t stream) {
     OSP_CHECK_ARG(ptr && n > 0, "bad bucket");
     OSP_CHECK_ARG(g_comm, "osp_comm_init has not been called");
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    OSP_CHECK_ARG(dev == g_device, "the current device is not the one osp_comm_init bound the communicator to");
     return check(g_rccl.AllReduce(ptr, ptr, (size_t)n, kNcclFloat32, kNcclSum, g_comm, stream), "ncclAllReduce");
 }
 
 extern "C" int osp_comm_destroy() {
     if (!g_comm) return OSP_OK;
     const int rc = check(g_rccl.CommDestroy(g_comm), "ncclCommDestroy");
-    g_comm = nullptr; g_world = 0;
+    g_comm = nullptr; g_world = 0; g_device = -1;
     return rc;
 }

@@ -243,7 +243,9 @@ class ConvStackFn(torch.autograd.Function):
         if need_x and ctx.u0:                                    # gradient of the whole input: zeros for the no-grad head
             # the head rows belong to the real waves, which carry no gradient: whatever stands there is narrowed away by the
             # backward of the torch.cat that built the batch (per-sample ops only in between), so they are not zero-filled
-            full = torch.empty((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
+            # (zeros, not empty: one memset keeps NaN/Inf of uninitialised memory away from anything that might reduce
+            # over the batch dimension later)
+            full = torch.zeros((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
             full[ctx.u0:] = g
             g = full
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)

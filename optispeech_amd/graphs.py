@@ -115,7 +115,10 @@ class StepGraphs:
         m, b = self.model, self.static
         opt_g, opt_d = m.optimizers()
         if not st.train_d:
-            return [([lambda: m._stage_g_forward(st, b), lambda: m._stage_g_backward(st)], lambda: self.red_g.start(opt_g.arena.grad)),
+            # pre-training regime: nothing to overlap the G all-reduce with -- start it and make the stream the AdamW(G)
+            # graph is launched on wait for it (without the wait the update read partially reduced gradients)
+            return [([lambda: m._stage_g_forward(st, b), lambda: m._stage_g_backward(st)],
+                     lambda: (self.red_g.start(opt_g.arena.grad), self.red_g.wait())),
                     ([lambda: m._stage_opt_g(st)], None)] if self.segmented else \
                    [([lambda: m._stage_g_forward(st, b), lambda: m._stage_g_backward(st), lambda: m._stage_opt_g(st)], None)]
         if not self.segmented:

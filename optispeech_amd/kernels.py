@@ -90,7 +90,8 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
     from . import values
     key = (w.data_ptr() - p.data_ptr(), n_out, taps, cin, tuple(w_strides))
     rk = (id(p), key)
-    if rk not in _PACK_REG:
+    reg = _PACK_REG.get(rk)
+    if reg is None or reg[0]() is not p:        # (id() of a collected Parameter is re-used: an entry with a dead weakref is not p's)
         _PACK_REG[rk] = (weakref.ref(p), key)
     stamp = (values.param_epoch(), p._version, p.data_ptr())
     cache = getattr(p, "_osp_packs", None)

@@ -338,9 +338,22 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         self.mr_stft_loss = spectral.MultiResolutionSTFTLoss()
 
     def forward_real(self, wav):
-        return self.multiperioddisc.forward_real(wav), self.multiresddisc.forward_real(wav)
+        with precision.disc_scope():
+            return self.multiperioddisc.forward_real(wav), self.multiresddisc.forward_real(wav)
 
     def prepare_disc_inputs(self, wav, wav_hat):
+        with precision.disc_scope():
+            return self._prepare_disc_inputs(wav, wav_hat)
+
+    def forward_disc(self, wav, wav_hat, real=None, pre=None, replay=False):
+        with precision.disc_scope():
+            return self._forward_disc(wav, wav_hat, real=real, pre=pre, replay=replay)
+
+    def forward_gen(self, wav, wav_hat, real=None):
+        with precision.disc_scope():
+            return self._forward_gen(wav, wav_hat, real=real)
+
+    def _prepare_disc_inputs(self, wav, wav_hat):
         """(concatenated waves, 'ready' event) for a later forward_disc: taken right after the generator forward so that the
         discriminator-phase forward does not have to wait for whatever the calling stream does in between (the generator's
         backward), only for the waves themselves."""
@@ -349,7 +362,7 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         x = torch.cat([wav, wav_hat], 0)
         return x, torch.cuda.current_stream().record_event()
 
-    def forward_disc(self, wav, wav_hat, real=None, pre=None, replay=False):
+    def _forward_disc(self, wav, wav_hat, real=None, pre=None, replay=False):
         """replay=True: reuse the forward the generator phase of the SAME step ran on these waves (same weights -> same
         activations) and only run the backward with weight gradients; falls back to a fresh forward when nothing valid is recorded."""
         # both families are launched before either is joined: the eight stacks overlap across the family boundary too
@@ -367,16 +380,19 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         loss = loss_mp + loss_mrd * self.loss_coeffs.lambda_mrd
         return loss, dict(loss_mp=loss_mp.detach(), loss_mrd=loss_mrd.detach())
 
-    def forward_gen(self, wav, wav_hat, real=None):
+    def _forward_gen(self, wav, wav_hat, real=None):
         _, g_mp, fr_mp, fg_mp = self.multiperioddisc(y=wav, y_hat=wav_hat, real=real[0] if real is not None else None, defer_join=True)
         _, g_mr, fr_mr, fg_mr = self.multiresddisc(y=wav, y_hat=wav_hat, real=real[1] if real is not None else None, defer_join=True)
         if precision.is_bf16() and _DISC_STREAMS and wav.is_cuda:
             # the spectral reconstruction losses do not depend on the discriminators: a ninth stream
-            mel_loss, mr_stft_loss = on_side_stream(("spectral", id(self)), lambda: (self._get_mel_loss(wav, wav_hat),
-                                                                                   self._get_mr_stft_loss(wav, wav_hat)), [wav, wav_hat])
+            def spectral_losses():
+                with precision.generator_scope():
+                    return self._get_mel_loss(wav, wav_hat), self._get_mr_stft_loss(wav, wav_hat)
+            mel_loss, mr_stft_loss = on_side_stream(("spectral", id(self)), spectral_losses, [wav, wav_hat])
         else:
-            mel_loss = self._get_mel_loss(wav, wav_hat)
-            mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
+            with precision.generator_scope():
+                mel_loss = self._get_mel_loss(wav, wav_hat)
+                mr_stft_loss = self._get_mr_stft_loss(wav, wav_hat)
         join_streams()
         lam = self.loss_coeffs.lambda_mrd
         if _fused_losses(g_mp[0]):

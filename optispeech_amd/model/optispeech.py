@@ -260,6 +260,7 @@ class OptiSpeech(nn.Module):
     def _stage_g_backward(self, st):
         if st.apply:
             self.optimizers()[0].zero_grad()
+        ops.begin_backward()
         with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):
             (st.loss_g / st.scale).backward()
         st.loss_g = None
@@ -275,12 +276,25 @@ class OptiSpeech(nn.Module):
                 again = self._process_batch(batch)
             st.wav, st.wav_hat, st.pre = again["wav"], again["wav_hat"], None
             self._real_pass = None
-        loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre,
-                                      replay=self.replay_disc_forward and self.train_args.cache_generator_outputs)
-        if st.apply:
-            self.optimizers()[1].zero_grad()
-        with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):
-            (loss_d / st.scale).backward()
+        # share_real_pass: two stack nodes (the kept real pass + the generated branch) accumulate into each
+        # sub-discriminator's arena slice, so a slice is only complete when BOTH backwards ran -- no gradient-ready
+        # collectives from inside this backward; the closing start_rest covers the whole arena
+        red_d = self._reducers[1] if self._reducers is not None else None
+        shared = self._real_pass is not None
+        keep_ranges = getattr(red_d, "eager_ranges", True)
+        if shared and red_d is not None:
+            red_d.eager_ranges = False
+        try:
+            loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre,
+                                          replay=self.replay_disc_forward and self.train_args.cache_generator_outputs)
+            if st.apply:
+                self.optimizers()[1].zero_grad()
+            ops.begin_backward()
+            with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):
+                (loss_d / st.scale).backward()
+        finally:
+            if shared and red_d is not None:
+                red_d.eager_ranges = keep_ranges
         st.pre = None
 
     def _stage_opt_g(self, st):

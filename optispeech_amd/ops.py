@@ -95,6 +95,23 @@ def _join_wgrad():
     _WG["used"], _WG["queued"], _WG["done"] = [], False, []
 
 
+def begin_backward():
+    """Called by the step right before it runs backward(): if a previous backward pass raised (OOM, kernel error), the
+    engine's end-of-backward callback never ran and the hand-over state is stale -- 'queued' still set (so no callback would be
+    queued for THIS pass and its side-stream work would never be joined) and 'pending' holding launches of the failed pass.
+    Drop the stale launches, join whatever did reach the side streams, start clean."""
+    if _WG["queued"] or _WG["pending"] or _WG["used"]:
+        _lib._RECORD[0] = None
+        _WG["pending"] = []
+        _WG["regions"] = 0
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream()
+            for side in _WG["used"]:
+                cur.wait_stream(side.stream)
+                side.pos = 0
+        _WG["used"], _WG["queued"], _WG["done"] = [], False, []
+
+
 def wgrad_side_streams():
     """Side streams with weight-gradient work of the running backward pass in flight (dp.GradReducer orders a gradient-ready
     collective behind them: the ready signal comes from the calling stream, which does not wait for them before the join)."""
