@@ -53,21 +53,30 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
     const int K = taps * Cin;
     const int rsub = lane >> 3, pslot = lane & 7;
     // wave w stages rows 8 * (w * RA + i) + rsub of A (i < RA) and 8 * (w * RB + i) + rsub of B (i < RB)
-    int a_t[RA], a_h[RA]; int64_t a_base[RA]; int64_t b_row[RB];
+    // K ORDER: channel block outer, TAP INNER.  Consecutive k-slabs of a tile then read the same 64 channels of input rows
+    // shifted by one tap step -- 255 of 256 rows of a stride-1 conv were fetched one slab earlier and are L2 (TCP) hits.  In the
+    // tap-major order of round 2 a tile came back to the same rows Cin / 64 slabs later, i.e. after the XCD's co-resident
+    // tiles had streamed Cin / 64 x 32 KB x 32 tiles = 16 MB through its 4 MB L2: every tap re-fetched the activation panel
+    // from MALL / HBM (TCC_EA traffic 2.7x the algorithmic bytes, profiles/r02b_pmc_glds.json).
+    // Per row: the element offset of (tap 0, channel 0) -- may lie outside the tensor, only dereferenced when the tap's frame is
+    // in range -- plus the frame coordinates for the range test; a tap adds a wave-uniform (SGPR) offset.
+    int a_t[RA], a_h[RA]; int64_t a_off0[RA]; int64_t b_row[RB];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + 8 * (wave * RA + i) + rsub;
+        const int r = 8 * (wave * RA + i) + rsub;
+        const int m = m0 + r;
         if (m < pp.M) {
             const int u = fd_div(m, pp.fd_trows), t = m - u * pp.Trows, th = fd_div(t, pp.fd_wrows), tw = t - th * pp.Wrows;
             a_t[i] = tw * pp.a_step + pp.a_off;
             a_h[i] = th * pp.a_step_h + pp.a_off_h;
-            a_base[i] = (int64_t)u * Hin * Tin;
-        } else { a_t[i] = -0x40000000; a_h[i] = 0; a_base[i] = 0; }
+            a_off0[i] = ((int64_t)u * Hin * Tin + (int64_t)a_h[i] * Tin + a_t[i]) * lda + (pslot ^ ((r >> 1) & 7)) * 8;
+        } else { a_t[i] = -0x40000000; a_h[i] = 0; a_off0[i] = 0; }
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = n0 + 8 * (wave * RB + i) + rsub;
-        b_row[i] = n < pp.N ? (int64_t)n * sBn : -1;
+        const int r = 8 * (wave * RB + i) + rsub;
+        const int n = n0 + r;
+        b_row[i] = n < pp.N ? (int64_t)n * sBn + (pslot ^ ((r >> 1) & 7)) * 8 : -1;
     }
     // accumulators as 64-row halves: the epilogue is instantiated per half with compile-time indices only (one 512-byte
     // array indexed through the epilogue's nested loops stayed a stack object and was stored to scratch every iteration)
@@ -80,29 +89,20 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
             for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
 
-    // Staging state: per owned row a source pointer for the current tap (or the zero page, with a zero channel stride);
-    // advancing k inside a tap is one 64-bit add per row, the row / bounds arithmetic runs once per tap.
-    const unsigned short* a_src[RA]; const unsigned short* b_src[RB]; int a_inc[RA], b_inc[RB];
-    int cur_tap = -1;
-    auto set_tap = [&](int j) {
+    // Staging state: per owned row the source pointer of the slab being staged (or the zero page).
+    const unsigned short* a_src[RA]; const unsigned short* b_src[RB];
+    auto set_tap = [&](int j, int cb) {
         const int kh = (KW == taps) ? 0 : j / KW, kw = j - kh * KW;
+        const int dt = kw * a_tapstep, dh = kh * a_tapstep_h;                                  // wave-uniform
+        const int64_t offA = ((int64_t)dh * Tin + dt) * lda + cb;
+        const int64_t offB = (int64_t)kh * sBtap_h + (int64_t)kw * sBtap + cb;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int r = 8 * (wave * RA + i) + rsub;
-            const int q = pslot ^ ((r >> 1) & 7);
-            const int tt = a_t[i] + kw * a_tapstep, hh = a_h[i] + kh * a_tapstep_h;
-            const bool ok = tt >= 0 && tt < Tin && hh >= 0 && hh < Hin;
-            a_src[i] = ok ? A + (a_base[i] + (int64_t)hh * Tin + tt) * lda + q * 8 : zero;
-            a_inc[i] = ok ? 1 : 0;
+            const bool ok = (unsigned)(a_t[i] + dt) < (unsigned)Tin && (unsigned)(a_h[i] + dh) < (unsigned)Hin;
+            a_src[i] = ok ? A + a_off0[i] + offA : zero;
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = 8 * (wave * RB + i) + rsub;
-            const int q = pslot ^ ((r >> 1) & 7);
-            b_src[i] = b_row[i] >= 0 ? B + b_row[i] + (int64_t)kh * sBtap_h + (int64_t)kw * sBtap + q * 8 : zero;
-            b_inc[i] = b_row[i] >= 0 ? 1 : 0;
-        }
-        cur_tap = j;
+        for (int i = 0; i < RB; ++i) b_src[i] = b_row[i] >= 0 ? B + b_row[i] + offB : zero;
     };
     int is_j = 0, is_cb = 0;                                   // (tap, channel offset) of the next k-slab to stage
     // one of the RA + RB row loads of a slab (compile-time index): the loads are spread over the 4 k-steps of the MFMA
@@ -112,12 +112,12 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         constexpr int I = decltype(idx)::value;
         if constexpr (I < RA) {
             unsigned short* dst = As + buf * BM_ * TBK + (wave * RA + I) * 8 * TBK;      // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[I] + is_cb * a_inc[I]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[I]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         } else {
             constexpr int J = I - RA;
             unsigned short* dst = Bs + buf * BN_ * TBK + (wave * RB + J) * 8 * TBK;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[J] + is_cb * b_inc[J]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[J]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
@@ -127,8 +127,8 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         if constexpr (L1 - L0 > 1) issue_one(buf, std::integral_constant<int, L0 + 1>{});
         if constexpr (L1 - L0 > 2) issue_one(buf, std::integral_constant<int, L0 + 2>{});
     };
-    auto issue_begin = [&]() { if (is_j != cur_tap) set_tap(is_j); };          // wave-uniform branch
-    auto issue_end = [&]() { is_cb += TBK; if (is_cb == Cin) { is_cb = 0; ++is_j; } };
+    auto issue_begin = [&]() { set_tap(is_j, is_cb); };
+    auto issue_end = [&]() { ++is_j; if (is_j == taps) { is_j = 0; is_cb += TBK; } };
     auto issue = [&](int buf) {
         issue_begin();
         issue_quarter(buf, std::integral_constant<int, 0>{}); issue_quarter(buf, std::integral_constant<int, 1>{});

@@ -68,6 +68,31 @@ def destroy_native_comm():
         _native["ready"], _native["stream"] = False, None
 
 
+# ---------------------------------------------------------------------------------------------- shared-GPU test aid
+#: Test aid only (tests/test_gpu_dp.py: two ranks on ONE GPU over gloo).  Two PROCESSES computing on one MI355X of this pool at
+#: the same time give occasionally different FFT results -- rocFFT behind torch.stft as well as this package's STFT kernel, never
+#: a process that has the GPU to itself (tools/probes/shared_gpu_all.sh, profiles/r03_shared_gpu_probe.txt).  So the ranks of
+#: that test take TURNS on the GPU: a rank computes while it holds this lock, and hands it over -- device drained -- whenever it
+#: blocks in a (host-side, gloo) collective.  None in every real run: one process per GPU.
+SHARED_GPU_TURN = None
+
+
+class _yield_turn:
+    """``with _yield_turn():`` around a blocking gloo collective: drain the device, let the other rank compute, take the GPU back."""
+
+    def __enter__(self):
+        self.lock = SHARED_GPU_TURN
+        if self.lock is not None:
+            torch.cuda.synchronize()
+            self.lock.release()
+        return self
+
+    def __exit__(self, *exc):
+        if self.lock is not None:
+            self.lock.acquire()
+        return False
+
+
 class _NativeWork:
     """Handle of one osp_allreduce_bucket launch: ``wait()`` orders the CURRENT stream behind it (no host sync)."""
 
@@ -115,7 +140,8 @@ class GradReducer:
             # reproducible to 1e-7 run to run in one process (tools/determinism_probe.py, also under contention).
             torch.cuda.synchronize()
             host = flat_grad.detach().to("cpu")
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            with _yield_turn():
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.copy_(host)
             torch.cuda.synchronize()
             return
@@ -174,7 +200,15 @@ class GradReducer:
         if not self.active:
             return
         if self._ctrl_drain and any(t.is_cuda for t in tensors):
+            # gloo (test aid): through the host, so that the collective itself involves no device work of either rank
             torch.cuda.synchronize()
+            for t in tensors:
+                host = t.detach().to("cpu")
+                with _yield_turn():
+                    dist.broadcast(host, src=0, group=self.group)
+                t.copy_(host)
+            torch.cuda.synchronize()
+            return
         for t in tensors:
             dist.broadcast(t, src=0, group=self.group)
 
@@ -183,6 +217,12 @@ class GradReducer:
         if self.world > 1:
             if self._ctrl_drain and t.is_cuda:
                 torch.cuda.synchronize()
+                host = t.detach().to("cpu")
+                with _yield_turn():
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(host)
+                t /= self.world
+                return t
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             t /= self.world
         return t

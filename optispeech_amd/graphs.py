@@ -24,9 +24,33 @@ The discriminator phase reads the discriminator weights of the step's start and 
 backward reads the same (frozen) discriminator weights, and the two optimisers own disjoint parameters: every stage sees exactly
 the values it sees in the reference's order (base_lightning_module.py:78-126), only the issue order differs.
 """
+import contextlib
+import gc
+
 import torch
 
 from . import rng, values
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """Keep Python's CYCLIC garbage collector out of a hipGraph capture.
+
+    A collection that happens to trigger inside a capture (any allocation can start one) finalises whatever cyclic garbage is
+    around -- e.g. an earlier StepGraphs / model pair with its pinned scalar ring, events and captured graphs -- and those
+    finalisers make HIP calls that are illegal while a stream is capturing (event queries of the pinned-memory allocator, graph
+    / event destruction).  The error surfaces inside a C++ destructor, i.e. as std::terminate: the interpreter dies with SIGABRT.
+    That is what killed round 2's driver run of the GPU suite (reproduced in round 3: the faulthandler stack shows
+    'Garbage-collecting' under a kernel launch inside ``with torch.cuda.graph(...)``, profiles/r03_gputest_abort_stack.txt).
+    Reference-counted frees are deterministic and stay as they are; only the cycle collector is held back until the capture ended."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _shape_key(model, batch, train_d):
@@ -190,7 +214,7 @@ class StepGraphs:
                 pool = None
                 for stages, hook in self._segments(st):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, stream=s, capture_error_mode="thread_local"):
+                    with no_gc_during_capture(), torch.cuda.graph(g, pool=pool, stream=s, capture_error_mode="thread_local"):
                         for f in stages:
                             f()
                     pool = g.pool() if pool is None else pool
@@ -268,13 +292,13 @@ class GraphedSegment:
             # eagerly would be read by the replays long after the next optimizer epoch has freed it
             values.bump_param_epoch()
             self.gf = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gf, stream=s, capture_error_mode="thread_local"):
+            with no_gc_during_capture(), torch.cuda.graph(self.gf, stream=s, capture_error_mode="thread_local"):
                 outs = fn(*self.static_in)
             self.outs = tuple(outs)
             self.grad_idx = [i for i, o in enumerate(self.outs) if o.requires_grad]
             self.static_go = [torch.zeros_like(self.outs[i]) for i in self.grad_idx]
             self.gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gb, pool=self.gf.pool(), stream=s, capture_error_mode="thread_local"):
+            with no_gc_during_capture(), torch.cuda.graph(self.gb, pool=self.gf.pool(), stream=s, capture_error_mode="thread_local"):
                 torch.autograd.backward([self.outs[i] for i in self.grad_idx], self.static_go)
             self.outs = tuple(o.detach() for o in self.outs)
             values.bump_param_epoch()                          # and nothing eager keeps using a pack that lives in the graph's pool

@@ -159,9 +159,10 @@ class OptiSpeechGenerator(nn.Module):
             cur.wait_stream(side)
             torch.cuda.synchronize(dev)
             g_am, g_voc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_am):
+            from ..graphs import no_gc_during_capture        # a cyclic-GC pass inside a capture can abort the process (see there)
+            with no_gc_during_capture(), torch.cuda.graph(g_am, capture_error_mode="thread_local"):
                 st["y"], st["mask"] = am()
-            with torch.cuda.graph(g_voc, pool=g_am.pool()):
+            with no_gc_during_capture(), torch.cuda.graph(g_voc, pool=g_am.pool(), capture_error_mode="thread_local"):
                 st["wav"] = self.vocoder(st["y"], f0=None, padding_mask=st["mask"])
             ent = self._decode_graphs[key] = (st, g_am, g_voc)
         st, g_am, g_voc = ent

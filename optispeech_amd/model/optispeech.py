@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
+from .. import ops
 from .. import rng
 from ..dp import GradReducer
 from ..optim import CosineWarmupSchedule, FusedAdamW

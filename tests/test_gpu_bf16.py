@@ -94,6 +94,8 @@ def test_mpd_bf16_path_matches_f32_path(which):
             rs, gs, _, _ = mpd(y, yh.detach())
             ld = _hinge_d(rs, gs)
             ld.backward()
+            missing = [k for k, p in mpd.named_parameters() if p.grad is None]
+            assert not missing, (mode, missing, [k for k, p in mpd.named_parameters() if not p.requires_grad])
             res[mode] = (lg.item(), ld.item(), yh.grad.clone(), {k: p.grad.clone() for k, p in mpd.named_parameters()})
         finally:
             precision.set_precision("f32")

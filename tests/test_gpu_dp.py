@@ -12,7 +12,13 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests._isolate import isolated
+
 pytestmark = pytest.mark.gpu
+
+#: |all-reduced sum / world - mean of the single-rank gradient sets| / |mean|, per arena.  Same kernels, same inputs; the only
+#: run-to-run freedom is the order of f32 atomics in the split-K weight gradients.
+TOL = 2e-5
 
 
 def _free_port():
@@ -65,20 +71,24 @@ def _worker(rank, world, port, graph, q, lock):
         from optispeech_amd import dp, precision
         precision.set_precision("f32")
         # ---- single-rank references, before the process group exists (their reducers are inert)
-        cfg, ref = _build(7)
-        batches = _batches(cfg)
-        ref.optimizers()
-        assert not ref._reducers[0].active
-        w0 = [o.arena.data.clone() for o in ref.optimizers()]
         with lock:                                        # one rank at a time on the shared GPU (see the test's docstring)
+            cfg, ref = _build(7)
+            batches = _batches(cfg)
+            ref.optimizers()
+            assert not ref._reducers[0].active
+            w0 = [o.arena.data.clone() for o in ref.optimizers()]
             singles = [_grads_of_one_step(ref, b, r01) for b, r01 in batches]
+            mean_g = (singles[0][0] + singles[1][0]) / 2
+            mean_d = (singles[0][1] + singles[1][1]) / 2
             torch.cuda.synchronize()
-        mean_g = (singles[0][0] + singles[1][0]) / 2
-        mean_d = (singles[0][1] + singles[1][1]) / 2
         # ---- the two-rank run: rank r sees micro-batch r; rank 1 deliberately starts from DIFFERENT weights, which the
         # broadcast from rank 0 in optimizers() must repair
         w, r, _ = dp.init_from_env()
         assert (w, r) == (world, rank) and dist.get_backend() == "gloo"
+        # from here on the ranks take TURNS on the one GPU they share: a rank computes while it holds the lock and hands it over,
+        # device drained, whenever it blocks in a gloo collective (dp.SHARED_GPU_TURN; see the test's docstring)
+        lock.acquire()
+        dp.SHARED_GPU_TURN = lock
         cfg, m = _build(7, rank_seed_offset=rank)
         m.graph_steps = graph
         m.graph_warmup_steps = 1
@@ -122,25 +132,37 @@ def _worker(rank, world, port, graph, q, lock):
                 worst = sorted(((((got - mean)[off:off + p.numel()]).norm().item(), by[id(p)]) for p, off in zip(o.arena.params, o.arena.offsets)),
                                reverse=True)[:4]
                 msgs.append(f"{name}: largest deviations " + ", ".join(f"{n} {v:.2e}" for v, n in worst))
-            # two runs of the SAME step differ by the f32-atomic order of the split-K weight gradients (observed up to 2.5e-4 on the
-            # discriminator arena); a missing / doubled contribution would show as O(1)
-            ok = ok and err < 6e-4
+            # two runs of the SAME step differ only by the f32-atomic order of the split-K weight gradients; a missing / doubled /
+            # unscaled contribution would show as O(1)
+            ok = ok and err < TOL
         # replicas identical after the update: compare every rank's arenas bit for bit
         for o in (og, od):
-            mine = o.arena.data.detach().clone()
+            mine = o.arena.data.detach().cpu()
             both = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(both, mine)
+            with dp._yield_turn():
+                dist.all_gather(both, mine)
+            mine = mine.to("cuda")
             same = torch.equal(both[0], both[1])
             ok = ok and same
             msgs.append(f"replicas bit-identical: {same}")
             moved = (mine - w0[0 if o is og else 1]).abs().max().item()
             ok = ok and moved > 0
         q.put((rank, bool(ok), msgs, {k: float(v) for k, v in logs.items() if k.startswith("total_loss")}))
-        dist.barrier()
+        with dp._yield_turn():
+            dist.barrier()
+        dp.SHARED_GPU_TURN = None
+        lock.release()
         dist.destroy_process_group()
     except Exception as e:                                # noqa: BLE001
         import traceback
         q.put((rank, False, [traceback.format_exc()], {}))
+        from optispeech_amd import dp as _dp
+        if _dp.SHARED_GPU_TURN is not None:               # do not leave the other rank waiting for its turn
+            _dp.SHARED_GPU_TURN = None
+            try:
+                lock.release()
+            except ValueError:
+                pass
         raise
 
 
@@ -160,30 +182,25 @@ def _attempt(graph):
 
 @pytest.mark.parametrize("graph", [False, True])
 def test_two_rank_training_step_equals_mean_of_single_rank_gradients(graph):
-    """Both ranks share ONE GPU here (RCCL needs a GPU per rank, the box has one).  Two processes computing on one GPU at the
-    same time is not a configuration the product runs in, and on this pool it makes the STFT-fed part of ANY training step (the
-    resolution discriminators, the spectral losses and through them the vocoder's gradients) come out 1e-3 off in a few percent
-    of the steps -- with or without data parallelism, never in a process that has the GPU to itself (tools/race2.sh,
-    tools/component_race_probe.py).  A data-parallel defect (a missing / doubled / unscaled contribution,
-    replicas that drift) is deterministic, so: the single-rank references are computed one rank at a time, and a mismatch must
-    reproduce on three independent attempts to fail the test."""
-    failures = []
-    for attempt in range(3):
-        res, codes = _attempt(graph)
-        bad = [(rank, msgs) for rank, ok, msgs, logs in res if not ok]
-        if not bad:
-            break
-        failures.append("\n".join(f"attempt {attempt} rank {rank}:\n  " + "\n  ".join(str(x) for x in msgs) for rank, msgs in bad))
-    else:
-        pytest.fail("\n".join(failures), pytrace=False)
-    if failures:
-        import warnings
-        warnings.warn(f"{len(failures)} attempt(s) disagreed before one matched (GPU shared by the two ranks):\n" + "\n".join(failures))
+    """ONE attempt, strict.  Both ranks share ONE GPU here (RCCL needs a GPU per rank, the box has one).  Two PROCESSES computing
+    on one MI355X of this pool at the same time is not a configuration the product runs in, and it makes FFT results come out
+    different in a few percent of the repetitions -- rocFFT behind torch.stft as well as this package's STFT kernel, also in a
+    stand-alone HIP program with no torch in it, never in a process that has the GPU to itself (tools/probes/shared_gpu_all.sh,
+    profiles/r03_shared_gpu_probe.txt).  So the two ranks take TURNS on the GPU (dp.SHARED_GPU_TURN: a rank
+    hands the GPU over, drained, whenever it blocks in a gloo collective): every kernel of either rank then runs with the GPU to
+    itself, and the comparison is strict again -- a single attempt, no retry."""
+    res, codes = _attempt(graph)
+    bad = [(rank, msgs) for rank, ok, msgs, logs in res if not ok]
+    if bad:
+        pytest.fail("\n".join(f"rank {rank}:\n  " + "\n  ".join(str(x) for x in msgs) for rank, msgs in bad), pytrace=False)
+    for rank, ok, msgs, logs in res:
+        print(f"rank {rank}: " + "; ".join(str(x) for x in msgs))
     # the logged losses are the mean over ranks (one packed all-reduce): identical on both
     assert res[0][3] == res[1][3] and all(np.isfinite(v) for v in res[0][3].values())
     assert codes == [0, 0]
 
 
+@isolated
 def test_native_comm_c_abi_single_rank(tmp_path):
     """The RCCL communicator behind the C ABI (csrc/comm.cpp) on this box's one GPU: (1) the C++ host example of
     tests/native/comm_example.cpp runs (unique id -> init -> all-reduce -> destroy, sum over 1 rank = identity), (2) the same entry

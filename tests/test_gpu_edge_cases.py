@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests._isolate import isolated
+
 pytestmark = pytest.mark.gpu
 
 
@@ -98,6 +100,7 @@ def test_text_as_long_as_the_mel():
 
 
 @pytest.mark.parametrize("graph_decode", [False, True])
+@isolated
 def test_synthesise_one_sentence_vs_oracle(graph_decode):
     """synthesise() on ONE sentence (the everyday inference call; generator/__init__.py:194-301): durations bit-exact, pitch /
     energy / waveform to 1e-3, eager and with the decode replayed from hipGraphs."""

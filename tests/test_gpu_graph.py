@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests._isolate import isolated
+
 pytestmark = pytest.mark.gpu
 
 
@@ -41,6 +43,7 @@ def _run(mode, steps=3):
 
 
 @pytest.mark.parametrize("mode", ["graph", "segments", "hybrid"])
+@isolated
 def test_graphed_step_matches_eager(mode):
     from optispeech_amd import precision
     precision.set_precision("bf16")
@@ -71,6 +74,7 @@ def test_graphed_step_matches_eager(mode):
         precision.set_precision("f32")
 
 
+@isolated
 def test_graph_replay_advances_dropout_seed_and_weights():
     """Replays are not re-runs of the captured step: the dropout masks change (seed in device memory), the weights keep moving
     and the logged losses change from replay to replay."""
@@ -85,6 +89,7 @@ def test_graph_replay_advances_dropout_seed_and_weights():
         precision.set_precision("f32")
 
 
+@isolated
 def test_graph_captured_decode_equals_eager_synthesise(golden):
     """BASELINE.json configs[4]: synthesise() with the decode replayed from hipGraphs returns exactly the eager result, for
     two different batches through the same and through a new capture."""

@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/probes/stft_shared_gpu.sh [iters]  -- prints one RESULT line per process
+BIN=tools/probes/stft_shared_gpu
+IT=${1:-2000}
+for v in stft wave ldsmix nolds; do
+  echo "== $v: ONE process"; timeout 300 $BIN $v $IT | grep -v "^  " | tail -4
+  echo "== $v: TWO processes side by side"
+  ( timeout 300 $BIN $v $IT | sed "s/^/A: /" ) > /tmp/_sa.txt & ( timeout 300 $BIN $v $IT | sed "s/^/B: /" ) > /tmp/_sb.txt & wait
+  grep "RESULT\|deviate" /tmp/_sa.txt /tmp/_sb.txt | cut -d: -f2-
+done
