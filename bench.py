@@ -26,7 +26,7 @@ B, T_TEXT, T_MEL = 32, 128, 800
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r02b_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/)
+PMC_SUMMARY = "r03_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/)
 
 
 def parse():
@@ -37,12 +37,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-am-only", action="store_true", help="skip the acoustic-model-only (pre-training regime) step timing")
     ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
-    ap.add_argument("--cpu-batch", type=int, default=4, help="utterances in the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm step); the default sample is ~12 s of CPU work")
-    ap.add_argument("--cpu-threads", type=str, default="8,32",
-                    help="thread counts tried for the CPU baseline (the best one is reported as `value`, the 8-thread figure beside it)")
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="SURVEY section 8(d) protocol instead of the bounded sample: B=32, 1 warm + 3 timed steps (takes ~10 min)")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="utterances per CPU-baseline step (32 = the configuration the GPU number is quoted on, SURVEY 8(d))")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps (SURVEY 8(d): 3 warm + 5 timed)")
+    ap.add_argument("--cpu-warm", type=int, default=3, help="untimed CPU-baseline steps")
+    ap.add_argument("--cpu-threads", type=str, default="8",
+                    help="thread counts tried for the CPU baseline, comma separated (SURVEY 8(d): 8; the port does not scale past ~8 threads)")
+    ap.add_argument("--cpu-budget", type=float, default=150.0,
+                    help="wall-clock budget in seconds for the CPU baseline: the 3 + 5 protocol is cut short (and says so) when the host is slow")
+    ap.add_argument("--cpu-full", action="store_true", help="no wall-clock budget: the full protocol whatever it takes")
     ap.add_argument("--graph", action="store_true",
                     help="time the hipGraph replay of the step (OptiSpeech.graph_steps) as the headline instead of the eager multi-stream "
                          "step.  Off by default: on ROCm 7.2 a captured multi-stream graph executes its branches almost serially "
@@ -66,28 +68,38 @@ def parse():
 
 
 class KernelTimer:
-    """HIP-event timing of selected C-ABI launches on the launch stream (torch's current stream): `select(name, args)` returns
-    (key, work) -- work = algorithmic flops or bytes of that launch -- or None; per key the sums give work / time."""
+    """HIP-event timing of C-ABI launches on the launch stream (torch's current stream).  Matrix-core kernels are classified by
+    the LIBRARY, not by this script: right after an entry point returns, ``osp_kernel_note_host`` says which symbol its
+    dispatcher launched and how many algorithmic flops (2 M taps Cin N, summed over the call's launches) that was -- so the
+    record follows the dispatcher's real selection rules (a Python mirror of them went stale in round 2: 35 of 47 launches
+    bracketed).  HBM kernels are picked by `select(name, args)` -> (key, algorithmic bytes)."""
 
     def __init__(self, select):
         self.select, self.events, self.enabled = select, [], False
 
     def install(self):
+        import ctypes
         from optispeech_amd import _lib
         lib = _lib.lib()
         orig = lib.call
         timer = self
+        note = lib.cdll.osp_kernel_note_host
+        note.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
+        buf, fl = ctypes.create_string_buffer(128), ctypes.c_double(0.0)
 
         def call(name, *args):
-            hit = timer.select(name, args) if timer.enabled else None
+            if not timer.enabled or _lib._RECORD[0] is not None:
+                return orig(name, *args)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, *args)
+            note(buf, 128, ctypes.byref(fl))
+            sym = buf.value.decode()
+            hit = ("mfma:" + sym, fl.value) if (sym and fl.value > 0) else timer.select(name, args)
             if hit:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                orig(name, *args)
+                e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
                 timer.events.append((hit[0], hit[1], e0, e1))
-            else:
-                orig(name, *args)
         lib.call = call
 
     def summary(self):
@@ -101,7 +113,7 @@ class KernelTimer:
         return {k: tuple(v) for k, v in out.items()}
 
 
-def cpu_baseline(nb, timed_steps=1, threads=None):
+def cpu_baseline(nb, timed_steps=1, threads=None, warm=1, budget_s=None):
     """Oracle (CPU port of the reference step) on a bounded sample: `nb` utterances of the same shape, one untimed +
     `timed_steps` timed full GAN steps incl. torch.optim.AdamW updates.  Returns (frames/s, threads, note)."""
     from oracle import generator as OG
@@ -134,31 +146,48 @@ def cpu_baseline(nb, timed_steps=1, threads=None):
         torch.nn.utils.clip_grad_norm_(dp_, 10.0)
         od.step()
 
-    step()
+    # SURVEY.md section 8(d) protocol: `warm` untimed steps, then `timed_steps` timed ones -- inside a wall-clock budget, so that
+    # the default bench run still finishes within minutes on a slow host: when the budget runs out the protocol is cut short
+    # and `sample` says what was actually run
+    t_begin = time.perf_counter()
+    done_warm = 0
+    for _ in range(max(1, warm)):
+        step()
+        done_warm += 1
+        one = (time.perf_counter() - t_begin) / done_warm
+        if budget_s and (time.perf_counter() - t_begin) + one * (1 + min(2, timed_steps)) > budget_s and done_warm >= 1:
+            break
+    one = (time.perf_counter() - t_begin) / done_warm
     t0 = time.perf_counter()
+    done = 0
     for _ in range(timed_steps):
         step()
-    dt = (time.perf_counter() - t0) / timed_steps
-    return nb * T_MEL / dt, threads, (f"{nb} utterances x (T_text={T_TEXT}, T_mel={T_MEL}), 1 warm + {timed_steps} timed GAN step(s), "
+        done += 1
+        if budget_s and done >= 1 and (time.perf_counter() - t_begin) + one > budget_s:
+            break
+    dt = (time.perf_counter() - t0) / done
+    return nb * T_MEL / dt, threads, (f"{nb} utterances x (T_text={T_TEXT}, T_mel={T_MEL}), {done_warm} warm + {done} timed GAN step(s), "
                                       f"{dt:.1f}s/step")
 
 
-def cpu_baseline_sweep(nb, timed_steps, thread_list):
+def cpu_baseline_sweep(nb, timed_steps, thread_list, warm=1, budget_s=None):
     """The oracle at several thread counts: the best one is the baseline `value`, every figure is kept in `sample`.  (It does
     not scale to the GPU host's 256 hardware threads: at "all" threads the many small ops oversubscribe and one B=4 step takes
-    minutes -- 5 frames/s measured -- so the default sweep stops at 32.)"""
+    minutes -- 5 frames/s measured -- so the sweep stops at 32.)"""
     have = os.cpu_count() or 1
     tried, seen = [], set()
-    for t in thread_list.split(","):
+    counts = [t for t in thread_list.split(",") if t.strip()]
+    for t in counts:
         n = have if t.strip() == "all" else min(int(t), have)
         if n in seen:
             continue
         seen.add(n)
-        v, th, note = cpu_baseline(nb, timed_steps, n)
+        v, th, note = cpu_baseline(nb, timed_steps, n, warm=warm, budget_s=(budget_s / len(counts)) if budget_s else None)
         tried.append((v, th, note))
     best = max(tried)
     return {"value": best[0], "unit": "mel-frames/s", "cores": best[1], "kind": "port",
             "sample": best[2] + "; thread sweep: " + ", ".join(f"{th} threads {v:.0f} frames/s" for v, th, _ in tried),
+            "protocol": f"SURVEY 8(d): B={nb}, {warm} warm + {timed_steps} timed steps" + (f", cut short by a {budget_s:.0f} s wall-clock budget when the host is slow" if budget_s else ""),
             "host_cpus": have}
 
 
@@ -191,42 +220,9 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7):
 
 
 def _selectors(precision):
-    """Launch classifiers for the roofline block.  MFMA: exactly the launches the dispatcher routes to the dominant kernel
-    (conv_gemm_bf16_glds_kernel: bf16 A and B, k-contiguous B, Cin % 64 == 0, N > 64, >= 160 tiles of 128x128; fused-phase
-    dgrad launches are the same kernel with blockIdx.z = output phase), algorithmic flops = 2 M taps Cin N.  HBM: the A1a-class
-    kernels north_star names, algorithmic bytes per launch as DESIGN.md section 4 states them."""
+    """Launch classifier for the HBM-bound A1a-class kernels north_star names (algorithmic bytes per launch as DESIGN.md section 4
+    states them); the matrix-core kernels are classified by the library itself (KernelTimer)."""
     M_DEC = B * T_MEL
-
-    def mfma(name, args):
-        if precision == "f32":
-            if name == "osp_conv_gemm_f32" and args[2] == M_DEC and args[4] * args[12] == 256 * 1024 and args[5] == 1:
-                return "glds", 2.0 * M_DEC * 256 * 1024
-            return None
-        if name == "osp_conv2d_gemm_bf16" and args[1] == 1 and args[18] == 1 and args[22] == 1 and args[8] % 64 == 0:
-            M_, N_ = args[3], args[23]
-            if N_ > 64 and -(-M_ // 128) * -(-N_ // 128) >= 160:
-                w8 = N_ >= 256 and -(-M_ // 256) * -(-N_ // 256) >= 160 and args[9] * args[8] >= 2304       # the dispatcher's 8-wave rule
-                return ("glds8" if w8 else "glds"), 2.0 * M_ * args[9] * args[8] * N_     # M, taps, Cin, N
-        if name == "osp_conv2d_dgrad_bf16" and args[1] == 1 and args[3] == 1:
-            U, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw = (args[6], args[7], args[8], args[11], args[12], args[13], args[14],
-                                                          args[15], args[16], args[17], args[18])
-            if Cout % 64 == 0 and Cin > 64 and Cout > 1:
-                fl, mmax, nph = 0.0, 0, 0
-                for rh in range(sh):
-                    for rw in range(sw):
-                        qh, qw = (H - rh + sh - 1) // sh, (W - rw + sw - 1) // sw
-                        if qh <= 0 or qw <= 0:
-                            continue
-                        n_h = (KH - (rh + ph) % sh + sh - 1) // sh
-                        n_w = (KW - (rw + pw) % sw + sw - 1) // sw
-                        fl += 2.0 * U * qh * qw * n_h * n_w * Cout * Cin
-                        mmax, nph = max(mmax, U * qh * qw), nph + 1
-                if -(-mmax // 128) * -(-Cin // 128) * nph >= 160:
-                    tmax = max(((KH - (rh + ph) % sh + sh - 1) // sh) * ((KW - (rw + pw) % sw + sw - 1) // sw)
-                               for rh in range(sh) for rw in range(sw))
-                    w8 = Cin >= 256 and -(-mmax // 256) * -(-Cin // 256) * nph >= 160 and tmax * Cout >= 2304
-                    return ("glds8" if w8 else "glds"), fl
-        return None
 
     def hbm(name, args):
         if name == "osp_dwconv7_ln_fwd":
@@ -241,9 +237,7 @@ def _selectors(precision):
             return "adamw_clip", args[4] * 28                   # p, g, m, v read; p, m, v written
         return None
 
-    def select(name, args):
-        return mfma(name, args) or hbm(name, args)
-    return select
+    return hbm
 
 
 def hbm_kernel_rooflines(model, dev, reps=50):
@@ -357,11 +351,14 @@ def main():
     from optispeech_amd.model import discriminator as _disc
     keep_streams, keep_graph, keep_pipe, keep_seg = _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments
     _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments = False, False, False, False
+    from optispeech_amd import ops as _ops
+    keep_wg, _ops._WG["on"] = _ops._WG["on"], False            # weight-gradient kernels inline too: events sit on the launch stream
     timer.enabled = True
     for i in range(3):
         model.training_step(batch, a.warmup + a.steps + i)
     sync()
     timer.enabled = False
+    _ops._WG["on"] = keep_wg
     _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments = keep_streams, keep_graph, keep_pipe, keep_seg
     ksum = timer.summary()
     # secondary figure: the acoustic-model-only step of the first `pretraining_steps` steps (no adversarial
@@ -447,37 +444,48 @@ def main():
     value = world * B * T_MEL / (dt / a.steps)
 
     if rank == 0:
-        roof_peak = PEAK_BF16_MFMA_TFLOPS if a.precision != "f32" else PEAK_F32_MFMA_TFLOPS
-        # the dominant kernel = whichever symbol of the direct-to-LDS conv-GEMM family spent more time in this run: the 8-wave
-        # 256x256 kernel (long-K DiscriminatorP layers at full batch) or the 4-wave 128x128 one (everything else >= 160 tiles)
-        # symbol the dispatcher launches for the 8-wave tile: the early-issue variant unless OSP_GEMM_W8_EARLY=0 (csrc/gemm_bf16.hip)
-        sym8 = "glds8e" if os.environ.get("OSP_GEMM_W8_EARLY", "1") != "0" else "glds8"
-        symof = {"glds8": sym8, "glds": "glds"}
-        names = {"glds8": f"conv_gemm_bf16_{sym8}_kernel (8 waves, 256x256 tiles: DiscriminatorP 512->1024 / 1024->1024 forward and dgrad at 2B waves)",
-                 "glds": "conv_gemm_bf16_glds_kernel (4 waves, 128x128 tiles: the remaining MPD / MRD conv-GEMM forward + fused-phase dgrad launches, N >= 128)"}
-        dom = max(("glds8", "glds"), key=lambda k: ksum.get(k, (0.0, 0.0, 0))[1])
-        roof_kernel = names[dom] if a.precision != "f32" else "conv_gemm_f32 (decoder pwconv1/pwconv2, M=25600, 256<->1024)"
-        flops, kms, nlaunch = ksum.get(dom, (0.0, 0.0, 0))
-        other = {k: ksum[k] for k in ("glds8", "glds") if k != dom and k in ksum}
-        roof = {"bound": "mfma", "kernel": roof_kernel,
-                "achieved": (flops / (kms * 1e-3) / 1e12) if kms else None, "peak": roof_peak,
-                "unit": "TFLOP/s", "traffic": None, "launches_timed": nlaunch,
-                "avg_launch_us": (kms / nlaunch * 1e3) if nlaunch else None,
-                "algorithmic_flop_per_launch": flops / nlaunch if nlaunch else None,
-                "how": "HIP events on the launch stream around each selected launch, 3 serialised eager steps right after the timed region"}
-        roof["frac"] = (roof["achieved"] / roof["peak"]) if roof["achieved"] else None
-        roof["symbol"] = "conv_gemm_bf16_%s_kernel" % symof[dom] if a.precision != "f32" else "conv_gemm_f32_kernel"
-        roof["other_mfma_kernels"] = {("conv_gemm_bf16_%s_kernel" % symof[k]): {"achieved": f / (ms * 1e-3) / 1e12, "frac": f / (ms * 1e-3) / 1e12 / roof_peak,
-                                                                         "avg_launch_us": ms / n * 1e3, "launches_timed": n,
-                                                                         "algorithmic_flop_per_launch": f / n}
-                                      for k, (f, ms, n) in other.items() if ms > 0}
+        # Every matrix-core symbol of the step, timed in the 3 serialised steps above and classified by the library's own
+        # dispatcher (KernelTimer); the roofline object is the symbol with the LARGEST TOTAL TIME, the others are listed beside it.
+        DESCR = {"conv_gemm_bf16_glds8e_kernel": "8 waves, 256x256 tiles, direct-to-LDS: DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
+                 "conv_gemm_bf16_glds_kernel": "4 waves, 128x128 tiles, direct-to-LDS: the remaining MPD / MRD conv-GEMM forward + dgrad launches (N >= 128)",
+                 "conv_gemm_bf16_glds_n64_kernel": "4 waves, 128x64 tiles, direct-to-LDS: the 64-channel DiscriminatorR layers",
+                 "conv_wgrad_bf16_tr8_kernel": "8 waves, 256x256 weight-gradient tiles (transposed LDS reads): DiscriminatorP 512->1024 / 1024->1024",
+                 "conv_wgrad_bf16_tr_kernel<128>": "weight gradients, 128-channel tiles", "conv_wgrad_bf16_tr_kernel<64>": "weight gradients, 64-channel tiles (DiscriminatorR)",
+                 "conv_wgrad_bf16_tr_kernel<64,f32>": "generator weight gradients (f32 operands through registers)",
+                 "conv_gemm_f32_kernel": "exact-f32 MFMA: the index-critical path (text encoder, alignment, duration predictor) and the f32 / mixed modes",
+                 "conv_gemm_bf16_s64_kernel": "small-problem 64x64 kernel (bf16 A)", "conv_gemm_bf16_s64_a32_kernel": "small-problem 64x64 kernel (f32 A)"}
+        F32_SYMS = ("conv_gemm_f32_kernel", "conv_wgrad_f32_kernel")
+        nroof = 3                                                 # serialised steps the events cover
+        mf = {k[5:]: v for k, v in ksum.items() if k.startswith("mfma:") and v[1] > 0}
+        table = {}
+        for sym, (fl, ms, n) in mf.items():
+            peak = PEAK_F32_MFMA_TFLOPS if sym in F32_SYMS else PEAK_BF16_MFMA_TFLOPS
+            ach = fl / (ms * 1e-3) / 1e12
+            table[sym] = {"ms_per_step": ms / nroof, "launches_per_step": n / nroof, "avg_launch_us": ms / n * 1e3, "achieved": ach, "peak": peak,
+                          "frac": ach / peak, "algorithmic_flop_per_launch": fl / n, "what": DESCR.get(sym, "")}
+        dom = max(table, key=lambda k: table[k]["ms_per_step"]) if table else None
+        roof = {"bound": "mfma", "symbol": dom, "kernel": (dom + " (" + DESCR.get(dom, "") + ")") if dom else None,
+                "achieved": table[dom]["achieved"] if dom else None, "peak": table[dom]["peak"] if dom else PEAK_BF16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": table[dom]["frac"] if dom else None, "traffic": None,
+                "launches_timed": mf[dom][2] if dom else 0, "avg_launch_us": table[dom]["avg_launch_us"] if dom else None,
+                "algorithmic_flop_per_launch": table[dom]["algorithmic_flop_per_launch"] if dom else None,
+                "how": "HIP events on the launch stream around every entry-point call of 3 serialised eager steps right after the timed "
+                       "region (sub-discriminator streams, vocoder stream and side weight-gradient streams off); symbol and algorithmic "
+                       "flops (2 M taps Cin N) reported by the library's dispatcher (osp_kernel_note_host); the dominant kernel = the "
+                       "symbol with the largest total time",
+                "mfma_kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] >= 0.2},
+                "mfma_ms_per_step_total": sum(v["ms_per_step"] for v in table.values())}
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read inside this run);
         # what is reported here is the committed summary of that pass, named so, never a live measurement
         pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-        if a.precision == "bf16" and not a.ragged and os.path.exists(pmc):
+        if a.precision != "f32" and not a.ragged and os.path.exists(pmc) and dom:
             with open(pmc) as fh:
                 pj = json.load(fh)
-            pj = pj.get(roof["symbol"], pj)
+            for sym, row in roof["mfma_kernels"].items():
+                hit = pj.get(sym.split("<")[0])
+                if hit:
+                    row["traffic"], row["l2_hit_rate"] = hit.get("traffic_bytes_per_launch"), hit.get("l2_hit_rate")
+            pj = pj.get(dom.split("<")[0], {})
             roof["traffic"] = pj.get("traffic_bytes_per_launch")
             roof["l2_hit_rate"] = pj.get("l2_hit_rate")
             roof["traffic_unit"] = "bytes/launch, read from profiles/" + PMC_SUMMARY + " (separate --pmc pass: TCC_EA0 read x 128 B + write x 64 B)"
@@ -485,10 +493,8 @@ def main():
         roof["hbm_kernels"] = hbm_kernel_rooflines(model, dev) if a.precision == "bf16" else {}
         cpu = None
         if not a.no_cpu_baseline and secondary:
-            if a.cpu_full:
-                cpu = cpu_baseline_sweep(B, 3, "8,32")
-            else:
-                cpu = cpu_baseline_sweep(a.cpu_batch, a.cpu_steps, a.cpu_threads)
+            cpu = cpu_baseline_sweep(a.cpu_batch, a.cpu_steps, a.cpu_threads, warm=a.cpu_warm,
+                                     budget_s=None if a.cpu_full else a.cpu_budget)
         sched = ("hipGraph replay (one graph per step)" if world == 1 else "hipGraph replay (5 segments, RCCL all-reduces between them)") \
             if model.graph_steps else (("eager multi-stream step" + (", serial" if a.no_pipeline else ", pipelined (pipeline_steps)")
                                         + (", acoustic model + vocoder forward / backward replayed from hipGraph segments" if model.graph_segments else "")))

@@ -209,21 +209,32 @@ __global__ __launch_bounds__(64) void mas_kernel(const float* __restrict__ lp, c
     if (T <= 0 || N <= 0) return;
 
     double q[R];
-    float nxt[R];
     float acc0 = 0.f;
+    // The recursion is T dependent steps of ~0.1 us of arithmetic each; a row of log-probabilities requested ONE step ahead
+    // (round 2) arrives after ~0.5-1 us, i.e. every step waited for memory (0.46 ms for T = 800 -- on the critical chain of the
+    // training step).  Now the rows of the next PD frames are in flight: a ring of PD register rows, loop unrolled by PD.
+    constexpr int PD = 8;
+    float pre[PD][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        q[r] = -INFINITY;
-        const int i = r * 64 + lane;
-        nxt[r] = i < N ? L[i] : 0.f;                                   // row j = 0
-    }
-    for (int j = 0; j < T; ++j) {
+    for (int k = 0; k < PD; ++k)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = r * 64 + lane;
+            pre[k][r] = (k < T && i < N) ? L[(int64_t)k * Nm + i] : 0.f;
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r) q[r] = -INFINITY;
+    for (int j0 = 0; j0 < T; j0 += PD) {
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {
+        const int j = j0 + k;
+        if (j >= T) break;                                             // wave-uniform
         float cur[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            cur[r] = nxt[r];
+            cur[r] = pre[k][r];
             const int i = r * 64 + lane;
-            nxt[r] = (j + 1 < T && i < N) ? L[(int64_t)(j + 1) * Nm + i] : 0.f;   // prefetch next frame
+            pre[k][r] = (j + PD < T && i < N) ? L[(int64_t)(j + PD) * Nm + i] : 0.f;   // frame j + PD takes the slot
         }
         double qn[R];
         double carry = 0.0;   // lane 63 of the previous round (column j-1)
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(64) void mas_kernel(const float* __restrict__ lp, c
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) q[r] = qn[r];
+      }
     }
     __syncthreads();   // single wave: orders the LDS / global bit stores before lane 0 reads them
     if (lane == 0) {

@@ -13,6 +13,30 @@ void osp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* osp_last_error() { return g_err; }
+
+// ---- measurement aid (bench.py's roofline block): which matrix-core kernel did the last entry-point call of this thread
+// launch, and how many algorithmic flops (2 * M * taps * Cin * N, summed over the launches of the call) did it stand for?  The
+// dispatchers know both; mirroring their selection rules in Python went stale once already (the bench bracketed
+// 35 of the 47 launches of a symbol).  Two thread-local words, written by the launch helpers, cost nothing on the hot path.
+#include <stdint.h>
+#include <string.h>
+static thread_local const char* g_note_sym = nullptr;
+static thread_local double g_note_flops = 0.0;
+void osp_note_symbol(const char* sym) { g_note_sym = sym; }
+void osp_note_flops(double flops) { g_note_flops += flops; }
+// name_host: buffer of `cap` bytes for the symbol ("" when the call launched no noted kernel); flops_host: one double.
+// The note is cleared by the read, so call it right after the entry point it asks about.
+extern "C" int osp_kernel_note_host(char* name_host, int64_t cap, double* flops_host) {
+    if (name_host && cap > 0) {
+        const char* sname = g_note_sym ? g_note_sym : "";
+        strncpy(name_host, sname, (size_t)cap - 1);
+        name_host[cap - 1] = 0;
+    }
+    if (flops_host) *flops_host = g_note_flops;
+    g_note_sym = nullptr;
+    g_note_flops = 0.0;
+    return 0;
+}
 extern "C" int osp_abi_version() { return 1; }
 
 // Content hash of the sources (and flags) this library was compiled from: optispeech_amd/build.py passes it on the command line

@@ -240,6 +240,50 @@ extern "C" int osp_layernorm_fwd(const float* x, const float* w, const float* b,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Two-stage reduction of the parameter-gradient rows of the backward kernels below (round 3).
+// Round 2 let every persistent workgroup add its partial rows into the gradient arena with device-scope float atomics: 256
+// workgroups x 512 (LayerNorm) / 2 560 (fused LN + dwconv) addresses.  The L2s of the 8 XCDs are not coherent with each other,
+// so those atomics execute at the memory side: 8-12 us of a 25-41 us kernel, and -- worse -- the reason the grids were capped
+// at one workgroup per CU (4-8 waves per CU: a streaming kernel needs several times that to cover HBM latency).
+// Now: stage 1, every workgroup STORES its partial rows (plain streaming stores) to ws[workgroup][ncols]; stage 2, a small
+// kernel sums 64 partials per workgroup and column with 16-byte loads and adds the result to the destination rows with one
+// atomic per column and 64 partials (ncols * parts / 64 atomics in total: a few thousand instead of 131 k - 655 k).  The kernel
+// boundary is what makes stage 1's stores visible: no fences, no tickets.
+struct PartialDst { float* p[4]; int n[4]; };           // columns [0, n0) -> p[0], [n0, n0 + n1) -> p[1], ...
+// Stage 2: grid (column blocks of 64, groups of RED_PARTS partial rows); a workgroup = 16 column quads x 16 part lanes, each thread
+// sums RED_PARTS / 16 partials of its quad with 16-byte loads, the part lanes meet in LDS, one atomic per column and group.
+#define RED_PARTS 32
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nparts, int ncols, PartialDst d) {
+    __shared__ float4 red[16][16];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    const int p0 = blockIdx.y * RED_PARTS, p1 = min(nparts, p0 + RED_PARTS);
+    float4 acc = f4zero();
+    if (c < ncols)
+        for (int q = p0 + pl; q < p1; q += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)q * ncols + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    red[pl][cq] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int q4 = threadIdx.x >> 2, e = threadIdx.x & 3, col = blockIdx.x * 64 + threadIdx.x;
+        if (col < ncols) {
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const float4 v = red[k][q4]; r += e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+            int seg = 0, off = 0;
+            while (seg < 3 && col >= off + d.n[seg]) { off += d.n[seg]; ++seg; }
+            if (d.p[seg]) atomicAdd(d.p[seg] + (col - off), r);
+        }
+    }
+}
+static void launch_reduce_partials(const float* ws, int nparts, int ncols, const PartialDst& d, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(ncols, 64), (unsigned)cdiv(nparts, RED_PARTS)), dim3(256), 0, stream,
+                       ws, nparts, ncols, d);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // LayerNorm backward.  g = dy * dropout * rowmask;  xhat = xin (mean == null) or (xin - mean)*rstd;
 //   dx = rstd * (g*w - mean_C(g*w) - xhat * mean_C(g*w*xhat))  [* (relu_src > 0) if given]
 //   dlnw += sum_rows g * xhat ; dlnb += sum_rows g
@@ -250,7 +294,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rowmask, float drop_p, uint64_t seed,
                                                             const int64_t* __restrict__ seed_dev, uint32_t stream_id, float* __restrict__ dx,
                                                             float* __restrict__ dlnw, float* __restrict__ dlnb,
-                                                            int64_t rows, int C) {
+                                                            float* __restrict__ ws, int64_t rows, int C) {
     __shared__ float red[2][4][256 * NCH];   // [w|b][wave][channel-in-lane-order]
     if (seed_dev) seed += (uint64_t)*seed_dev;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -341,29 +385,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         *reinterpret_cast<float4*>(&red[1][wave][k * 256 + lane * 4]) = ab[k];
     }
     __syncthreads();
+    float* part = ws ? ws + (int64_t)blockIdx.x * 2 * C : nullptr;       // stage 1 of the two-stage reduction (see above)
     for (int ch = threadIdx.x; ch < C; ch += 256) {
         const float a = red[0][0][ch] + red[0][1][ch] + red[0][2][ch] + red[0][3][ch];
         const float bsum = red[1][0][ch] + red[1][1][ch] + red[1][2][ch] + red[1][3][ch];
-        atomicAdd(dlnw + ch, a);
-        atomicAdd(dlnb + ch, bsum);
+        if (part) { part[ch] = a; part[C + ch] = bsum; }
+        else { atomicAdd(dlnw + ch, a); atomicAdd(dlnb + ch, bsum); }
     }
 }
 
+// ws (optional): ws_blocks * 2 * C floats of scratch for the two-stage parameter-gradient reduction; with it the grid is
+// min(rows / (4 * FRAMES), ws_blocks) workgroups (many waves per CU), without it at most 256 (device-scope atomics per workgroup).
 extern "C" int osp_layernorm_bwd(const float* dy, const float* xin, const float* mean, const float* rstd,
                                  const float* w, const float* relu_src, const float* rowmask, float drop_p,
                                  int64_t seed, const int64_t* seed_dev, int64_t stream_id, float* dx, float* dlnw, float* dlnb, int64_t rows,
-                                 int64_t C, hipStream_t stream) {
+                                 int64_t C, float* ws, int64_t ws_blocks, hipStream_t stream) {
     OSP_CHECK_ARG(dy && xin && rstd && w && dx, "null operand");
     OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr), "dlnw/dlnb come together");
     OSP_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXCH, "C must be a multiple of 4, <= 1024");
-    const int64_t blocks = cdiv(rows, 4 * FRAMES);   // FRAMES rows per wave => few atomics
+    OSP_CHECK_ARG(!ws || ws_blocks > 0, "ws needs ws_blocks > 0");
+    const int64_t blocks = cdiv(rows, 4 * FRAMES);   // FRAMES rows per wave
     static int64_t lnb_cap = 0;
-    if (!lnb_cap) { const char* e = getenv("OSP_LNBWD_WG"); lnb_cap = e ? atoll(e) : 256; }      // tools/lndw_probe.py at 32 x 800 x 256, two rows in flight: caps 256 / 512 / 1024 = 25.0 / 26.8 / 31.3 us (the device-scope atomics of the parameter gradients cost more than the lost latency hiding)
-    dim3 grid((unsigned)(blocks < lnb_cap ? blocks : lnb_cap));
+    if (!lnb_cap) { const char* e = getenv("OSP_LNBWD_WG"); lnb_cap = e ? atoll(e) : 256; }      // atomics path: tools/lndw_probe.py at 32 x 800 x 256, caps 256 / 512 / 1024 = 25.0 / 26.8 / 31.3 us
+    const bool two_stage = ws && dlnw;
+    const int64_t cap = two_stage ? ws_blocks : (dlnw ? lnb_cap : 4096);
+    dim3 grid((unsigned)(blocks < cap ? blocks : cap));
     const int nch = (int)cdiv(C, 256);
-#define L(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), grid, dim3(256), 0, stream, dy, xin, mean, rstd, w, relu_src, rowmask, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, dx, dlnw, dlnb, rows, (int)C)
+#define L(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), grid, dim3(256), 0, stream, dy, xin, mean, rstd, w, relu_src, rowmask, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id, dx, dlnw, dlnb, two_stage ? ws : nullptr, rows, (int)C)
     if (nch == 1) L(1); else if (nch == 2) L(2); else if (nch == 3) L(3); else L(4);
 #undef L
+    if (two_stage) {
+        PartialDst d = {{dlnw, dlnb, nullptr, nullptr}, {(int)C, (int)C, 0, 0}};
+        launch_reduce_partials(ws, (int)grid.x, 2 * (int)C, d, stream);
+    }
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
@@ -481,7 +535,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void ln_dwconv7_bwd_kernel(const
                                                              const float* __restrict__ x, const float* __restrict__ dw,
                                                              const float* __restrict__ dres, const float* __restrict__ dres_rowmask,
                                                              float* __restrict__ dx, float* __restrict__ dlnw, float* __restrict__ dlnb,
-                                                             float* __restrict__ ddw, float* __restrict__ ddb, int B, int T, int C) {
+                                                             float* __restrict__ ddw, float* __restrict__ ddb, float* __restrict__ ws,
+                                                             int B, int T, int C) {
     __shared__ float red[NWV][10][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int runs_per_utt = (T + FR - 1) / FR, nruns = B * runs_per_utt;
@@ -583,24 +638,156 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void ln_dwconv7_bwd_kernel(const
     for (int j = 0; j < 10; ++j)
         *reinterpret_cast<float4*>(&red[wave][j][lane * 4]) = j < 7 ? gwt[j] : j == 7 ? gb : j == 8 ? aw : ab;
     __syncthreads();
+    float* part = ws ? ws + (int64_t)blockIdx.x * 10 * C : nullptr;      // stage 1 of the two-stage reduction: rows [7 taps | ddb | dlnw | dlnb]
     for (int i = threadIdx.x; i < 10 * 256; i += 64 * NWV) {
         const int j = i >> 8, c = i & 255;
         float* dst = j < 7 ? (ddw ? ddw + (int64_t)j * C : nullptr) : j == 7 ? ddb : j == 8 ? dlnw : dlnb;
-        if (dst && c < C) {
+        if (c < C && (dst || part)) {
             float sum = 0.f;
 #pragma unroll
             for (int q = 0; q < NWV; ++q) sum += red[q][j][c];
-            atomicAdd(dst + c, sum);
+            if (part) part[(int64_t)j * C + c] = sum;
+            else atomicAdd(dst + c, sum);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: the same fused backward as a TILE kernel.  The run kernel above re-reads 2.5 rows per frame of dh / xhat / x (a run of
+// FR = 4 frames needs FR + 6 rows of each), keeps three 10-row windows in registers (248 VGPRs = 8 waves per CU) and walks its
+// three load bursts one after the other: 52-55 % of the HBM roofline even without parameter gradients.  Here a workgroup of 8
+// waves owns a tile of up to LT_ROWS - 6 consecutive frames of one utterance and shares the halo through LDS:
+//   phase 1  the tile's nrows + 6 window rows are dealt round-robin to the waves; a wave requests all its dh / xhat / x rows at
+//            once, rebuilds dc (two wave reductions per row) and parks dc and x in LDS -- every input row is fetched ONCE per tile
+//            ((26 + 6) / 26 = 1.23 rows per frame instead of 2.5);
+//   phase 2  the owned frames are dealt round-robin again: dx[t] = dres[t] + sum_j w[j] dc[t - j + 3] and the tap gradients
+//            ddw[j] += dc[t] x[t + j - 3] read dc / x rows out of LDS (14 ds_read_b128 per frame and lane).
+// No windows in registers: <= 128 VGPRs, two workgroups = 16 waves per CU; while one workgroup computes out of LDS the other
+// one's loads are in flight.  Persistent workgroups (at most 2 per CU), parameter-gradient rows -> per-workgroup partials ->
+// reduce_partials_kernel (no atomics here).  Algorithmic bytes per frame as before: 5 * C * 4.
+#define LT_ROWS 32
+#define LT_NWV 8
+__global__ __launch_bounds__(64 * LT_NWV, 4) void ln_dwconv7_bwd_tile_kernel(const float* __restrict__ dh, const float* __restrict__ xhat,
+                                                             const float* __restrict__ rstd, const float* __restrict__ lnw,
+                                                             const float* __restrict__ x, const float* __restrict__ dw,
+                                                             const float* __restrict__ dres, const float* __restrict__ dres_rowmask,
+                                                             float* __restrict__ dx, float* __restrict__ dlnw, float* __restrict__ dlnb,
+                                                             float* __restrict__ ddw, float* __restrict__ ddb, float* __restrict__ ws,
+                                                             int B, int T, int C, int TR, int tiles_per_utt) {
+    __shared__ __attribute__((aligned(16))) float dcs[LT_ROWS][256];
+    __shared__ __attribute__((aligned(16))) float xs[LT_ROWS][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ch = lane * 4;
+    const bool chan = ch < C;
+    const int chs = chan ? ch : 0;
+    const float invC = 1.0f / (float)C;
+    const float4 gw = chan ? *reinterpret_cast<const float4*>(lnw + chs) : f4zero();
+    // the 7 taps live in LDS (28 VGPRs otherwise: with them the kernel spills at the 128-VGPR budget of 16 waves per CU)
+    __shared__ __attribute__((aligned(16))) float wsm[7][256];
+    if (wave < 7) *reinterpret_cast<float4*>(&wsm[wave][lane * 4]) = chan ? *reinterpret_cast<const float4*>(dw + (int64_t)wave * C + chs) : f4zero();
+    float4 gwt[7], gb = f4zero(), aw = f4zero(), ab = f4zero();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) gwt[j] = f4zero();
+    const bool want_taps = ddw != nullptr;                              // kernel-uniform
+    const int ntiles = B * tiles_per_utt;
+    constexpr int RPW = LT_ROWS / LT_NWV;                               // window rows per wave (4)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_utt, t0 = (tile - b * tiles_per_utt) * TR;
+        const int nrows = min(TR, T - t0);
+        const int64_t base = (int64_t)b * T * C;
+        // ---- phase 1: window row r <-> frame t0 + r - 3, r = wave + LT_NWV * i
+        float4 d[RPW], v[RPW], xr[RPW];
+        float rs[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + LT_NWV * i, t = t0 + r - 3;
+            const bool in = r < nrows + 6 && t >= 0 && t < T;
+            const int64_t off = base + (int64_t)(in ? t : t0) * C + chs;
+            d[i] = *reinterpret_cast<const float4*>(dh + off);
+            v[i] = *reinterpret_cast<const float4*>(xhat + off);
+            xr[i] = *reinterpret_cast<const float4*>(x + off);
+            rs[i] = in ? rstd[(int64_t)b * T + t] : 0.f;              // rows outside the utterance are the conv's zero padding
+            if (!(in && chan)) { d[i] = f4zero(); v[i] = f4zero(); xr[i] = f4zero(); }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + LT_NWV * i;
+            if (r >= nrows + 6) continue;                               // wave-uniform
+            const float4 dd = d[i], vv = v[i];
+            if (r >= 3 && r < nrows + 3) {                              // owned frame: LayerNorm parameter gradients
+                aw = f4fma(dd, vv, aw);
+                ab.x += dd.x; ab.y += dd.y; ab.z += dd.z; ab.w += dd.w;
+            }
+            const float4 g = make_float4(dd.x * gw.x, dd.y * gw.y, dd.z * gw.z, dd.w * gw.w);
+            const float m1 = wave_sum(f4sum(g)) * invC;
+            const float m2 = wave_sum(g.x * vv.x + g.y * vv.y + g.z * vv.z + g.w * vv.w) * invC;
+            const float sc = rs[i];
+            const float4 c = chan ? make_float4(sc * (g.x - m1 - vv.x * m2), sc * (g.y - m1 - vv.y * m2), sc * (g.z - m1 - vv.z * m2),
+                                                sc * (g.w - m1 - vv.w * m2)) : f4zero();
+            *reinterpret_cast<float4*>(&dcs[r][lane * 4]) = c;
+            *reinterpret_cast<float4*>(&xs[r][lane * 4]) = xr[i];
+        }
+        __syncthreads();
+        // ---- phase 2: owned frame f <-> window row f + 3.  The residual rows are requested first (all of them, then consumed: the
+        // registers of phase 1 are free again; requesting them before the barrier spilled at the 128-VGPR budget)
+        float4 dr[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f = wave + LT_NWV * i;
+            const bool in = f < nrows;
+            dr[i] = f4zero();
+            if (dres && in && chan) {
+                const float4 q = *reinterpret_cast<const float4*>(dres + base + (int64_t)(t0 + f) * C + ch);
+                const float rm = dres_rowmask ? dres_rowmask[(int64_t)b * T + t0 + f] : 1.f;
+                dr[i] = make_float4(q.x * rm, q.y * rm, q.z * rm, q.w * rm);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f = wave + LT_NWV * i;
+            if (f >= nrows) continue;                                   // wave-uniform
+            float4 a = dr[i];
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                a = f4fma(*reinterpret_cast<const float4*>(&wsm[j][lane * 4]), *reinterpret_cast<const float4*>(&dcs[f + 6 - j][lane * 4]), a);   // w[j] dc[t - j + 3]
+            if (chan) st_stream(reinterpret_cast<float4*>(dx + base + (int64_t)(t0 + f) * C + ch), a);
+            if (want_taps) {
+                const float4 d0 = *reinterpret_cast<const float4*>(&dcs[f + 3][lane * 4]);                             // dc[t]
+#pragma unroll
+                for (int j = 0; j < 7; ++j) gwt[j] = f4fma(d0, *reinterpret_cast<const float4*>(&xs[f + j][lane * 4]), gwt[j]);   // x[t + j - 3]
+                gb.x += d0.x; gb.y += d0.y; gb.z += d0.z; gb.w += d0.w;
+            }
+        }
+        __syncthreads();                                                // the next tile overwrites dcs / xs
+    }
+    if (!ddw && !dlnw) return;                                          // kernel-uniform
+    // parameter-gradient rows [7 taps | ddb | dlnw | dlnb]: per-wave partials -> LDS (dcs re-used: 8 waves x 256 floats per row),
+    // one row at a time, -> the workgroup's partial row in ws (two-stage reduction) or atomics
+    float* part = ws ? ws + (int64_t)blockIdx.x * 10 * C : nullptr;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const float4 val = j < 7 ? gwt[j] : j == 7 ? gb : j == 8 ? aw : ab;
+        *reinterpret_cast<float4*>(&dcs[wave][lane * 4]) = val;
+        __syncthreads();
+        float* dst = j < 7 ? (ddw ? ddw + (int64_t)j * C : nullptr) : j == 7 ? ddb : j == 8 ? dlnw : dlnb;
+        if (threadIdx.x < 256 && (int)threadIdx.x < C && (dst || part)) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < LT_NWV; ++q) sum += dcs[q][threadIdx.x];
+            if (part) part[(int64_t)j * C + threadIdx.x] = sum;
+            else atomicAdd(dst + threadIdx.x, sum);
+        }
+        __syncthreads();
     }
 }
 
 extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const float* rstd, const float* lnw, const float* x,
                                   const float* dw, const float* dres, const float* dres_rowmask, float* dx, float* dlnw, float* dlnb,
-                                  float* ddw, float* ddb, int64_t B, int64_t T, int64_t C, hipStream_t stream) {
+                                  float* ddw, float* ddb, int64_t B, int64_t T, int64_t C, float* ws, int64_t ws_blocks, hipStream_t stream) {
     OSP_CHECK_ARG(dh && xhat && rstd && lnw && x && dw && dx, "null operand");
     OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr) && (ddw == nullptr) == (ddb == nullptr), "dlnw/dlnb and ddw/ddb come in pairs");
     OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256, "C must be a multiple of 4, <= 256 (wider blocks: osp_layernorm_bwd + osp_dwconv7_bwd)");
+    OSP_CHECK_ARG(!ws || ws_blocks > 0, "ws needs ws_blocks > 0");
     static int fr = -1;
     if (fr < 0) { const char* e = getenv("OSP_LNDW_FR"); fr = e ? atoi(e) : 4; }      // tools/lndw_probe.py at 32 x 800 x 256: FR 4 / 6 / 8 = 41.9 / 49.7 / 50.6 us (8 spills: 256-VGPR cap for two workgroups / CU)
     // 256 VGPRs per thread: 8 waves per CU are resident, as one workgroup of 8 waves (256 workgroups: half the atomics per address)
@@ -608,9 +795,33 @@ extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const floa
     static int nwv = -1, maxwg = -1;
     if (nwv < 0) { const char* e = getenv("OSP_LNDW_NWV"); nwv = (e && atoi(e) == 4) ? 4 : 8; }
     if (maxwg < 0) { const char* e = getenv("OSP_LNDW_WG"); maxwg = e ? atoi(e) : 2048 / nwv; }
-#define L(F, W) hipLaunchKernelGGL((ln_dwconv7_bwd_kernel<F, W>), dim3((unsigned)(cdiv(B * cdiv(T, F), W) < maxwg ? cdiv(B * cdiv(T, F), W) : maxwg)), dim3(64 * W), 0, stream, dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, (int)B, (int)T, (int)C)
+    const bool two_stage = ws && (dlnw || ddw);
+    static int tile_v = -1;
+    if (tile_v < 0) { const char* e = getenv("OSP_LNDW_TILE"); tile_v = (e && atoi(e) == 0) ? 0 : 1; }
+    if (tile_v) {
+        // tile kernel (round 3): tiles of TR <= LT_ROWS - 6 frames, equal within an utterance; persistent workgroups, 2 per CU
+        const int64_t tpu = cdiv(T, LT_ROWS - 6), TR = cdiv(T, tpu), ntiles = B * tpu;
+        int64_t nb = ntiles < 512 ? ntiles : 512;
+        if (two_stage && nb > ws_blocks) nb = ws_blocks;
+        hipLaunchKernelGGL(ln_dwconv7_bwd_tile_kernel, dim3((unsigned)nb), dim3(64 * LT_NWV), 0, stream, dh, xhat, rstd, lnw, x, dw, dres,
+                           dres_rowmask, dx, dlnw, dlnb, ddw, ddb, two_stage ? ws : nullptr, (int)B, (int)T, (int)C, (int)TR, (int)tpu);
+        if (two_stage) {
+            PartialDst d = {{ddw, ddb, dlnw, dlnb}, {7 * (int)C, (int)C, (int)C, (int)C}};
+            launch_reduce_partials(ws, (int)nb, 10 * (int)C, d, stream);
+        }
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
+    const int64_t cap = two_stage ? (ws_blocks < maxwg ? ws_blocks : maxwg) : maxwg;
+    unsigned nblk = 0;
+#define L(F, W) do { nblk = (unsigned)(cdiv(B * cdiv(T, F), W) < cap ? cdiv(B * cdiv(T, F), W) : cap); \
+        hipLaunchKernelGGL((ln_dwconv7_bwd_kernel<F, W>), dim3(nblk), dim3(64 * W), 0, stream, dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, two_stage ? ws : nullptr, (int)B, (int)T, (int)C); } while (0)
     if (nwv == 8) { if (fr == 8) L(8, 8); else L(4, 8); } else { if (fr == 8) L(8, 4); else L(4, 4); }
 #undef L
+    if (two_stage) {
+        PartialDst d = {{ddw, ddb, dlnw, dlnb}, {7 * (int)C, (int)C, (int)C, (int)C}};
+        launch_reduce_partials(ws, (int)nblk, 10 * (int)C, d, stream);
+    }
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

@@ -247,6 +247,8 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_kernel(GemmP p) {
 template <int BM, int BN>
 static int launch_gemm(const GemmP& p, int b_kcontig, int batch, hipStream_t stream) {
     dim3 grid((unsigned)cdiv(p.N, BN), (unsigned)cdiv(p.M, BM), (unsigned)batch);
+    osp_note_symbol("conv_gemm_f32_kernel");                            // measurement aid (api.cpp)
+    osp_note_flops(2.0 * p.M * p.taps * (double)p.Cin * p.N * batch);
     if (b_kcontig)
         hipLaunchKernelGGL((conv_gemm_f32_kernel<BM, BN, true>), grid, dim3(256), 0, stream, p);
     else
@@ -437,6 +439,8 @@ extern "C" int osp_conv_wgrad_f32(const float* dY, int64_t ldy, const float* X, 
     p.chunk = (int)chunk;
     p.splits = (int)splits;
     dim3 grid((unsigned)cdiv(N, bmo), (unsigned)(taps * cdiv(Cin, bmo)), (unsigned)(splits * batch));
+    osp_note_symbol("conv_wgrad_f32_kernel");
+    osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);
     if (big) hipLaunchKernelGGL((conv_wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_f32_kernel<64, 64>), grid, dim3(256), 0, stream, p);
     OSP_LAUNCH_CHECK();

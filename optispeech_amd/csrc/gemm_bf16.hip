@@ -127,8 +127,12 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         if constexpr (L1 - L0 > 1) issue_one(buf, std::integral_constant<int, L0 + 1>{});
         if constexpr (L1 - L0 > 2) issue_one(buf, std::integral_constant<int, L0 + 2>{});
     };
-    auto issue_begin = [&]() { set_tap(is_j, is_cb); };
-    auto issue_end = [&]() { ++is_j; if (is_j == taps) { is_j = 0; is_cb += TBK; } };
+    // The source pointers of a slab are computed right AFTER the previous slab's loads were issued (issue_end), i.e. in the
+    // shadow of that iteration's remaining MFMAs -- computed at the top of the iteration they delayed its first loads and
+    // first MFMA (8-wave kernel: 128 -> 139 us per launch when this order was introduced).
+    auto issue_begin = [&]() {};
+    auto issue_end = [&]() { ++is_j; if (is_j == taps) { is_j = 0; is_cb += TBK; } if (is_cb < Cin) set_tap(is_j, is_cb); };
+    set_tap(0, 0);
     auto issue = [&](int buf) {
         issue_begin();
         issue_quarter(buf, std::integral_constant<int, 0>{}); issue_quarter(buf, std::integral_constant<int, 1>{});
@@ -173,8 +177,9 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
                 }
         };
         kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
+        if constexpr (EARLY) { if (ld >= 0) issue_end(); }              // all loads of the slab are out: next pointers under k-steps 2-3
         kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
-        if (ld >= 0) issue_end();
+        if constexpr (!EARLY) { if (ld >= 0) issue_end(); }
     };
     const int nk = K / TBK;
     if constexpr (NST == 2) {
@@ -413,6 +418,12 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
     const void *A = p.A, *B = p.B;
     const float* a_rowscale = p.a_rowscale;
     const int64_t batch = p.nphase > 0 ? p.nphase : batch_in;          // grid z
+    {   // algorithmic flops of this launch (measurement aid, api.cpp)
+        double fl = 0.0;
+        if (p.nphase > 0) for (int i = 0; i < p.nphase; ++i) fl += 2.0 * p.ph[i].M * p.ph[i].taps * (double)Cin * N;
+        else fl = 2.0 * M * taps * (double)Cin * N * batch_in;
+        osp_note_flops(fl);
+    }
     const bool single = p.nphase == 0 && batch_in == 1;                  // the degenerate-shape kernels take one problem
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const int64_t ea = a_bf16 ? 2 : 4, eb = b_bf16 ? 2 : 4;
@@ -430,6 +441,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         const int64_t nb = cdiv(M, 256 / L);
         const dim3 grid((unsigned)(nb < 4096 ? nb : 4096));
         const size_t lds = (size_t)taps * Cin * 2;
+        osp_note_symbol("conv_rowdot_bf16_kernel");
 #define OSP_ROWDOT(L_) hipLaunchKernelGGL((conv_rowdot_bf16_kernel<L_>), grid, dim3(256), lds, stream, p)
         switch (L) { case 64: OSP_ROWDOT(64); break; case 32: OSP_ROWDOT(32); break; case 16: OSP_ROWDOT(16); break;
                      case 8: OSP_ROWDOT(8); break; case 4: OSP_ROWDOT(4); break; case 2: OSP_ROWDOT(2); break; default: OSP_ROWDOT(1); }
@@ -439,6 +451,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
     }
     if (use_degen && Cin == 1 && single && !a_rowscale && taps <= OUTER_MAXT && N % 8 == 0 && N >= 8 && N <= 2048) {
         const int64_t rpb = 256 / (N / 8) > 0 ? 256 / (N / 8) : 1, nb = cdiv(M, rpb * 4);
+        osp_note_symbol("conv_outer_bf16_kernel");
         hipLaunchKernelGGL(conv_outer_bf16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, p);
         OSP_LAUNCH_CHECK();
         return OSP_OK;
@@ -470,6 +483,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * TBK * 2);
             attr64 = 1;
         }
+        osp_note_symbol("conv_gemm_bf16_glds_n64_kernel");
         hipLaunchKernelGGL(conv_gemm_bf16_glds_n64_kernel, grid, dim3(256), 2 * (128 + 64) * TBK * 2, stream, p);
         OSP_LAUNCH_CHECK();
         return OSP_OK;
@@ -498,6 +512,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
                 const char* e = getenv("OSP_GEMM_W8_EARLY"); early = (e && atoi(e) == 0) ? 0 : 1;      // +1..3 % in A/B runs (tools/gemm_quick.py)
                 hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8e_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
             }
+            osp_note_symbol(early ? "conv_gemm_bf16_glds8e_kernel" : "conv_gemm_bf16_glds8_kernel");
             if (early) hipLaunchKernelGGL(conv_gemm_bf16_glds8e_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
             else hipLaunchKernelGGL(conv_gemm_bf16_glds8_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
             OSP_LAUNCH_CHECK();
@@ -517,8 +532,10 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         // k-slab and the LDS latency of the first k-step are exposed.  Kept for the next round's 8-wave version.
         if (big && cdiv(M, 256) * cdiv(N, TBN) * batch >= 200) {
             const dim3 g256((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, 256), (unsigned)batch);
+            osp_note_symbol("conv_gemm_bf16_glds256_kernel");
             hipLaunchKernelGGL(conv_gemm_bf16_glds256_kernel, g256, dim3(256), 3 * (256 + TBN) * TBK * 2, stream, p);
         } else {
+            osp_note_symbol("conv_gemm_bf16_glds_kernel");
             hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), 2 * (128 + TBN) * TBK * 2, stream, p);
         }
         OSP_LAUNCH_CHECK();

@@ -63,9 +63,14 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pin) {
         if (p.a_rowscale) v *= p.a_rowscale[bz * p.M + row];
         return v;
     };
+    // K order: when the channel count is a whole number of k-tiles, slab kt = (channel block kt / taps, tap kt % taps) -- the
+    // channel-major order of the direct-to-LDS kernels (gemm_bf16.hip), so that a layer gives bit-identical results whichever
+    // member of the family its size selects (tests/test_gpu_fullsize.py); otherwise the flat tap-major index k = tap * Cin + c.
+    const bool cm = FAST && (p.Cin % BKT == 0);
     auto gload = [&](int kt) {
         const int k0 = kt * BKT + g * 8;
-        const int j0k = k0 / p.Cin, c0k = k0 - j0k * p.Cin, kh0 = (p.KW == p.taps) ? 0 : j0k / p.KW, kw0 = j0k - kh0 * p.KW;
+        const int j0k = cm ? kt % p.taps : k0 / p.Cin, c0k = cm ? (kt / p.taps) * BKT + g * 8 : k0 - j0k * p.Cin;
+        const int kh0 = (p.KW == p.taps) ? 0 : j0k / p.KW, kw0 = j0k - kh0 * p.KW;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -115,7 +120,8 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pin) {
                 const int k = kt * BKT + kg * 8 + q;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (kg < 8 && k < K && nn < p.N) {
-                    const int j = k / p.Cin, c = k - j * p.Cin, kh = j / p.KW, kw = j - kh * p.KW;
+                    const int j = cm ? kt % p.taps : k / p.Cin, c = cm ? (kt / p.taps) * BKT + kg * 8 + q : k - j * p.Cin;
+                    const int kh = j / p.KW, kw = j - kh * p.KW;
                     const int64_t off = (int64_t)c * p.sBk + (int64_t)kh * p.sBtap_h + (int64_t)kw * p.sBtap + nn;
                     if (FAST && nn + 3 < p.N) x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + off);
                     else {
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_kernel(const GemmB pin) {
 
 
 int osp_launch_gemm_reg(const GemmB& p, dim3 grid, int bm, int bn, bool b_kcontig, bool fast, bool bk32, hipStream_t stream) {
+    osp_note_symbol(bm == 128 && bn == 128 ? "conv_gemm_bf16_kernel<128x128>" : bm == 128 ? "conv_gemm_bf16_kernel<128x64>" : "conv_gemm_bf16_kernel<64x64>");
 #define OSP_LAUNCH_TILE(KC, F)                                                                                              \
     do {                                                                                                                    \
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_gemm_bf16_kernel<KC, 64, F, 128, 128>), grid, dim3(256), 0, stream, p); \

@@ -109,8 +109,10 @@ __device__ __forceinline__ void gemm_small_body(const GemmB& pp, unsigned char* 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + is_cb * b_inc[i]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        is_cb += TBK;
-        if (is_cb == Cin) { is_cb = 0; ++is_j; }
+        // channel block outer, tap inner: the K order of the whole bf16 conv-GEMM family (gemm_bf16.hip explains why); a layer
+        // must give bit-identical results whichever kernel its size selects
+        ++is_j;
+        if (is_j == taps) { is_j = 0; is_cb += TBK; }
     };
     const int l31 = lane & 31, lh = lane >> 5;
     const int arow = wm0 + l31, brow = wn0 + l31;
@@ -176,6 +178,7 @@ int osp_launch_gemm_small(const GemmB& p, int64_t batch, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_s64_a32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F);
         attr = 1;
     }
+    osp_note_symbol(p.a_bf16 ? "conv_gemm_bf16_s64_kernel" : "conv_gemm_bf16_s64_a32_kernel");
     if (p.a_bf16) hipLaunchKernelGGL(conv_gemm_bf16_s64_kernel, grid, dim3(256), LDS_B, stream, p);
     else hipLaunchKernelGGL(conv_gemm_bf16_s64_a32_kernel, grid, dim3(256), LDS_F, stream, p);
     OSP_LAUNCH_CHECK();

@@ -230,10 +230,23 @@ __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int
     const int tok = s >> 1;
     float* col[2] = {sh + 2, sh + (SW + 2) + 2};
     if (s < 2) { sh[s] = -INFINITY; sh[(SW + 2) + s] = -INFINITY; }
+    // Both recursions are T dependent steps (LDS exchange + barrier + three expf / one logf: ~0.15 us); round 2 also LOADED each
+    // step's emission -- and in the second pass the stored alpha -- inside the step, a full memory latency per step (1.7 ms for
+    // T = 800).  Now the values of the next CPD steps are in flight in a register ring (loops unrolled by CPD).
+    constexpr int CPD = 8;
+    auto emis = [&](int t) -> float { return live ? ((lab ? L[(int64_t)t * Nm + tok] : log_blank) - LW[t]) : -INFINITY; };
     // ---- alpha
     float a = -INFINITY;
-    for (int t = 0; t < T; ++t) {
-        const float y = live ? ((lab ? L[(int64_t)t * Nm + tok] : log_blank) - LW[t]) : -INFINITY;
+    float yq[CPD];
+#pragma unroll
+    for (int k = 0; k < CPD; ++k) yq[k] = k < T ? emis(k) : -INFINITY;
+    for (int t0 = 0; t0 < T; t0 += CPD) {
+#pragma unroll
+      for (int k = 0; k < CPD; ++k) {
+        const int t = t0 + k;
+        if (t >= T) break;                                              // block-uniform
+        const float y = yq[k];
+        yq[k] = t + CPD < T ? emis(t + CPD) : -INFINITY;
         float v;
         if (t == 0) v = (s < 2 && live) ? y : -INFINITY;
         else {
@@ -245,6 +258,7 @@ __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int
         col[t & 1][s] = v;
         AW[(int64_t)t * SW + s] = v;
         __syncthreads();
+      }
     }
     if (s == 0) {
         const float* pc = col[(T - 1) & 1];
@@ -259,8 +273,21 @@ __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int
     const float gs = 1.f / ((float)N * (float)B);
     // ---- beta + gradient (columns stored with two trailing guard cells: index s+1, s+2 may run past S)
     float be = -INFINITY;
-    for (int t = T - 1; t >= 0; --t) {
-        const float y = live ? ((lab ? L[(int64_t)t * Nm + tok] : log_blank) - LW[t]) : -INFINITY;
+    float aq[CPD];
+#pragma unroll
+    for (int k = 0; k < CPD; ++k) {
+        const int t = T - 1 - k;
+        yq[k] = t >= 0 ? emis(t) : -INFINITY;
+        aq[k] = (t >= 0 && live && lab) ? AW[(int64_t)t * SW + s] : 0.f;
+    }
+    for (int t0 = T - 1; t0 >= 0; t0 -= CPD) {
+#pragma unroll
+      for (int k = 0; k < CPD; ++k) {
+        const int t = t0 - k;
+        if (t < 0) break;                                               // block-uniform
+        const float y = yq[k], al = aq[k];
+        yq[k] = t - CPD >= 0 ? emis(t - CPD) : -INFINITY;
+        aq[k] = (t - CPD >= 0 && live && lab) ? AW[(int64_t)(t - CPD) * SW + s] : 0.f;
         float v;
         if (t == T - 1) v = (s == S - 1 || s == S - 2) ? y : -INFINITY;
         else {
@@ -272,10 +299,11 @@ __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int
         be = v;
         col[t & 1][s] = v;
         if (live && lab) {
-            const float occ = expf(AW[(int64_t)t * SW + s] + v + nll - y);
+            const float occ = expf(al + v + nll - y);
             G[(int64_t)t * Nm + tok] = (expf(y) - occ) * gs;
         }
         __syncthreads();
+      }
     }
 }
 

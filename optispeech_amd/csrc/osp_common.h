@@ -12,6 +12,9 @@
 
 extern "C" const char* osp_last_error();
 void osp_set_error(const char* fmt, ...);
+// measurement aid (api.cpp): symbol of the matrix-core kernel a launch helper picked, algorithmic flops of the launch
+void osp_note_symbol(const char* sym);
+void osp_note_flops(double flops);
 
 #define OSP_CHECK_ARG(cond, msg)                                      \
     do {                                                              \

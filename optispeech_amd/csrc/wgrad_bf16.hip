@@ -611,6 +611,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     p.y_bytes = 0; p.x_bytes = 0;
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.x_step_h = (int)d2[3]; p.pad_h = (int)d2[4];
     p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
+    osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);          // measurement aid (api.cpp)
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
@@ -662,12 +663,15 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
             sp8 = cdiv(M, ch8);
             p.chunk = (int)ch8; p.splits = (int)sp8;
             const dim3 g8((unsigned)((N / 256) * taps * (Cin / 256) * sp8 * batch));
+            osp_note_symbol("conv_wgrad_bf16_tr8_kernel");
             if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr8_kernel<true>), g8, dim3(512), 131072, stream, p);
             else hipLaunchKernelGGL((conv_wgrad_bf16_tr8_kernel<false>), g8, dim3(512), 131072, stream, p);
         } else if (T_ == 128) {
+            osp_note_symbol("conv_wgrad_bf16_tr_kernel<128>");
             if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<128, false, true>), g, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<128>, g, dim3(256), 0, stream, p);
         } else {
+            osp_note_symbol("conv_wgrad_bf16_tr_kernel<64>");
             if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<64, false, true>), g, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL(conv_wgrad_bf16_tr_kernel<64>, g, dim3(256), 0, stream, p);
         }
@@ -682,10 +686,11 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         sp = cdiv(M, ch);
         p.chunk = (int)ch; p.splits = (int)sp;
         const dim3 g((unsigned)(N / 64), (unsigned)(taps * (Cin / 64)), (unsigned)(sp * batch));
+        osp_note_symbol("conv_wgrad_bf16_tr_kernel<64,f32>");
         hipLaunchKernelGGL((conv_wgrad_bf16_tr_kernel<64, true>), g, dim3(256), 0, stream, p);
     }
-    else if (fast) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p);
+    else if (fast) { osp_note_symbol("conv_wgrad_bf16_kernel<fast>"); hipLaunchKernelGGL((conv_wgrad_bf16_kernel<true>), grid, dim3(256), 0, stream, p); }
+    else { osp_note_symbol("conv_wgrad_bf16_kernel"); hipLaunchKernelGGL((conv_wgrad_bf16_kernel<false>), grid, dim3(256), 0, stream, p); }
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

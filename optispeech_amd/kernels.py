@@ -187,7 +187,9 @@ def ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, d
     B, T, C = x.shape
     assert dh.is_contiguous() and xhat.is_contiguous() and x.is_contiguous()
     dx = torch.empty_like(x)
-    call("osp_ln_dwconv7_bwd", dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, B, T, C)
+    nb = 256 if (_LNDW_TWO_STAGE and (dlnw is not None or ddw is not None) and B * T >= 4096) else 0
+    ws = torch.empty((nb * 10 * C,), device=x.device, dtype=torch.float32) if nb else None
+    call("osp_ln_dwconv7_bwd", dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx, dlnw, dlnb, ddw, ddb, B, T, C, ws, nb)
     return dx
 
 
@@ -295,6 +297,10 @@ def layernorm_fwd(x, w, b, eps, *, save=True, rowmask=None, drop_p=0.0, seed=0, 
     return y, mean, rstd
 
 
+_LNBWD_BLOCKS = int(__import__('os').environ.get('OSP_LNBWD_BLOCKS', '1024'))
+_LNDW_TWO_STAGE = __import__('os').environ.get('OSP_LNDW_TWO_STAGE', '1') != '0'
+
+
 def layernorm_bwd(dy, xin, mean, rstd, w, dlnw, dlnb, *, relu_src=None, rowmask=None, drop_p=0.0, seed=0,
                   stream_id=0):
     _f32(dy, xin, mean, rstd, w, relu_src, rowmask, dlnw, dlnb)
@@ -303,8 +309,12 @@ def layernorm_bwd(dy, xin, mean, rstd, w, dlnw, dlnb, *, relu_src=None, rowmask=
     assert dy.is_contiguous() and xin.is_contiguous()
     dx = torch.empty_like(dy)
     sh, sd = _seed(seed)
+    # two-stage parameter-gradient reduction (csrc/convnext.hip): per-workgroup partial rows + a small reduce kernel instead of
+    # device-scope atomics from every workgroup, which also lifts the one-workgroup-per-CU cap of the grid
+    nb = min(_LNBWD_BLOCKS, (rows + 31) // 32) if (dlnw is not None and rows >= 4096) else 0
+    ws = torch.empty((nb * 2 * C,), device=dy.device, dtype=torch.float32) if nb else None
     call("osp_layernorm_bwd", dy, xin, mean, rstd, w, relu_src, rowmask, float(drop_p), sh, sd, int(stream_id),
-         dx, dlnw, dlnb, rows, C)
+         dx, dlnw, dlnb, rows, C, ws, nb)
     return dx
 
 

@@ -92,6 +92,8 @@ REPLACES = {
     "osp_segment_starts": "get_random_segments start indices: utils/segments.py:12-38 (caller generator/__init__.py:147-153)",
     "osp_last_error": "error text of the last failing call on this thread",
     "osp_abi_version": "ABI version of this library",
+    "osp_kernel_note_host": "measurement aid, no reference counterpart: symbol and algorithmic flops of the matrix-core kernel(s) the calling "
+                            "thread's last entry-point call launched (bench.py's roofline block reads it; cleared by the read)",
     "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
 }
 

@@ -51,8 +51,37 @@ __global__ void nolds_kernel(const float* __restrict__ x, float* __restrict__ ou
     out[i] = acc;
 }
 
+// "hog": the OTHER process of a pair -- long kernels (~2 ms each) on every CU with 64 KB of LDS per workgroup, back to back for
+// `iters` milliseconds, so that the victim's workgroups can only run by pre-empting / time-slicing against them.
+__global__ __launch_bounds__(256) void hog_kernel(float* out, int spins) {
+    __shared__ float s[16384];
+    for (int i = threadIdx.x; i < 16384; i += 256) s[i] = (float)i;
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < spins; ++k) {
+        acc += s[(threadIdx.x * 33 + k * 7) & 16383];
+        if ((k & 1023) == 0) __syncthreads();
+    }
+    if (acc == 12345.678f) out[blockIdx.x] = acc;
+}
+
 int main(int argc, char** argv) {
     const char* variant = argc > 1 ? argv[1] : "stft";
+    if (!strcmp(variant, "hog")) {
+        const int ms = argc > 2 ? atoi(argv[2]) : 5000;
+        float* o; CK(hipMalloc(&o, 1 << 20));
+        hipStream_t hs; CK(hipStreamCreate(&hs));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float total = 0.f; int n = 0;
+        while (total < (float)ms) {
+            CK(hipEventRecord(e0, hs));
+            for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(hog_kernel, dim3(1024), dim3(256), 0, hs, o, 400000);
+            CK(hipEventRecord(e1, hs)); CK(hipStreamSynchronize(hs));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); total += t; n += 8;
+        }
+        printf("RESULT hog pid %d: %d kernels, %.2f ms each\n", (int)getpid(), n, total / n);
+        return 0;
+    }
     const int iters = argc > 2 ? atoi(argv[2]) : 2000;
     const int B = 8, T = 64 * 256 * 4;
     std::vector<float> hx((size_t)B * T);

@@ -7,4 +7,9 @@ for v in stft wave ldsmix nolds; do
   echo "== $v: TWO processes side by side"
   ( timeout 300 $BIN $v $IT | sed "s/^/A: /" ) > /tmp/_sa.txt & ( timeout 300 $BIN $v $IT | sed "s/^/B: /" ) > /tmp/_sb.txt & wait
   grep "RESULT\|deviate" /tmp/_sa.txt /tmp/_sb.txt | cut -d: -f2-
+  echo "== $v next to a HOG process (long kernels on every CU, 64 KB LDS per workgroup: the victim only runs by time-slicing)"
+  ( timeout 300 $BIN hog 20000 ) > /tmp/_sh.txt & HP=$!
+  sleep 1
+  timeout 300 $BIN $v $IT | grep -v "^  " | tail -4
+  kill $HP 2>/dev/null; wait $HP 2>/dev/null; cat /tmp/_sh.txt
 done
