@@ -90,6 +90,7 @@ class KernelTimer:
         def call(name, *args):
             if not timer.enabled or _lib._RECORD[0] is not None:
                 return orig(name, *args)
+            note(buf, 128, ctypes.byref(fl))                         # clear whatever earlier (untimed) calls left in the note
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             orig(name, *args)
@@ -101,6 +102,23 @@ class KernelTimer:
                 e1.record()
                 timer.events.append((hit[0], hit[1], e0, e1))
         lib.call = call
+        # grouped launches (opt-in, OSP_DISC_GROUPED=1) go through _lib.call_rows: same bracket
+        orig_rows = _lib.call_rows
+
+        def call_rows(name, rows):
+            if not timer.enabled:
+                return orig_rows(name, rows)
+            note(buf, 128, ctypes.byref(fl))
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_rows(name, rows)
+            note(buf, 128, ctypes.byref(fl))
+            sym = buf.value.decode()
+            if sym and fl.value > 0:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                timer.events.append(("mfma:" + sym, fl.value, e0, e1))
+        _lib.call_rows = call_rows
 
     def summary(self):
         """{key: (work, ms, launches)}"""
@@ -446,7 +464,10 @@ def main():
     if rank == 0:
         # Every matrix-core symbol of the step, timed in the 3 serialised steps above and classified by the library's own
         # dispatcher (KernelTimer); the roofline object is the symbol with the LARGEST TOTAL TIME, the others are listed beside it.
-        DESCR = {"conv_gemm_bf16_glds8e_kernel": "8 waves, 256x256 tiles, direct-to-LDS: DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
+        DESCR = {"conv_gemm_bf16_glds8e_grp_kernel": "8 waves, 256x256 tiles, direct-to-LDS, GROUPED over the five DiscriminatorP stacks: 512->1024 / 1024->1024 forward + fused-phase dgrad (1 020 tiles per launch)",
+                 "conv_gemm_bf16_glds_grp_kernel": "4 waves, 128x128 tiles, direct-to-LDS, grouped over the stacks of a family: the remaining MPD conv-GEMM forward + dgrad launches (N >= 128)",
+                 "conv_gemm_bf16_glds_n64_grp_kernel": "4 waves, 128x64 tiles, direct-to-LDS, grouped over the three DiscriminatorR stacks (64-channel layers)",
+                 "conv_gemm_bf16_glds8e_kernel": "8 waves, 256x256 tiles, direct-to-LDS: DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
                  "conv_gemm_bf16_glds_kernel": "4 waves, 128x128 tiles, direct-to-LDS: the remaining MPD / MRD conv-GEMM forward + dgrad launches (N >= 128)",
                  "conv_gemm_bf16_glds_n64_kernel": "4 waves, 128x64 tiles, direct-to-LDS: the 64-channel DiscriminatorR layers",
                  "conv_wgrad_bf16_tr8_kernel": "8 waves, 256x256 weight-gradient tiles (transposed LDS reads): DiscriminatorP 512->1024 / 1024->1024",

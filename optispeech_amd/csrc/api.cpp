@@ -1,5 +1,6 @@
 // libosp_hip: error reporting + version.  All entry points are extern "C", return int (0 = ok),
 // never throw, never allocate, never synchronise: work is enqueued on the caller's hipStream_t.
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -46,3 +47,13 @@ extern "C" int osp_abi_version() { return 1; }
 #endif
 static const char g_source_hash[] = "OSP_SOURCE_HASH=" OSP_SOURCE_HASH;
 extern "C" const char* osp_source_hash() { return g_source_hash + 16; }
+
+// Stream hand-over in one call: record `event_host_handle` (a hipEvent_t) on `stream` and make `dst_stream_host_handle` (a
+// hipStream_t) wait for it.  The step does this ~45 times (weight-gradient side streams, ops.side_wgrad); through torch it is two
+// Python calls + two runtime calls each.
+extern "C" int osp_stream_handover(void* event_host_handle, void* dst_stream_host_handle, hipStream_t stream) {
+    hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(event_host_handle), stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(reinterpret_cast<hipStream_t>(dst_stream_host_handle), reinterpret_cast<hipEvent_t>(event_host_handle), 0);
+    if (e != hipSuccess) { osp_set_error("osp_stream_handover: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}

@@ -797,7 +797,10 @@ extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const floa
     if (maxwg < 0) { const char* e = getenv("OSP_LNDW_WG"); maxwg = e ? atoi(e) : 2048 / nwv; }
     const bool two_stage = ws && (dlnw || ddw);
     static int tile_v = -1;
-    if (tile_v < 0) { const char* e = getenv("OSP_LNDW_TILE"); tile_v = (e && atoi(e) == 0) ? 0 : 1; }
+    // opt-in (OSP_LNDW_TILE=1): measured at 32 x 800 x 256 (profiles/r03_lndw_variants.txt) the tile kernel and the run kernel
+    // are the same speed -- 41.1 vs 41.2 us with atomics, 42.9 vs 42.1 us with the two-stage reduction, 34-35 vs 32 us without
+    // parameter gradients -- although the tile kernel fetches half the rows from L2: neither is bound by L2 / HBM bytes
+    if (tile_v < 0) { const char* e = getenv("OSP_LNDW_TILE"); tile_v = (e && atoi(e) == 1) ? 1 : 0; }
     if (tile_v) {
         // tile kernel (round 3): tiles of TR <= LT_ROWS - 6 frames, equal within an utterance; persistent workgroups, 2 per CU
         const int64_t tpu = cdiv(T, LT_ROWS - 6), TR = cdiv(T, tpu), ntiles = B * tpu;

@@ -32,8 +32,8 @@ __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
 //   (256 + 256) x 128 B per slab for 4x the flops of a 128x128 tile (2x fewer HBM / L2 bytes per flop); two 64 KB stages,
 //   one barrier per slab, 1 workgroup / CU whose second wave per SIMD covers the other's LDS latency.
 template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false>
-__device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem) {
-    const GemmB pp = gemm_select_phase(pin);
+__device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem, const TileCtx tc) {
+    const GemmB pp = gemm_select_phase(pin, tc.z);
     constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
     constexpr int RA = BM_ / (8 * NW), RB = BN_ / (8 * NW), TM_ = BM_ / (32 * WM_), TN_ = BN_ / (32 * WN_);   // rows staged per thread (A, B); 32x32 tiles per wave
     static_assert(TM_ == 2 || TM_ == 4, "wave tile is 64 or 128 rows");
@@ -42,9 +42,9 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WN_) * (BM_ / WM_), wn0 = (wave % WN_) * (BN_ / WN_);
     int mb_, nb_;
-    xcd_tile(mb_, nb_);
+    xcd_tile(tc, mb_, nb_);
     const int m0 = mb_ * BM_, n0 = nb_ * BN_;
-    const int64_t bz = pp.nphase > 0 ? 0 : blockIdx.z;
+    const int64_t bz = pp.nphase > 0 ? 0 : tc.z;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(pp.A) + bz * pp.sAb;
     const unsigned short* B = reinterpret_cast<const unsigned short*>(pp.B) + bz * pp.sBb;
     const int Cin = pp.Cin, Tin = pp.Tin, Hin = pp.Hin, KW = pp.KW, a_tapstep = pp.a_tapstep, a_tapstep_h = pp.a_tapstep_h;
@@ -220,23 +220,52 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
 
 extern __shared__ __attribute__((aligned(1024))) unsigned short glds_smem[];
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<128, 2>(pp, glds_smem);
+    conv_gemm_bf16_glds_body<128, 2>(pp, glds_smem, grid_tile_ctx());
 }
 // narrow outputs (N <= 64: the DiscriminatorR stacks): 128x64 tiles, 48 KB of LDS -> 3 workgroups / CU
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<128, 2, 64>(pp, glds_smem);
+    conv_gemm_bf16_glds_body<128, 2, 64>(pp, glds_smem, grid_tile_ctx());
 }
 // 8 waves, 256x256 tiles, two 64 KB stages (the epilogue's wave-private staging tiles need 144 KB: that is what is allocated)
 #define GLDS8_LDS (8 * 128 * (32 * 2 + 8) * 2)
 __global__ __launch_bounds__(512) void conv_gemm_bf16_glds8_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<256, 2, 256, 8>(pp, glds_smem);
+    conv_gemm_bf16_glds_body<256, 2, 256, 8>(pp, glds_smem, grid_tile_ctx());
 }
 __global__ __launch_bounds__(512) void conv_gemm_bf16_glds8e_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<256, 2, 256, 8, true>(pp, glds_smem);
+    conv_gemm_bf16_glds_body<256, 2, 256, 8, true>(pp, glds_smem, grid_tile_ctx());
 }
 // one workgroup per CU (144 KB of LDS): let the register allocator use the whole 512-entry file of a single wave / SIMD
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_bf16_glds256_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<256, 3>(pp, glds_smem);
+    conv_gemm_bf16_glds_body<256, 3>(pp, glds_smem, grid_tile_ctx());
+}
+
+// ---- GROUPED launch (round 3): up to GEMM_GROUP_MAX problems of the same kernel class in ONE grid -- the same layer of the five
+// DiscriminatorP (three DiscriminatorR) stacks, which differ in operand pointers and row counts only.  One period's 1024 -> 1024
+// layer is 51 x 4 = 204 tiles of 256 x 256 on 256 CUs (80 % of one round, and every number measured on it carried that 80 %);
+// the five together are 1 020 tiles = 3.98 rounds.  It also turns 5 (3) launches into one.  A workgroup finds its problem in the
+// prefix table (wave-uniform scalar work), takes that problem's parameter block out of the kernel-argument segment and runs the
+// unchanged body with a TileCtx of its own.
+#define GEMM_GROUP_MAX 5
+struct GemmGroup { int n; int tile_end[GEMM_GROUP_MAX]; int nb[GEMM_GROUP_MAX]; int mb[GEMM_GROUP_MAX]; GemmB p[GEMM_GROUP_MAX]; };
+__device__ __forceinline__ int group_pick(const GemmGroup& g, TileCtx& tc) {
+    const int bid = blockIdx.x;
+    int k = 0;
+    while (k < g.n - 1 && bid >= g.tile_end[k]) ++k;
+    const int local = bid - (k ? g.tile_end[k - 1] : 0), per = g.nb[k] * g.mb[k];
+    tc.NB = g.nb[k]; tc.MB = g.mb[k]; tc.z = local / per; tc.lin = local - tc.z * per;
+    return k;
+}
+__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_grp_kernel(const GemmGroup g) {
+    TileCtx tc; const int k = group_pick(g, tc);
+    conv_gemm_bf16_glds_body<128, 2>(g.p[k], glds_smem, tc);
+}
+__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_grp_kernel(const GemmGroup g) {
+    TileCtx tc; const int k = group_pick(g, tc);
+    conv_gemm_bf16_glds_body<128, 2, 64>(g.p[k], glds_smem, tc);
+}
+__global__ __launch_bounds__(512) void conv_gemm_bf16_glds8e_grp_kernel(const GemmGroup g) {
+    TileCtx tc; const int k = group_pick(g, tc);
+    conv_gemm_bf16_glds_body<256, 2, 256, 8, true>(g.p[k], glds_smem, tc);
 }
 
 // C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
@@ -408,7 +437,12 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
 
 // Kernel selection + launch for a filled parameter block.  With p.nphase > 0 (fused dgrad phases) the grid's z dimension
 // enumerates the phases and p.M is the largest phase (see GemmB::Phase); batch must then be 1.
-static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
+// kind_out (grouped launches): when the dispatcher picks one of the direct-to-LDS kernels for a single problem (batch 1), it
+// does NOT launch but reports the class (1 = 128x128, 2 = 128x64, 3 = 8-wave 256x256) so that the caller can put the problem
+// into a group; every other class is launched as usual and reported as 0.
+enum { GK_LAUNCHED = 0, GK_GLDS = 1, GK_N64 = 2, GK_W8E = 3 };
+static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind_out = nullptr) {
+    if (kind_out) *kind_out = GK_LAUNCHED;
     static int nt_env = -1;
     if (nt_env < 0) { const char* e = getenv("OSP_GEMM_NT"); nt_env = e ? atoi(e) : 0; }
     p.nt_out = nt_env;
@@ -483,6 +517,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * TBK * 2);
             attr64 = 1;
         }
+        if (kind_out && batch_in == 1) { *kind_out = GK_N64; return OSP_OK; }
         osp_note_symbol("conv_gemm_bf16_glds_n64_kernel");
         hipLaunchKernelGGL(conv_gemm_bf16_glds_n64_kernel, grid, dim3(256), 2 * (128 + 64) * TBK * 2, stream, p);
         OSP_LAUNCH_CHECK();
@@ -508,6 +543,10 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
             }
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
             static int early = -1;
+            if (kind_out && batch_in == 1) {
+                const char* e = getenv("OSP_GEMM_W8_EARLY");
+                if (!(e && atoi(e) == 0)) { *kind_out = GK_W8E; return OSP_OK; }
+            }
             if (early < 0) {
                 const char* e = getenv("OSP_GEMM_W8_EARLY"); early = (e && atoi(e) == 0) ? 0 : 1;      // +1..3 % in A/B runs (tools/gemm_quick.py)
                 hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8e_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
@@ -530,6 +569,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         // 256-row / three-stage variant: opt-in (OSP_GEMM_BIG=1).  Measured on MI355X it does not beat the 128x128
         // kernel at 2 workgroups / CU (M=13056, N=1024, K=5120: 218 vs 209 us): with one wave per SIMD the barrier per
         // k-slab and the LDS latency of the first k-step are exposed.  Kept for the next round's 8-wave version.
+        if (kind_out && batch_in == 1 && !big) { *kind_out = GK_GLDS; return OSP_OK; }
         if (big && cdiv(M, 256) * cdiv(N, TBN) * batch >= 200) {
             const dim3 g256((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, 256), (unsigned)batch);
             osp_note_symbol("conv_gemm_bf16_glds256_kernel");
@@ -549,6 +589,52 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
     return osp_launch_gemm_reg(p, grid, bm, bn, sBk == 1, fast, bk32, stream);
 }
 
+// Launch up to GEMM_GROUP_MAX filled problems: each goes through the dispatcher; those it assigns to a direct-to-LDS class are
+// collected per class and leave as ONE grouped grid per class, the rest are launched on the spot.
+static int gemm_launch_group(GemmB* ps, int n, hipStream_t stream) {
+    int kind[GEMM_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        const int rc = gemm_launch(ps[i], 1, stream, &kind[i]);
+        if (rc != OSP_OK) return rc;
+    }
+    static int attr = 0;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_grp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + TBN) * TBK * 2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_n64_grp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * TBK * 2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8e_grp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
+        attr = 1;
+    }
+    for (int k = GK_GLDS; k <= GK_W8E; ++k) {
+        GemmGroup g;
+        g.n = 0;
+        const int bm = k == GK_W8E ? 256 : 128, bn = k == GK_W8E ? 256 : (k == GK_N64 ? 64 : 128);
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) {
+            if (kind[i] != k) continue;
+            const GemmB& p = ps[i];
+            g.p[g.n] = p;
+            g.nb[g.n] = (int)cdiv(p.N, bn); g.mb[g.n] = (int)cdiv(p.M, bm);
+            tiles += g.nb[g.n] * g.mb[g.n] * (p.nphase > 0 ? p.nphase : 1);
+            g.tile_end[g.n] = tiles;
+            ++g.n;
+        }
+        if (!g.n) continue;
+        for (int i = g.n; i < GEMM_GROUP_MAX; ++i) { g.tile_end[i] = tiles; g.nb[i] = g.mb[i] = 1; }
+        if (k == GK_W8E) {
+            osp_note_symbol("conv_gemm_bf16_glds8e_grp_kernel");
+            hipLaunchKernelGGL(conv_gemm_bf16_glds8e_grp_kernel, dim3((unsigned)tiles), dim3(512), GLDS8_LDS, stream, g);
+        } else if (k == GK_N64) {
+            osp_note_symbol("conv_gemm_bf16_glds_n64_grp_kernel");
+            hipLaunchKernelGGL(conv_gemm_bf16_glds_n64_grp_kernel, dim3((unsigned)tiles), dim3(256), 2 * (128 + 64) * TBK * 2, stream, g);
+        } else {
+            osp_note_symbol("conv_gemm_bf16_glds_grp_kernel");
+            hipLaunchKernelGGL(conv_gemm_bf16_glds_grp_kernel, dim3((unsigned)tiles), dim3(256), 2 * (128 + TBN) * TBK * 2, stream, g);
+        }
+    }
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
 static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
                                   int64_t Cin, int64_t taps, int64_t a_step, int64_t a_tapstep, int64_t a_off,
                                   const float* a_rowscale, const void* B, int64_t b_bf16, int64_t sBn, int64_t sBtap,
@@ -557,7 +643,7 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
                                   const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
                                   void* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
                                   int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, GemmB* fill_only = nullptr) {
     OSP_CHECK_ARG(A && B && C, "null operand");
     OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && Tin > 0 && batch > 0, "bad shape");
     OSP_CHECK_ARG(d2[0] > 0 && d2[1] > 0 && d2[2] > 0 && taps % d2[2] == 0 && Trows % d2[0] == 0, "bad 2-D geometry");
@@ -580,6 +666,7 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
     p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
+    if (fill_only) { *fill_only = p; return OSP_OK; }                  // grouped launch: the caller collects the blocks
     return gemm_launch(p, batch, stream);
 }
 
@@ -618,6 +705,28 @@ extern "C" int osp_conv2d_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, 
                                nullptr, nullptr, aux_in, aux_bf16, ld_aux, slope, 1, 0, 0, 0, 0, 0, stream);
 }
 
+static inline float f_of_bits(int64_t v) { float f; const unsigned u = (unsigned)v; memcpy(&f, &u, 4); return f; }
+static inline const void* ptr_of(int64_t v) { return reinterpret_cast<const void*>(static_cast<uintptr_t>(v)); }
+
+// GROUPED form of osp_conv2d_gemm_bf16: `count` (<= 5) problems, row r of rows_host = the 42 arguments of that entry point in
+// order, as int64 (pointers as addresses, `slope` as the bit pattern of the float in the low 32 bits).  Problems the dispatcher
+// sends to the same direct-to-LDS kernel class leave as one grid (GemmGroup above); the others are launched one by one.
+extern "C" int osp_conv2d_gemm_bf16_multi(const int64_t* rows_host, int64_t count, hipStream_t stream) {
+    OSP_CHECK_ARG(rows_host && count > 0 && count <= GEMM_GROUP_MAX, "1..5 problems");
+    GemmB ps[GEMM_GROUP_MAX];
+    for (int64_t r = 0; r < count; ++r) {
+        const int64_t* a = rows_host + r * 42;
+        const int64_t d2[10] = {a[5], a[6], a[10], a[11], a[12], a[13], a[28], a[29], a[30], a[20]};
+        const int rc = conv_gemm_bf16_impl(d2, ptr_of(a[0]), a[1], a[2], a[3], a[4], a[7], a[8], a[9], a[14], a[15], a[16], nullptr,
+                                           ptr_of(a[17]), a[18], a[19], a[21], a[22], a[23], const_cast<void*>(ptr_of(a[24])), a[25], a[26],
+                                           a[27], a[31], a[32], a[33], reinterpret_cast<const float*>(ptr_of(a[34])), nullptr, ptr_of(a[35]),
+                                           a[36], a[37], nullptr, nullptr, nullptr, ptr_of(a[38]), a[39], a[40], f_of_bits(a[41]), 1, 0, 0, 0,
+                                           0, 0, stream, &ps[r]);
+        if (rc != OSP_OK) return rc;
+    }
+    return gemm_launch_group(ps, (int)count, stream);
+}
+
 // dgrad of a strided channels-last conv2d, all output phases in ONE launch.
 //   dx[u, h, w, c] = epi( sum_{kh, kw, n} dy[u, (h + ph - kh) / sh, (w + pw - kw) / sw, n] * Wt[c, kh, kw, n] )   (exact divisions only)
 // Output phase (rh, rw) = (h % sh, w % sw) only sees the taps kh = kh0 + i*sh, kw = kw0 + j*sw (kh0 = (rh + ph) % sh, ...),
@@ -625,10 +734,11 @@ extern "C" int osp_conv2d_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, 
 // (GemmB::Phase) and run as blockIdx.z of one grid instead of sh*sw small launches (DiscriminatorR: 4, DiscriminatorP: 3).
 // Wt: (Cin, KH, KW, Cout) = the weights transposed for dgrad.  epi: BEPI_NONE or BEPI_LRELU_BWD (aux_in = forward output y
 // of the previous layer, `res` an extra addend: the feature-matching gradient of that layer).
-extern "C" int osp_conv2d_dgrad_bf16(const void* dy, int64_t dy_bf16, const void* wt, int64_t w_bf16, void* dx, int64_t dx_bf16,
-                                     int64_t U, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int64_t KH,
-                                     int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t epi, const void* aux_in,
-                                     int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream) {
+static int conv2d_dgrad_impl(const void* dy, int64_t dy_bf16, const void* wt, int64_t w_bf16, void* dx, int64_t dx_bf16,
+                             int64_t U, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int64_t KH,
+                             int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t epi, const void* aux_in,
+                             int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream, GemmB* fill_only,
+                             int* filled) {
     OSP_CHECK_ARG(dy && wt && dx, "null operand");
     OSP_CHECK_ARG(U > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && sh > 0 && sw > 0, "bad shape");
     OSP_CHECK_ARG(sh * sw <= 4 && KH >= sh && KW >= sw, "unsupported stride (at most 4 phases, kernel >= stride)");
@@ -673,9 +783,36 @@ extern "C" int osp_conv2d_dgrad_bf16(const void* dy, int64_t dy_bf16, const void
             for (int k = 0; k < np; ++k) { mmax = p.ph[k].M > mmax ? p.ph[k].M : mmax; tmax = p.ph[k].taps > tmax ? p.ph[k].taps : tmax; }
             r.M = mmax; r.Trows = p.ph[0].Trows; r.Wrows = p.ph[0].Wrows; r.taps = tmax; r.KW = p.ph[0].KW;
             r.a_off_h = r.a_off = r.c_off_h = r.c_off = 0; r.fd_trows = p.ph[0].fd_trows; r.fd_wrows = p.ph[0].fd_wrows;
+            if (fill_only) { *fill_only = r; *filled = 1; return OSP_OK; }     // grouped launch: the caller collects the blocks
         }
         rc = gemm_launch(r, 1, stream);
     }
     return rc;
+}
+
+extern "C" int osp_conv2d_dgrad_bf16(const void* dy, int64_t dy_bf16, const void* wt, int64_t w_bf16, void* dx, int64_t dx_bf16,
+                                     int64_t U, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int64_t KH,
+                                     int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t epi, const void* aux_in,
+                                     int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream) {
+    return conv2d_dgrad_impl(dy, dy_bf16, wt, w_bf16, dx, dx_bf16, U, H, W, Ho, Wo, Cin, Cout, KH, KW, sh, sw, ph, pw, epi, aux_in, aux_bf16,
+                             res, res_bf16, slope, stream, nullptr, nullptr);
+}
+
+// GROUPED form of osp_conv2d_dgrad_bf16 (rows of its 25 arguments as int64, `slope` as float bits): the fused-phase dgrads of the
+// same layer of several stacks in one grid; degenerate channel counts (first / last layers) are launched one by one as before.
+extern "C" int osp_conv2d_dgrad_bf16_multi(const int64_t* rows_host, int64_t count, hipStream_t stream) {
+    OSP_CHECK_ARG(rows_host && count > 0 && count <= GEMM_GROUP_MAX, "1..5 problems");
+    GemmB ps[GEMM_GROUP_MAX];
+    int n = 0;
+    for (int64_t r = 0; r < count; ++r) {
+        const int64_t* a = rows_host + r * 25;
+        int filled = 0;
+        const int rc = conv2d_dgrad_impl(ptr_of(a[0]), a[1], ptr_of(a[2]), a[3], const_cast<void*>(ptr_of(a[4])), a[5], a[6], a[7], a[8], a[9],
+                                         a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19], ptr_of(a[20]), a[21],
+                                         ptr_of(a[22]), a[23], f_of_bits(a[24]), stream, &ps[n], &filled);
+        if (rc != OSP_OK) return rc;
+        n += filled;
+    }
+    return n ? gemm_launch_group(ps, n, stream) : OSP_OK;
 }
 

@@ -54,17 +54,26 @@ struct GemmB {
     struct Phase { int M, Trows, Wrows, taps, KW, a_off_h, a_off, c_off_h, c_off; int64_t b_off; FastDiv fd_trows, fd_wrows; } ph[4];
 };
 
+// Where a workgroup stands in its problem: linear tile id, tile-grid extent, z (batch index, or output phase of a fused dgrad).
+// A plain launch derives it from blockIdx / gridDim; a GROUPED launch (several problems -- the five period discriminators' copies
+// of one layer -- in one grid, gemm_bf16.hip) from the group's prefix table.
+struct TileCtx { int lin, NB, MB, z; };
+__device__ __forceinline__ TileCtx grid_tile_ctx() {
+    TileCtx t; t.NB = gridDim.x; t.MB = gridDim.y; t.lin = blockIdx.y * gridDim.x + blockIdx.x; t.z = blockIdx.z; return t;
+}
+
 // effective parameters of this workgroup (wave-uniform: stays in SGPRs)
-__device__ __forceinline__ GemmB gemm_select_phase(const GemmB& pin) {
+__device__ __forceinline__ GemmB gemm_select_phase(const GemmB& pin, int z) {
     GemmB pp = pin;
     if (pin.nphase > 0) {
-        const GemmB::Phase q = pin.ph[blockIdx.z];
+        const GemmB::Phase q = pin.ph[z];
         pp.M = q.M; pp.Trows = q.Trows; pp.Wrows = q.Wrows; pp.taps = q.taps; pp.KW = q.KW; pp.a_off_h = q.a_off_h; pp.a_off = q.a_off;
         pp.c_off_h = q.c_off_h; pp.c_off = q.c_off; pp.fd_trows = q.fd_trows; pp.fd_wrows = q.fd_wrows;
         pp.B = reinterpret_cast<const char*>(pin.B) + q.b_off * (pin.b_bf16 ? 2 : 4);
     }
     return pp;
 }
+__device__ __forceinline__ GemmB gemm_select_phase(const GemmB& pin) { return gemm_select_phase(pin, (int)blockIdx.z); }
 
 // 16-byte output row chunk; nt (kernel-uniform): the consumer is a later kernel, keep the operand panels in L2 instead
 __device__ __forceinline__ void st_rows(uint4* p, uint4 v, int nt) {
@@ -384,9 +393,9 @@ __device__ __forceinline__ void gemm_bf16_epilogue(const GemmB& pp, f32x16 (&acc
 // XCD has its own 4 MB L2.  The linear id is first folded so that every XCD owns one contiguous range of tile ids, then
 // tiles are ordered in groups of 8 row blocks x all column blocks: the ~64 workgroups resident on one XCD share 8 A row
 // panels and the B column panels through that XCD's L2 instead of streaming 64 different A panels from HBM.
-__device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
-    const int NB = gridDim.x, MB = gridDim.y, total = NB * MB;
-    const int lin = blockIdx.y * NB + blockIdx.x;
+__device__ __forceinline__ void xcd_tile(const TileCtx& tc, int& mb, int& nb) {
+    const int NB = tc.NB, MB = tc.MB, total = NB * MB;
+    const int lin = tc.lin;
     const int xcd = lin & 7, local = lin >> 3;
     const int per = total >> 3, rem = total & 7;               // XCDs < rem own per + 1 tiles
     const int pid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + local;
@@ -397,6 +406,7 @@ __device__ __forceinline__ void xcd_tile(int& mb, int& nb) {
     mb = first + in_g % gm;
     nb = in_g / gm;
 }
+__device__ __forceinline__ void xcd_tile(int& mb, int& nb) { xcd_tile(grid_tile_ctx(), mb, nb); }
 
 
 // register-staged kernel family (gemm_bf16_reg.hip): tile (bm x bn), k-contiguous / k-strided B, fast / generic loaders

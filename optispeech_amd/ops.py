@@ -51,7 +51,9 @@ class _Side:
 
     def next_event(self):
         if self.pos == len(self.events):
-            self.events.append(torch.cuda.Event())
+            ev = torch.cuda.Event()
+            ev.record()                                              # (torch creates the hipEvent lazily: force the handle to exist)
+            self.events.append(ev)
         ev = self.events[self.pos]
         self.pos += 1
         return ev
@@ -71,9 +73,9 @@ def _flush_wgrad():
     if side not in _WG["used"]:
         _WG["used"].append(side)
     ev = side.next_event()
-    ev.record()                                                    # on the current stream: everything the operands depend on
-    side.stream.wait_event(ev)
     lib = _lib.lib()
+    # record on the current stream (everything the operands depend on) + side stream waits: one C-ABI call on the raw handles
+    lib.call("osp_stream_handover", ev.cuda_event, side.raw)
     _lib._STREAM_OVERRIDE[0] = side.raw
     try:
         for name, args in pend:

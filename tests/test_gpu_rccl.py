@@ -137,3 +137,49 @@ def test_bench_single_rank_under_torchrun(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+@isolated
+def test_graphed_pretraining_step_waits_for_the_generator_all_reduce():
+    """under data parallelism with ``graph_steps`` in the pre-training regime (global_step < pretraining_steps)
+    the generator all-reduce was started after the [G forward + backward] graph and never waited for before the AdamW(G) graph.
+    Here: the segmented (data-parallel) graph order on one rank with the reducers forced active over the C-ABI communicator --
+    after every step nothing may be left pending, and the replayed steps must match the eager pre-training steps."""
+    from optispeech_amd import dp
+    assert dp.init_native_comm() == 1
+    try:
+        res = {}
+        for graph in (False, True):
+            m, batch = _model()
+            m.train_args.pretraining_steps = 1 << 60
+            m.optimizers()
+            for red in m._reducers:
+                red._force_active = True
+            waits = {"n": 0}
+            rg = m._reducers[0]
+            w0 = rg.wait
+
+            def counted_wait(_w=w0):
+                waits["n"] += 1
+                return _w()
+            rg.wait = counted_wait
+            m.graph_steps, m.graph_warmup_steps = graph, 1
+            logs = []
+            for i in range(3):
+                m.training_step(batch, i)
+                assert not rg._pending, "generator all-reduce still pending after the step"
+                logs.append(m.fetch_logs())
+            torch.cuda.synchronize()
+            assert waits["n"] >= 3, waits
+            og, od = m.optimizers()
+            assert od.step_count == 0 and og.step_count == 3                     # no discriminator phase in this regime
+            res[graph] = (logs, og.arena.data.clone())
+        for a, b in zip(res[False][0], res[True][0]):
+            assert a.keys() == b.keys() and all(np.isfinite(v) for v in b.values())
+            for k in a:
+                assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+        err = ((res[True][1] - res[False][1]).norm() / res[False][1].norm()).item()
+        assert err < 1e-3, err
+    finally:
+        torch.cuda.synchronize()
+        dp.destroy_native_comm()

@@ -94,6 +94,11 @@ REPLACES = {
     "osp_abi_version": "ABI version of this library",
     "osp_kernel_note_host": "measurement aid, no reference counterpart: symbol and algorithmic flops of the matrix-core kernel(s) the calling "
                             "thread's last entry-point call launched (bench.py's roofline block reads it; cleared by the read)",
+    "osp_stream_handover": "torch.cuda.Event.record + Stream.wait_event of the multi-stream schedule in one call (no reference counterpart: "
+                           "the reference runs on one stream)",
+    "osp_conv2d_gemm_bf16_multi": "the same layer of the five DiscriminatorP / three DiscriminatorR stacks in one grid "
+                                  "(vocoder/wavenext/disc/_discriminators.py:10-38,100-136: the reference loops over the sub-discriminators)",
+    "osp_conv2d_dgrad_bf16_multi": "autograd dgrad of the same, grouped over the sub-discriminators",
     "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
 }
 

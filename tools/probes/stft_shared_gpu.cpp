@@ -53,8 +53,11 @@ __global__ void nolds_kernel(const float* __restrict__ x, float* __restrict__ ou
 
 // "hog": the OTHER process of a pair -- long kernels (~2 ms each) on every CU with 64 KB of LDS per workgroup, back to back for
 // `iters` milliseconds, so that the victim's workgroups can only run by pre-empting / time-slicing against them.
+// (dynamic LDS: OSP_PROBE_HOG_LDS bytes, default 64 KB; 147456 = the 144 KB of the 8-wave conv-GEMM -- more than the 64 KB a
+// kernel gets without hipFuncAttributeMaxDynamicSharedMemorySize)
+extern __shared__ float hog_s[];
 __global__ __launch_bounds__(256) void hog_kernel(float* out, int spins) {
-    __shared__ float s[16384];
+    float* s = hog_s;
     for (int i = threadIdx.x; i < 16384; i += 256) s[i] = (float)i;
     __syncthreads();
     float acc = 0.f;
@@ -63,6 +66,15 @@ __global__ __launch_bounds__(256) void hog_kernel(float* out, int spins) {
         if ((k & 1023) == 0) __syncthreads();
     }
     if (acc == 12345.678f) out[blockIdx.x] = acc;
+}
+
+static size_t hog_lds() {
+    static size_t v = 0;
+    if (!v) {
+        v = getenv("OSP_PROBE_HOG_LDS") ? (size_t)atoi(getenv("OSP_PROBE_HOG_LDS")) : 65536;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)v));
+    }
+    return v;
 }
 
 int main(int argc, char** argv) {
@@ -75,7 +87,7 @@ int main(int argc, char** argv) {
         float total = 0.f; int n = 0;
         while (total < (float)ms) {
             CK(hipEventRecord(e0, hs));
-            for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(hog_kernel, dim3(1024), dim3(256), 0, hs, o, 400000);
+            for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(hog_kernel, dim3(1024), dim3(256), hog_lds(), hs, o, 400000);
             CK(hipEventRecord(e1, hs)); CK(hipStreamSynchronize(hs));
             float t; CK(hipEventElapsedTime(&t, e0, e1)); total += t; n += 8;
         }
@@ -100,6 +112,9 @@ int main(int argc, char** argv) {
     else if (!strcmp(variant, "wave")) cfgs = {{256, 64}};
     else cfgs = {{0, 0}};
     long long bad_iters = 0, bad_elems = 0;
+    const int mix_spins = getenv("OSP_PROBE_MIX") ? atoi(getenv("OSP_PROBE_MIX")) : 0;
+    float* hog_out = nullptr;
+    if (mix_spins > 0) CK(hipMalloc(&hog_out, 1 << 20));
     for (size_t c = 0; c < cfgs.size(); ++c) {
         const int N = cfgs[c].N, hop = cfgs[c].hop;
         size_t n_out;
@@ -108,6 +123,9 @@ int main(int argc, char** argv) {
         long long bi = 0, be = 0;
         for (int it = 0; it <= iters; ++it) {
             float* dst = it == 0 ? ref : out;
+            // OSP_PROBE_MIX=<spins>: this process is HEAVY too -- a long LDS-resident kernel on every CU before each victim launch
+            // (profiles/r03_shared_gpu_race_matrix.txt: the deviation needs BOTH processes to be heavy)
+            if (mix_spins > 0 && it > 0) hipLaunchKernelGGL(hog_kernel, dim3(1024), dim3(256), hog_lds(), st, hog_out, mix_spins);
             if (N) { if (osp_stft_mag_fwd(x, nullptr, tw, -1.f, dst, B, T, N, hop, st) != 0) { printf("launch failed: %s\n", osp_last_error()); return 2; } }
             else if (!strcmp(variant, "ldsmix")) hipLaunchKernelGGL(ldsmix_kernel, dim3(B * T / 1024), dim3(256), 0, st, x, dst, B * T);
             else hipLaunchKernelGGL(nolds_kernel, dim3(B * T / 256), dim3(256), 0, st, x, dst, B * T);
