@@ -85,17 +85,24 @@ class KernelTimer:
         timer = self
         note = lib.cdll.osp_kernel_note_host
         note.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
-        buf, fl = ctypes.create_string_buffer(128), ctypes.c_double(0.0)
+        note_bytes = lib.cdll.osp_kernel_note_bytes_host
+        note_bytes.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        buf, fl, by = ctypes.create_string_buffer(128), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        timer.bytes = {}                                             # symbol -> algorithmic HBM bytes of the timed launches
 
         def call(name, *args):
             if not timer.enabled or _lib._RECORD[0] is not None:
                 return orig(name, *args)
             note(buf, 128, ctypes.byref(fl))                         # clear whatever earlier (untimed) calls left in the note
+            note_bytes(ctypes.byref(by))
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             orig(name, *args)
             note(buf, 128, ctypes.byref(fl))
+            note_bytes(ctypes.byref(by))
             sym = buf.value.decode()
+            if sym and fl.value > 0:
+                timer.bytes["mfma:" + sym] = timer.bytes.get("mfma:" + sym, 0.0) + by.value
             hit = ("mfma:" + sym, fl.value) if (sym and fl.value > 0) else timer.select(name, args)
             if hit:
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -109,12 +116,15 @@ class KernelTimer:
             if not timer.enabled:
                 return orig_rows(name, rows)
             note(buf, 128, ctypes.byref(fl))
+            note_bytes(ctypes.byref(by))
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             orig_rows(name, rows)
             note(buf, 128, ctypes.byref(fl))
+            note_bytes(ctypes.byref(by))
             sym = buf.value.decode()
             if sym and fl.value > 0:
+                timer.bytes["mfma:" + sym] = timer.bytes.get("mfma:" + sym, 0.0) + by.value
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
                 timer.events.append(("mfma:" + sym, fl.value, e0, e1))
@@ -482,8 +492,17 @@ def main():
         for sym, (fl, ms, n) in mf.items():
             peak = PEAK_F32_MFMA_TFLOPS if sym in F32_SYMS else PEAK_BF16_MFMA_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
+            # which roofline binds this symbol's launches: the matrix pipe, or HBM at their arithmetic intensity (algorithmic flops /
+            # algorithmic bytes, both reported by the dispatcher: short-K layers such as the 5-tap 32 -> 128 convolution, K = 160,
+            # cannot exceed ~400 TFLOP/s at 8 TB/s whatever the kernel does)
+            nbytes = getattr(timer, "bytes", {}).get("mfma:" + sym, 0.0)
+            hbm_tf = (fl / nbytes) * PEAK_HBM_GBS * 1e9 / 1e12 if nbytes > 0 else None
+            bound = min(peak, hbm_tf) if hbm_tf else peak
             table[sym] = {"ms_per_step": ms / nroof, "launches_per_step": n / nroof, "avg_launch_us": ms / n * 1e3, "achieved": ach, "peak": peak,
-                          "frac": ach / peak, "algorithmic_flop_per_launch": fl / n, "what": DESCR.get(sym, "")}
+                          "frac": ach / peak, "algorithmic_flop_per_launch": fl / n, "algorithmic_bytes_per_launch": nbytes / n if nbytes else None,
+                          "flop_per_byte": fl / nbytes if nbytes else None, "hbm_bound_tflops": hbm_tf,
+                          "binding_roofline": "hbm" if (hbm_tf and hbm_tf < peak) else "mfma", "frac_of_binding_roofline": ach / bound,
+                          "what": DESCR.get(sym, "")}
         dom = max(table, key=lambda k: table[k]["ms_per_step"]) if table else None
         roof = {"bound": "mfma", "symbol": dom, "kernel": (dom + " (" + DESCR.get(dom, "") + ")") if dom else None,
                 "achieved": table[dom]["achieved"] if dom else None, "peak": table[dom]["peak"] if dom else PEAK_BF16_MFMA_TFLOPS,
@@ -494,6 +513,9 @@ def main():
                        "region (sub-discriminator streams, vocoder stream and side weight-gradient streams off); symbol and algorithmic "
                        "flops (2 M taps Cin N) reported by the library's dispatcher (osp_kernel_note_host); the dominant kernel = the "
                        "symbol with the largest total time",
+                "algorithmic_bytes_per_launch": table[dom]["algorithmic_bytes_per_launch"] if dom else None,
+                "hbm_bound_tflops": table[dom]["hbm_bound_tflops"] if dom else None,
+                "frac_of_binding_roofline": table[dom]["frac_of_binding_roofline"] if dom else None,
                 "mfma_kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"]) if v["ms_per_step"] >= 0.2},
                 "mfma_ms_per_step_total": sum(v["ms_per_step"] for v in table.values())}
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read inside this run);

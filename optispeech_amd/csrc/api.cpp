@@ -23,8 +23,10 @@ extern "C" const char* osp_last_error() { return g_err; }
 #include <string.h>
 static thread_local const char* g_note_sym = nullptr;
 static thread_local double g_note_flops = 0.0;
+static thread_local double g_note_bytes = 0.0;
 void osp_note_symbol(const char* sym) { g_note_sym = sym; }
 void osp_note_flops(double flops) { g_note_flops += flops; }
+void osp_note_bytes(double bytes) { g_note_bytes += bytes; }
 // name_host: buffer of `cap` bytes for the symbol ("" when the call launched no noted kernel); flops_host: one double.
 // The note is cleared by the read, so call it right after the entry point it asks about.
 extern "C" int osp_kernel_note_host(char* name_host, int64_t cap, double* flops_host) {
@@ -36,6 +38,15 @@ extern "C" int osp_kernel_note_host(char* name_host, int64_t cap, double* flops_
     if (flops_host) *flops_host = g_note_flops;
     g_note_sym = nullptr;
     g_note_flops = 0.0;
+    return 0;
+}
+// ALGORITHMIC HBM bytes of the same launches (every operand and the output once: unique input rows x channels, the weights, the
+// output tile, the epilogue's extra operands) -- what decides whether a layer is bound by the matrix pipe or by HBM: a 5-tap
+// 32 -> 128 convolution (K = 160) moves ~100 KB per 5 MFLOP tile, i.e. cannot exceed ~420 TFLOP/s at 8 TB/s whatever the kernel does.
+// Read (and cleared) separately so that older callers of osp_kernel_note_host keep working.
+extern "C" int osp_kernel_note_bytes_host(double* bytes_host) {
+    if (bytes_host) *bytes_host = g_note_bytes;
+    g_note_bytes = 0.0;
     return 0;
 }
 extern "C" int osp_abi_version() { return 1; }

@@ -528,3 +528,34 @@ extern "C" int osp_period_fold(const float* x, float* y, int64_t B, int64_t T, i
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ clip (WaveNeXtHead, A12)
+// audio = clip(x, -1, 1)  (vocoder/wavenext/__init__.py:47) and its backward dx = dy where lo <= x <= hi (torch.clamp's rule),
+// 16-byte accesses; dy == null selects the forward.
+__global__ __launch_bounds__(256) void clip_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int64_t n,
+                                                   float lo, float hi) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 o;
+        if (!dy) {
+            o = make_float4(fminf(fmaxf(v.x, lo), hi), fminf(fmaxf(v.y, lo), hi), fminf(fmaxf(v.z, lo), hi), fminf(fmaxf(v.w, lo), hi));
+        } else {
+            const float4 g = reinterpret_cast<const float4*>(dy)[i];
+            o = make_float4((v.x >= lo && v.x <= hi) ? g.x : 0.f, (v.y >= lo && v.y <= hi) ? g.y : 0.f, (v.z >= lo && v.z <= hi) ? g.z : 0.f,
+                            (v.w >= lo && v.w <= hi) ? g.w : 0.f);
+        }
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256)
+            out[i] = dy ? ((x[i] >= lo && x[i] <= hi) ? dy[i] : 0.f) : fminf(fmaxf(x[i], lo), hi);
+}
+extern "C" int osp_clip(const float* x, const float* dy, float* out, int64_t n, float lo, float hi, hipStream_t stream) {
+    OSP_CHECK_ARG(x && out && n > 0 && lo <= hi, "bad args");
+    OSP_CHECK_ARG((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15) == 0, "16-byte aligned operands");
+    const int64_t blocks = cdiv(n, 256 * 4 * 4);
+    hipLaunchKernelGGL(clip_kernel, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, stream, x, dy, out, n, lo, hi);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}

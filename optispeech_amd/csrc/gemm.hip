@@ -249,6 +249,7 @@ static int launch_gemm(const GemmP& p, int b_kcontig, int batch, hipStream_t str
     dim3 grid((unsigned)cdiv(p.N, BN), (unsigned)cdiv(p.M, BM), (unsigned)batch);
     osp_note_symbol("conv_gemm_f32_kernel");                            // measurement aid (api.cpp)
     osp_note_flops(2.0 * p.M * p.taps * (double)p.Cin * p.N * batch);
+    osp_note_bytes(4.0 * batch * ((double)p.M * p.Cin + (double)p.N * p.taps * p.Cin + (double)p.M * p.N));
     if (b_kcontig)
         hipLaunchKernelGGL((conv_gemm_f32_kernel<BM, BN, true>), grid, dim3(256), 0, stream, p);
     else

@@ -457,6 +457,16 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
         if (p.nphase > 0) for (int i = 0; i < p.nphase; ++i) fl += 2.0 * p.ph[i].M * p.ph[i].taps * (double)Cin * N;
         else fl = 2.0 * M * taps * (double)Cin * N * batch_in;
         osp_note_flops(fl);
+        // algorithmic bytes: unique input frames x Cin, the weights, the output (+ the epilogue's extra operands), each once
+        const double ec = p.c_bf16 ? 2.0 : 4.0, nb = (double)batch_in, ea = a_bf16 ? 2.0 : 4.0, eb = b_bf16 ? 2.0 : 4.0;
+        const double rows_in = (double)(M / (p.Trows > 0 ? p.Trows : 1)) * p.Hin * p.Tin;         // frames of the input tensor
+        double rows_out = (double)M;
+        if (p.nphase > 0) { rows_out = 0.0; for (int i = 0; i < p.nphase; ++i) rows_out += p.ph[i].M; }
+        double by = nb * (rows_in * Cin * ea + (double)N * taps * Cin * eb + rows_out * N * ec);
+        if (p.aux_in) by += nb * rows_out * N * (p.aux_bf16 ? 2.0 : 4.0);
+        if (p.res_any) by += nb * rows_out * N * (p.res_bf16 ? 2.0 : 4.0);
+        if (p.aux_out) by += nb * rows_out * N * (p.aux_bf16 ? 2.0 : 4.0);
+        osp_note_bytes(by);
     }
     const bool single = p.nphase == 0 && batch_in == 1;                  // the degenerate-shape kernels take one problem
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

@@ -15,6 +15,7 @@ void osp_set_error(const char* fmt, ...);
 // measurement aid (api.cpp): symbol of the matrix-core kernel a launch helper picked, algorithmic flops of the launch
 void osp_note_symbol(const char* sym);
 void osp_note_flops(double flops);
+void osp_note_bytes(double bytes);
 
 #define OSP_CHECK_ARG(cond, msg)                                      \
     do {                                                              \

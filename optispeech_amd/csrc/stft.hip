@@ -12,6 +12,7 @@
 // spectrum, evaluates Re(sum_k G_k e^{+i 2 pi k n / N}) as Re(FFT(conj G)) with the same routine, applies the window
 // and overlap-adds into dx with the reflect index map (f32 atomics).
 #include "osp_common.h"
+#include <stdlib.h>
 
 __global__ void fft_twiddles_kernel(float2* tw, int N) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,7 +36,8 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 
 // In-LDS Stockham FFT of N complex points held in buf0 (natural order); returns the buffer holding the
 // result (natural order).  blockDim.x == N/4.  Forward transform (e^{-i...}).
-__device__ __forceinline__ float2* lds_fft(float2* buf0, float2* buf1, const float2* __restrict__ tw, int N) {
+// ``tws``: stride into the twiddle table (a transform of size N out of a table made for tws * N points).
+__device__ __forceinline__ float2* lds_fft(float2* buf0, float2* buf1, const float2* __restrict__ tw, int N, int tws = 1) {
     const int j = threadIdx.x, Q = N >> 2;
     float2 *in = buf0, *out = buf1;
     int Ns = 1;
@@ -45,9 +47,9 @@ __device__ __forceinline__ float2* lds_fft(float2* buf0, float2* buf1, const flo
         const int tstep = N / (Ns * 4);                       // twiddle index of angle -2 pi k / (4 Ns)
         float2 v0 = in[j], v1 = in[j + Q], v2 = in[j + 2 * Q], v3 = in[j + 3 * Q];
         if (Ns > 1) {
-            v1 = cmul(v1, tw[k * tstep]);
-            v2 = cmul(v2, tw[2 * k * tstep]);
-            v3 = cmul(v3, tw[3 * k * tstep]);
+            v1 = cmul(v1, tw[k * tstep * tws]);
+            v2 = cmul(v2, tw[2 * k * tstep * tws]);
+            v3 = cmul(v3, tw[3 * k * tstep * tws]);
         }
         const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), d = csub(v1, v3);
         const float2 a3 = make_float2(d.y, -d.x);              // -i * (v1 - v3)
@@ -64,7 +66,7 @@ __device__ __forceinline__ float2* lds_fft(float2* buf0, float2* buf1, const flo
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int jj = j + r * Q, k = jj & (Ns - 1);
-            const float2 a = in[jj], b = cmul(in[jj + H], tw[k * (N / (Ns * 2))]);
+            const float2 a = in[jj], b = cmul(in[jj + H], tw[k * (N / (Ns * 2)) * tws]);
             const int base = ((jj - k) << 1) + k;
             out[base] = cadd(a, b);
             out[base + Ns] = csub(a, b);
@@ -156,6 +158,106 @@ __global__ __launch_bounds__(N / 4 < 64 ? 64 : N / 4) void stft_mag_bwd_kernel(c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ real-input transform (round 3)
+// A frame is REAL: the kernels above transform it as N complex points (imaginary parts zero), i.e. twice the butterflies, LDS and
+// threads a real-input transform needs.  Here the frame is packed as M = N / 2 complex points z[m] = x[2m] + i x[2m+1], transformed
+// by the same in-LDS Stockham routine at size M (N / 8 threads), and unpacked with one post-twiddle pass:
+//     X[k] = (Z[k] + conj Z[M-k]) / 2  -  i e^{-2 pi i k / N} (Z[k] - conj Z[M-k]) / 2,      k = 0 .. M,  Z[M] = Z[0].
+// Backward: with H = conj(dmag * X / |X|) on k = 0 .. M the gradient is dx[n] = Re sum_k H_k e^{-2 pi i k n / N}.  Extending H to the
+// Hermitian sequence A (A_0 = 2 Re H_0, A_M = 2 Re H_M, A_k = H_k) gives dx[2m] + i dx[2m+1] = FFT_M(P)[m] / 2 with
+//     P[k] = (A_k + conj A_{M-k}) + i e^{-2 pi i k / N} (A_k - conj A_{M-k}),                  k = 0 .. M-1
+// -- again one size-M transform.  Same twiddle table as the complex kernels (stride 2 for the size-M stages).
+template <int N>
+__device__ __forceinline__ float2 rfft_unpack(const float2* __restrict__ Z, const float2* __restrict__ tw, int k) {
+    constexpr int M = N / 2;
+    const float2 a = Z[k == M ? 0 : k], b0 = Z[k == 0 ? 0 : M - k];
+    const float2 b = make_float2(b0.x, -b0.y);                                  // conj Z[M - k]
+    const float2 s = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y)), d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 w = k == M ? make_float2(-1.f, 0.f) : tw[k];                   // e^{-2 pi i k / N}
+    const float2 wd = cmul(w, d);
+    return make_float2(s.x + wd.y, s.y - wd.x);                                 // s - i w d
+}
+
+template <int N>
+__global__ __launch_bounds__(N / 8 < 64 ? 64 : N / 8) void stft_mag_fwd_real_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                    const float2* __restrict__ tw, float clamp_min, float* __restrict__ mag, int T,
+                                    int hop, int frames) {
+    constexpr int M = N / 2, Q = M / 4;
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * M];
+    float2 *b0 = lds, *b1 = lds + M;
+    const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x;
+    const float* xb = x + (int64_t)b * T;
+    const int start = f * hop - (N >> 1);
+    if (j < Q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = j + r * Q;
+            float v0 = xb[reflect_index(start + 2 * m, T)], v1 = xb[reflect_index(start + 2 * m + 1, T)];
+            if (window) { v0 *= window[2 * m]; v1 *= window[2 * m + 1]; }
+            b0[m] = make_float2(v0, v1);
+        }
+    }
+    const float2* Z = lds_fft(b0, b1, tw, M, 2);
+    const int bins = M + 1;
+    float* out = mag + ((int64_t)b * frames + f) * bins;
+    for (int k = j; k < bins; k += blockDim.x) {
+        const float2 c = rfft_unpack<N>(Z, tw, k);
+        const float p = c.x * c.x + c.y * c.y;
+        out[k] = sqrtf(clamp_min >= 0.f ? fmaxf(p, clamp_min) : p);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(N / 8 < 64 ? 64 : N / 8) void stft_mag_bwd_real_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                    const float2* __restrict__ tw, float clamp_min, const float* __restrict__ dmag,
+                                    float* __restrict__ dx, int T, int hop, int frames) {
+    constexpr int M = N / 2, Q = M / 4;
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * M];
+    __shared__ __attribute__((aligned(16))) float2 hs[M + 1];                     // A_k, k = 0 .. M
+    float2 *b0 = lds, *b1 = lds + M;
+    const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x;
+    const float* xb = x + (int64_t)b * T;
+    const int start = f * hop - (N >> 1);
+    if (j < Q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = j + r * Q;
+            float v0 = xb[reflect_index(start + 2 * m, T)], v1 = xb[reflect_index(start + 2 * m + 1, T)];
+            if (window) { v0 *= window[2 * m]; v1 *= window[2 * m + 1]; }
+            b0[m] = make_float2(v0, v1);
+        }
+    }
+    float2* Z = lds_fft(b0, b1, tw, M, 2);
+    float2* other = (Z == b0) ? b1 : b0;
+    const float* g = dmag + ((int64_t)b * frames + f) * (M + 1);
+    for (int k = j; k <= M; k += blockDim.x) {                                    // H_k = conj(dmag_k X_k / |X_k|), Hermitian end points doubled
+        const float2 c = rfft_unpack<N>(Z, tw, k);
+        const float p = c.x * c.x + c.y * c.y;
+        const bool live = clamp_min >= 0.f ? (p >= clamp_min) : (p > 0.f);
+        float2 h = make_float2(0.f, 0.f);
+        if (live) { const float sc = g[k] * rsqrtf(p); h = make_float2(sc * c.x, -sc * c.y); }
+        if (k == 0 || k == M) h = make_float2(2.f * h.x, 0.f);
+        hs[k] = h;
+    }
+    __syncthreads();
+    for (int k = j; k < M; k += blockDim.x) {                                     // P_k
+        const float2 a = hs[k], c0 = hs[M - k];
+        const float2 cj = make_float2(c0.x, -c0.y);
+        const float2 s = cadd(a, cj), d = csub(a, cj);
+        const float2 wd = cmul(tw[k], d);
+        other[k] = make_float2(s.x - wd.y, s.y + wd.x);                           // s + i w d
+    }
+    const float2* U = lds_fft(other, Z, tw, M, 2);
+    float* dxb = dx + (int64_t)b * T;
+    for (int m = j; m < M; m += blockDim.x) {
+        const float2 u = U[m];
+        float v0 = 0.5f * u.x, v1 = 0.5f * u.y;
+        if (window) { v0 *= window[2 * m]; v1 *= window[2 * m + 1]; }
+        if (v0 != 0.f) atomicAdd(dxb + reflect_index(start + 2 * m, T), v0);
+        if (v1 != 0.f) atomicAdd(dxb + reflect_index(start + 2 * m + 1, T), v1);
+    }
+}
+
 static int stft_check(const void* x, const void* tw, int64_t B, int64_t T, int64_t N, int64_t hop) {
     if (!x || !tw || B <= 0 || hop <= 0) return 0;
     if (N < 16 || N > 4096 || (N & (N - 1))) return 0;
@@ -169,6 +271,19 @@ extern "C" int osp_stft_mag_fwd(const float* x, const float* window, const float
                                 int64_t B, int64_t T, int64_t N, int64_t hop, hipStream_t stream) {
     OSP_CHECK_ARG(stft_check(x, tw, B, T, N, hop) && mag, "bad STFT arguments");
     const int frames = (int)(1 + T / hop);
+    static int use_real = -1;
+    if (use_real < 0) { const char* e = getenv("OSP_STFT_REAL"); use_real = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_real && N >= 64) {
+#define OSP_STFT_FWDR(NN) case NN: hipLaunchKernelGGL((stft_mag_fwd_real_kernel<NN>), dim3((unsigned)frames, (unsigned)B), dim3(NN / 8), 0, stream, \
+                       x, window, (const float2*)tw, clamp_min, mag, (int)T, (int)hop, frames); break
+        switch ((int)N) {
+            OSP_STFT_FWDR(64); OSP_STFT_FWDR(128); OSP_STFT_FWDR(256); OSP_STFT_FWDR(512); OSP_STFT_FWDR(1024); OSP_STFT_FWDR(2048); OSP_STFT_FWDR(4096);
+            default: OSP_CHECK_ARG(false, "n_fft must be a power of two in [16, 4096]");
+        }
+#undef OSP_STFT_FWDR
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
 #define OSP_STFT_FWD(NN) case NN: hipLaunchKernelGGL((stft_mag_fwd_kernel<NN>), dim3((unsigned)frames, (unsigned)B), dim3(NN / 4), 0, stream, \
                        x, window, (const float2*)tw, clamp_min, mag, (int)T, (int)hop, frames); break
     switch ((int)N) {
@@ -186,6 +301,19 @@ extern "C" int osp_stft_mag_bwd(const float* x, const float* window, const float
                                 float* dx, int64_t B, int64_t T, int64_t N, int64_t hop, hipStream_t stream) {
     OSP_CHECK_ARG(stft_check(x, tw, B, T, N, hop) && dmag && dx, "bad STFT arguments");
     const int frames = (int)(1 + T / hop);
+    static int use_real = -1;
+    if (use_real < 0) { const char* e = getenv("OSP_STFT_REAL"); use_real = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_real && N >= 64) {
+#define OSP_STFT_BWDR(NN) case NN: hipLaunchKernelGGL((stft_mag_bwd_real_kernel<NN>), dim3((unsigned)frames, (unsigned)B), dim3(NN / 8), 0, stream, \
+                       x, window, (const float2*)tw, clamp_min, dmag, dx, (int)T, (int)hop, frames); break
+        switch ((int)N) {
+            OSP_STFT_BWDR(64); OSP_STFT_BWDR(128); OSP_STFT_BWDR(256); OSP_STFT_BWDR(512); OSP_STFT_BWDR(1024); OSP_STFT_BWDR(2048); OSP_STFT_BWDR(4096);
+            default: OSP_CHECK_ARG(false, "n_fft must be a power of two in [16, 4096]");
+        }
+#undef OSP_STFT_BWDR
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
 #define OSP_STFT_BWD(NN) case NN: hipLaunchKernelGGL((stft_mag_bwd_kernel<NN>), dim3((unsigned)frames, (unsigned)B), dim3(NN / 4), 0, stream, \
                        x, window, (const float2*)tw, clamp_min, dmag, dx, (int)T, (int)hop, frames); break
     switch ((int)N) {

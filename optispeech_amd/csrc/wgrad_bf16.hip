@@ -612,6 +612,8 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.x_step_h = (int)d2[3]; p.pad_h = (int)d2[4];
     p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
     osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);          // measurement aid (api.cpp)
+    osp_note_bytes((double)batch * ((double)M * N * (y_bf16 ? 2.0 : 4.0) + (double)(M / Trows) * d2[1] * Tin * Cin * (x_bf16 ? 2.0 : 4.0) +
+                                    (double)N * taps * Cin * 4.0));
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;

@@ -782,6 +782,26 @@ def run_on_side_stream(key, fn, inputs):
     return out
 
 
+class ClipFn(torch.autograd.Function):
+    """clip(x, lo, hi) (WaveNeXtHead, wavenext/__init__.py:47) on osp_clip; the gradient passes where lo <= x <= hi."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        K.call("osp_clip", x, None, out, x.numel(), float(lo), float(hi))
+        ctx.save_for_backward(x)
+        ctx.lim = (float(lo), float(hi))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        K.call("osp_clip", x, dy.contiguous(), dx, x.numel(), ctx.lim[0], ctx.lim[1])
+        return dx, None, None
+
+
 _named = {}
 
 

@@ -220,3 +220,20 @@ def test_period_fold_matches_reflect_pad_and_view(period, B, T):
     want.backward(g)
     got.backward(g)
     torch.testing.assert_close(x.grad, xr.grad, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 32 * 64 * 256 + 3])
+def test_clip_matches_torch_clamp_forward_and_backward(n):
+    """osp_clip (WaveNeXtHead's clip to [-1, 1], wavenext/__init__.py:47) vs torch.clip incl. its gradient rule at the limits."""
+    from optispeech_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * 1.5
+    x[: min(n, 3)] = torch.tensor([1.0, -1.0, 0.0])[: min(n, 3)]             # exactly on the limits: the gradient passes (<=, >=)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.clip(xr, min=-1.0, max=1.0)
+    dy = torch.randn(n, generator=g)
+    yr.backward(dy)
+    xg = x.to("cuda").requires_grad_(True)
+    y = ops.ClipFn.apply(xg, -1.0, 1.0)
+    y.backward(dy.to("cuda"))
+    assert torch.equal(y.detach().cpu(), yr.detach()) and torch.equal(xg.grad.cpu(), xr.grad)

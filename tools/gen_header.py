@@ -94,6 +94,8 @@ REPLACES = {
     "osp_abi_version": "ABI version of this library",
     "osp_kernel_note_host": "measurement aid, no reference counterpart: symbol and algorithmic flops of the matrix-core kernel(s) the calling "
                             "thread's last entry-point call launched (bench.py's roofline block reads it; cleared by the read)",
+    "osp_kernel_note_bytes_host": "measurement aid: algorithmic HBM bytes of the launches osp_kernel_note_host reports (decides matrix-pipe-bound vs HBM-bound)",
+    "osp_clip": "torch.clip(audio, -1, 1) of WaveNeXtHead.forward and its backward: vocoder/wavenext/__init__.py:47",
     "osp_stream_handover": "torch.cuda.Event.record + Stream.wait_event of the multi-stream schedule in one call (no reference counterpart: "
                            "the reference runs on one stream)",
     "osp_conv2d_gemm_bf16_multi": "the same layer of the five DiscriminatorP / three DiscriminatorR stacks in one grid "
