@@ -241,9 +241,14 @@ __global__ __launch_bounds__(64) void mas_kernel(const float* __restrict__ lp, c
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = r * 64 + lane;
-            double prev = __shfl_up(q[r], 1, 64);
-            if (lane == 0) prev = carry;
-            carry = __shfl(q[r], 63, 64);
+            // column i - 1 of the previous frame: a whole-wave shift by one lane (DPP wave_shr:1, lane 0 takes the carry = lane 63 of
+            // the previous 64-column group) and a readlane -- round 2 used __shfl_up / __shfl on doubles = four ds_bpermute round
+            // trips through the LDS crossbar per group and step, on the critical path of a T-step recursion
+            const int qlo = __double2loint(q[r]), qhi = __double2hiint(q[r]);
+            const int plo = __builtin_amdgcn_update_dpp(__double2loint(carry), qlo, 0x138, 0xf, 0xf, false);
+            const int phi = __builtin_amdgcn_update_dpp(__double2hiint(carry), qhi, 0x138, 0xf, 0xf, false);
+            const double prev = __hiloint2double(phi, plo);
+            carry = __hiloint2double(__builtin_amdgcn_readlane(qhi, 63), __builtin_amdgcn_readlane(qlo, 63));
             const bool take_prev = prev >= q[r];
             const unsigned long long mask = __ballot(take_prev);
             if (lane == 0) bits[(int64_t)j * R + r] = mask;

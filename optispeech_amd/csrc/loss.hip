@@ -210,6 +210,29 @@ __global__ __launch_bounds__(256) void ctc_frame_lse_kernel(const float* __restr
     if (lane == 0) lse[row] = mx + logf(sm);
 }
 
+// Branch-free log-sum-exp on the hardware exp2 / log2 (v_exp_f32 / v_log_f32 behind __expf / __logf, ~1 ulp each): the recursions
+// below are ~1 600 dependent steps whose length IS the instruction stream of one wave -- the library expf / logf (range reduction,
+// denormal paths) plus the -inf branches made a step ~200 instructions.  All-(-inf) inputs: the max is replaced by 0 for the
+// differences, exp(-inf) = 0, log(0) = -inf -- no branch.  The error per step is ~1e-7 absolute on log(sum <= 3).
+__device__ __forceinline__ float lse2_fast(float a, float b) {
+    const float m = fmaxf(a, b), ms = m == -INFINITY ? 0.f : m;
+    return m + __logf(__expf(a - ms) + __expf(b - ms));
+}
+__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c)), ms = m == -INFINITY ? 0.f : m;
+    return m + __logf(__expf(a - ms) + __expf(b - ms) + __expf(c - ms));
+}
+
+// Barrier for the LDS column exchange of the recursions below.  __syncthreads() carries a workgroup fence that the compiler
+// lowers to s_waitcnt vmcnt(0): every step then waited for the global store of its alpha row (and drained the emission prefetch
+// ring) -- ~1 us per step, 1.7-1.8 ms for T = 800, which is what the kernel cost until this was found (round 3).  The exchange
+// only needs the LDS operations of this wave complete (lgkmcnt(0)) and the barrier itself; global stores stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int64_t* __restrict__ x_len,
                                          const int64_t* __restrict__ y_len, float log_blank, float* __restrict__ alpha_ws,
                                          const float* __restrict__ lse_ws, float* __restrict__ loss_item,
@@ -230,35 +253,46 @@ __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int
     const int tok = s >> 1;
     float* col[2] = {sh + 2, sh + (SW + 2) + 2};
     if (s < 2) { sh[s] = -INFINITY; sh[(SW + 2) + s] = -INFINITY; }
-    // Both recursions are T dependent steps (LDS exchange + barrier + three expf / one logf: ~0.15 us); round 2 also LOADED each
-    // step's emission -- and in the second pass the stored alpha -- inside the step, a full memory latency per step (1.7 ms for
-    // T = 800).  Now the values of the next CPD steps are in flight in a register ring (loops unrolled by CPD).
+    // Both recursions are T dependent steps (LDS exchange + barrier + three expf / one logf).  Round 2 loaded each step's
+    // emission -- and in the second pass the stored alpha -- inside the step: a memory latency per step.  A register RING refilled
+    // inside the steps did not help: behind the divergent -inf branches of lse3 the compiler waits with vmcnt(0) in every step,
+    // which drains the ring and the alpha store.  So the values are fetched a CHUNK ahead: the loads of chunk c + 1 are issued
+    // before the CPD steps of chunk c, which touch no load result; the only vmcnt wait sits at the chunk boundary.
     constexpr int CPD = 8;
-    auto emis = [&](int t) -> float { return live ? ((lab ? L[(int64_t)t * Nm + tok] : log_blank) - LW[t]) : -INFINITY; };
+    // the loads of a chunk are UNCONDITIONAL (clamped indices) and nothing is computed from them until the step that uses them:
+    // a conditional load is an exec-masked branch and arithmetic right behind a load is a wait -- either serialises the chunk's
+    // loads, one memory latency each
+    const int tokc = (live && lab) ? tok : 0;
+    struct Em { float l, w; };
+    auto fetch = [&](int t) -> Em { const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t); Em e; e.l = L[(int64_t)tc * Nm + tokc]; e.w = LW[tc]; return e; };
+    auto emis_of = [&](const Em& e) -> float { return live ? ((lab ? e.l : log_blank) - e.w) : -INFINITY; };
     // ---- alpha
     float a = -INFINITY;
-    float yq[CPD];
+    Em yc[CPD], yn[CPD];
 #pragma unroll
-    for (int k = 0; k < CPD; ++k) yq[k] = k < T ? emis(k) : -INFINITY;
+    for (int k = 0; k < CPD; ++k) yc[k] = fetch(k);
     for (int t0 = 0; t0 < T; t0 += CPD) {
 #pragma unroll
-      for (int k = 0; k < CPD; ++k) {
-        const int t = t0 + k;
-        if (t >= T) break;                                              // block-uniform
-        const float y = yq[k];
-        yq[k] = t + CPD < T ? emis(t + CPD) : -INFINITY;
-        float v;
-        if (t == 0) v = (s < 2 && live) ? y : -INFINITY;
-        else {
-            const float* pc = col[(t - 1) & 1];
-            v = lab ? lse3(a, pc[s - 1], pc[s - 2]) : lse2(a, pc[s - 1]);
-            v = live ? v + y : -INFINITY;
+        for (int k = 0; k < CPD; ++k) yn[k] = fetch(t0 + CPD + k);
+#pragma unroll
+        for (int k = 0; k < CPD; ++k) {
+            const int t = t0 + k;
+            if (t >= T) break;                                          // block-uniform
+            const float y = emis_of(yc[k]);
+            float v;
+            if (t == 0) v = (s < 2 && live) ? y : -INFINITY;
+            else {
+                const float* pc = col[(t - 1) & 1];
+                v = lse3_fast(a, pc[s - 1], lab ? pc[s - 2] : -INFINITY);          // (a third term of -inf contributes exp(-inf) = 0)
+                v = live ? v + y : -INFINITY;
+            }
+            a = v;
+            col[t & 1][s] = v;
+            AW[(int64_t)t * SW + s] = v;
+            lds_barrier();
         }
-        a = v;
-        col[t & 1][s] = v;
-        AW[(int64_t)t * SW + s] = v;
-        __syncthreads();
-      }
+#pragma unroll
+        for (int k = 0; k < CPD; ++k) yc[k] = yn[k];
     }
     if (s == 0) {
         const float* pc = col[(T - 1) & 1];
@@ -273,37 +307,36 @@ __global__ void forwardsum_ctc_mw_kernel(const float* __restrict__ lp, const int
     const float gs = 1.f / ((float)N * (float)B);
     // ---- beta + gradient (columns stored with two trailing guard cells: index s+1, s+2 may run past S)
     float be = -INFINITY;
-    float aq[CPD];
+    float ac[CPD], an[CPD];
+    auto alpha_at = [&](int t) -> float { return AW[(int64_t)(t < 0 ? 0 : t) * SW + s]; };        // (every thread owns column s of its rows)
 #pragma unroll
-    for (int k = 0; k < CPD; ++k) {
-        const int t = T - 1 - k;
-        yq[k] = t >= 0 ? emis(t) : -INFINITY;
-        aq[k] = (t >= 0 && live && lab) ? AW[(int64_t)t * SW + s] : 0.f;
-    }
+    for (int k = 0; k < CPD; ++k) { const int t = T - 1 - k; yc[k] = fetch(t); ac[k] = alpha_at(t); }
     for (int t0 = T - 1; t0 >= 0; t0 -= CPD) {
 #pragma unroll
-      for (int k = 0; k < CPD; ++k) {
-        const int t = t0 - k;
-        if (t < 0) break;                                               // block-uniform
-        const float y = yq[k], al = aq[k];
-        yq[k] = t - CPD >= 0 ? emis(t - CPD) : -INFINITY;
-        aq[k] = (t - CPD >= 0 && live && lab) ? AW[(int64_t)(t - CPD) * SW + s] : 0.f;
-        float v;
-        if (t == T - 1) v = (s == S - 1 || s == S - 2) ? y : -INFINITY;
-        else {
-            const float* pc = col[(t + 1) & 1];
-            const float n1 = s + 1 < S ? pc[s + 1] : -INFINITY, n2 = s + 2 < S ? pc[s + 2] : -INFINITY;
-            v = (lab && s + 2 < S) ? lse3(be, n1, n2) : lse2(be, n1);
-            v = live ? v + y : -INFINITY;
+        for (int k = 0; k < CPD; ++k) { const int t = t0 - CPD - k; yn[k] = fetch(t); an[k] = alpha_at(t); }
+#pragma unroll
+        for (int k = 0; k < CPD; ++k) {
+            const int t = t0 - k;
+            if (t < 0) break;                                           // block-uniform
+            const float y = emis_of(yc[k]), al = ac[k];
+            float v;
+            if (t == T - 1) v = (s == S - 1 || s == S - 2) ? y : -INFINITY;
+            else {
+                const float* pc = col[(t + 1) & 1];
+                const float n1 = s + 1 < S ? pc[s + 1] : -INFINITY, n2 = s + 2 < S ? pc[s + 2] : -INFINITY;
+                v = lse3_fast(be, n1, (lab && s + 2 < S) ? n2 : -INFINITY);
+                v = live ? v + y : -INFINITY;
+            }
+            be = v;
+            col[t & 1][s] = v;
+            if (live && lab) {
+                const float occ = expf(al + v + nll - y);
+                G[(int64_t)t * Nm + tok] = (expf(y) - occ) * gs;
+            }
+            lds_barrier();
         }
-        be = v;
-        col[t & 1][s] = v;
-        if (live && lab) {
-            const float occ = expf(al + v + nll - y);
-            G[(int64_t)t * Nm + tok] = (expf(y) - occ) * gs;
-        }
-        __syncthreads();
-      }
+#pragma unroll
+        for (int k = 0; k < CPD; ++k) { yc[k] = yn[k]; ac[k] = an[k]; }
     }
 }
 

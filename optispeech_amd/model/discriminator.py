@@ -291,6 +291,7 @@ class _Multi(nn.Module):
         joins the streams at the end of backward(), so the backward overlaps the same way."""
         main = torch.cuda.current_stream()
         streams = _disc_streams(id(self), len(self.discriminators), x.device)
+        assert len(streams) == len(self.discriminators)
         if ready is None:
             ready = main.record_event()
         outs = []
@@ -358,7 +359,10 @@ def on_side_stream(key, fn, inputs):
 
 
 def _disc_streams(key, n, device):
-    k = (key, torch.device(device).index)
+    """n persistent side streams for ``key``.  The COUNT is part of the cache key: callers key by id(module), CPython re-uses the id
+    of a collected object, and a five-stack family that inherited a dead three-stack family's entry was zipped against three
+    streams -- two sub-discriminators silently dropped (found in round 3 by a test that builds both families in one process)."""
+    k = (key, n, torch.device(device).index)
     if k not in _STREAMS:
         pool = [torch.cuda.Stream(device=device) for _ in range(min(n, _MAX_STREAMS))]
         _STREAMS[k] = [pool[i % len(pool)] for i in range(n)]
