@@ -210,37 +210,38 @@ __global__ __launch_bounds__(64) void mas_kernel(const float* __restrict__ lp, c
 
     double q[R];
     float acc0 = 0.f;
-    // The recursion is T dependent steps of ~0.1 us of arithmetic each; a row of log-probabilities requested ONE step ahead
-    // (round 2) arrives after ~0.5-1 us, i.e. every step waited for memory (0.46 ms for T = 800 -- on the critical chain of the
-    // training step).  Now the rows of the next PD frames are in flight: a ring of PD register rows, loop unrolled by PD.
-    constexpr int PD = 8;
-    float pre[PD][R];
+    // The recursion is T dependent steps of a few dozen instructions; what it must never do is wait for memory inside a step.
+    // Round 2 requested a row ONE step ahead (every step waited a memory latency: 0.46 ms for T = 800, on the critical chain of
+    // the training step).  A register ring refilled inside the steps is no better: the use of an old entry makes the compiler
+    // drain vmcnt, the just-issued refill included, and a conditional load is an exec-masked branch.  So: the rows of the NEXT
+    // PD frames are requested as a chunk -- unconditional loads from clamped indices, untouched until the chunk is used -- before
+    // the PD steps of the current chunk, which consume registers only; one wait per chunk.
+    constexpr int PD = R <= 4 ? 8 : (R <= 8 ? 4 : 2);                  // 2 * PD * R row registers: wide texts take shorter chunks
+    float cur[PD][R], nxt[PD][R];
+    int icl[R];
 #pragma unroll
-    for (int k = 0; k < PD; ++k)
+    for (int r = 0; r < R; ++r) { const int i = r * 64 + lane; icl[r] = i < N ? i : 0; q[r] = -INFINITY; }
+    auto fetch = [&](float (&dst)[PD][R], int j0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = r * 64 + lane;
-            pre[k][r] = (k < T && i < N) ? L[(int64_t)k * Nm + i] : 0.f;
+        for (int k = 0; k < PD; ++k) {
+            const int j = j0 + k < T ? j0 + k : T - 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[k][r] = L[(int64_t)j * Nm + icl[r]];
         }
-#pragma unroll
-    for (int r = 0; r < R; ++r) q[r] = -INFINITY;
+    };
+    fetch(cur, 0);
     for (int j0 = 0; j0 < T; j0 += PD) {
+      fetch(nxt, j0 + PD);
 #pragma unroll
       for (int k = 0; k < PD; ++k) {
         const int j = j0 + k;
         if (j >= T) break;                                             // wave-uniform
-        float cur[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            cur[r] = pre[k][r];
-            const int i = r * 64 + lane;
-            pre[k][r] = (j + PD < T && i < N) ? L[(int64_t)(j + PD) * Nm + i] : 0.f;   // frame j + PD takes the slot
-        }
         double qn[R];
         double carry = 0.0;   // lane 63 of the previous round (column j-1)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = r * 64 + lane;
+            const float lpv = i < N ? cur[k][r] : 0.f;
             // column i - 1 of the previous frame: a whole-wave shift by one lane (DPP wave_shr:1, lane 0 takes the carry = lane 63 of
             // the previous 64-column group) and a readlane -- round 2 used __shfl_up / __shfl on doubles = four ds_bpermute round
             // trips through the LDS crossbar per group and step, on the critical path of a T-step recursion
@@ -251,21 +252,25 @@ __global__ __launch_bounds__(64) void mas_kernel(const float* __restrict__ lp, c
             carry = __hiloint2double(__builtin_amdgcn_readlane(qhi, 63), __builtin_amdgcn_readlane(qlo, 63));
             const bool take_prev = prev >= q[r];
             const unsigned long long mask = __ballot(take_prev);
-            if (lane == 0) bits[(int64_t)j * R + r] = mask;
-            double v;
-            if (i == 0) {
-                acc0 = acc0 + cur[r];                                  // sequential f32 prefix sum (:186-188)
-                v = (double)acc0;
-            } else if (i < N && i <= j) {
-                v = (take_prev ? prev : q[r]) + (double)cur[r];        // :191-193
-            } else {
-                v = -INFINITY;
-            }
-            qn[r] = v;
+            // every lane stores the (wave-uniform) mask to the same address: one LDS / memory transaction, and no exec-mask branch
+            // in the step; typed stores (a generic pointer is a flat store, which counts against both vmcnt and lgkmcnt)
+            if (bits_in_lds) sbits[(int64_t)j * R + r] = mask;
+            else bits_ws[((int64_t)b * Tm + j) * R + r] = mask;
+            // branch-free (three-way divergent branches cost more scalar latency per step than the arithmetic they skip):
+            // column 0 is the sequential f32 prefix sum (:186-188), columns 1 .. min(j, N - 1) the DP update (:191-193), the
+            // rest -inf.  Values and operation order per column are exactly those of the branched form.
+            if (r == 0) acc0 = acc0 + (i == 0 ? lpv : 0.f);            // only lane 0 of group 0 ever reads it (compile-time r)
+            const double v_dp = (take_prev ? prev : q[r]) + (double)lpv;
+            const double v_in = (i < N && i <= j) ? v_dp : (double)-INFINITY;
+            qn[r] = (i == 0) ? (double)acc0 : v_in;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) q[r] = qn[r];
       }
+#pragma unroll
+      for (int k = 0; k < PD; ++k)
+#pragma unroll
+          for (int r = 0; r < R; ++r) cur[k][r] = nxt[k][r];
     }
     __syncthreads();   // single wave: orders the LDS / global bit stores before lane 0 reads them
     if (lane == 0) {
