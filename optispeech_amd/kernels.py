@@ -838,6 +838,34 @@ def attn_fused_fwd(q, k, v, klen, H):
     return o
 
 
+def attn_train_fwd(q, k, v, klen, H, drop_p=0.0, seed=0, stream_id=0):
+    """Fused training forward (csrc/attention_train.hip): (B, T, H*dk) f32 q, k, v -> (o, lse); the (T x T) scores never exist.
+    The dropout mask is the one osp_attn_softmax_fwd would draw from the same (seed, stream_id)."""
+    _f32(q, k, v)
+    B, T, C = q.shape
+    dk = C // H
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and klen.dtype == torch.int64
+    o = torch.empty_like(q)
+    lse = torch.empty((B * H, T), device=q.device, dtype=torch.float32)
+    sh, sd = _seed(seed)
+    call("osp_attn_train_fwd", q, k, v, klen, o, lse, B, H, T, dk, 1.0 / float(dk) ** 0.5, float(drop_p), sh, sd, int(stream_id))
+    return o, lse
+
+
+def attn_train_bwd(q, k, v, o, lse, dout, klen, H, drop_p=0.0, seed=0, stream_id=0):
+    """Fused backward: recomputes the probabilities tile by tile; returns (dq, dk, dv) in the (B, T, H*dk) layout."""
+    _f32(q, k, v, o, dout)
+    B, T, C = q.shape
+    dk = C // H
+    assert dout.is_contiguous()
+    dq, dkk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    dbuf = torch.empty_like(lse)
+    sh, sd = _seed(seed)
+    call("osp_attn_train_bwd", q, k, v, o, lse, dout, klen, dq, dkk, dv, dbuf, B, H, T, dk, 1.0 / float(dk) ** 0.5, float(drop_p),
+         sh, sd, int(stream_id))
+    return dq, dkk, dv
+
+
 def attn_softmax_bwd(P, dPd, scale, drop_p=0.0, seed=0, stream_id=0):
     """in place: dPd (gradient w.r.t. the dropped probabilities) -> gradient w.r.t. the raw scores."""
     T2 = P.shape[-1]

@@ -162,6 +162,7 @@ class side_wgrad:
 
 _FUSED_LN_DW = _os.environ.get("OSP_FUSED_LN_DW", "1") != "0"
 _FUSED_ATTN = _os.environ.get("OSP_FUSED_ATTN", "1") != "0"
+_FUSED_ATTN_TRAIN = _os.environ.get("OSP_FUSED_ATTN_TRAIN", "1") != "0"
 
 
 class ConvNeXtBlockFn(torch.autograd.Function):
@@ -690,6 +691,17 @@ class AttentionFn(torch.autograd.Function):
                 and _precision.is_bf16() and dk in (32, 64, 128)):
             # no-grad / inference: one flash-style kernel, the (B*H, T, T) scores never exist (csrc/attention.hip)
             return K.attn_fused_fwd(q.contiguous(), k.contiguous(), v.contiguous(), klen, H)
+        ctx.fused = False
+        if (_FUSED_ATTN_TRAIN and sbias is None and q.is_cuda and _precision.is_bf16() and dk in (32, 64, 128)):
+            # training, performance mode: fused forward that keeps the per-row log-sum-exp, fused recomputing backward
+            # (csrc/attention_train.hip) -- no (B*H, T, T) tensor in either direction, no head-major copies
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+            o, lse = K.attn_train_fwd(q, k, v, klen, H, drop_p, seed, stream_id)
+            if any(ctx.needs_input_grad[:3]):
+                ctx.save_for_backward(q, k, v, o, lse, klen)
+                ctx.cfg = (H, drop_p, seed, stream_id)
+                ctx.fused = True
+            return o
         heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)      # noqa: E731
         qh, kh, vh = heads(q), heads(k), heads(v)
         scale = 1.0 / float(dk) ** 0.5
@@ -706,6 +718,11 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.fused:
+            q, k, v, o, lse, klen = ctx.saved_tensors
+            H, drop_p, seed, stream_id = ctx.cfg
+            dq, dk_, dv = K.attn_train_bwd(q, k, v, o, lse, dout.contiguous(), klen, H, drop_p, seed, stream_id)
+            return dq, dk_, dv, None, None, None, None, None, None
         qh, kh, vh, P, Pd = ctx.saved_tensors
         B, T, H, dk, scale, drop_p, seed, stream_id = ctx.cfg
         Z = B * H

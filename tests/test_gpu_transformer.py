@@ -136,8 +136,87 @@ def test_attention_function_takes_the_fused_kernel_without_grad():
         klen = torch.tensor([96, 40], device=DEV)
         with torch.no_grad():
             fused = ops.AttentionFn.apply(q, k, v, klen, 2, 0.0, 0, 0)
-        ref = ops.AttentionFn.apply(q.requires_grad_(True), k, v, klen, 2, 0.0, 0, 0)                  # unfused (saves probabilities)
+        keep = ops._FUSED_ATTN_TRAIN
+        ops._FUSED_ATTN_TRAIN = False
+        try:
+            ref = ops.AttentionFn.apply(q.requires_grad_(True), k, v, klen, 2, 0.0, 0, 0)              # unfused (saves probabilities)
+        finally:
+            ops._FUSED_ATTN_TRAIN = keep
         assert ref.grad_fn is not None
         torch.testing.assert_close(fused, ref.detach(), rtol=3e-2, atol=3e-2)
     finally:
+        precision.set_precision("f32")
+
+
+def _dropout_keep(Z, T, p, seed, stream_id):
+    """The keep / (1 - p) factors the attention kernels draw for element (z, i, j): read back from the UNFUSED softmax kernel on
+    all-zero scores (P is uniform and positive there, so Pd / P is the factor)."""
+    from optispeech_amd import kernels as K
+    if p == 0.0:
+        return torch.ones(Z, T, T, dtype=torch.float64)
+    S = torch.zeros(Z, T, T, device=DEV)
+    P, Pd = K.attn_softmax_fwd(S, torch.full((Z,), T, device=DEV, dtype=torch.int64), Z, 1, T, T, 1.0, p, seed, stream_id)
+    return (Pd / P).double().cpu()
+
+
+@pytest.mark.parametrize("B,T,H,dk,p", [(3, 37, 2, 32, 0.0), (2, 130, 2, 64, 0.2), (2, 800, 2, 128, 0.2), (1, 5, 4, 32, 0.3),
+                                        (2, 257, 2, 128, 0.0), (2, 131, 2, 128, 0.2)])
+def test_fused_attention_training_pair_vs_f64(B, T, H, dk, p):
+    """osp_attn_train_fwd / osp_attn_train_bwd (csrc/attention_train.hip: no (T x T) tensor in HBM, probabilities recomputed in the
+    backward) against MultiHeadedAttention's arithmetic (_transformer/attention.py:80-98, :120-125: masked softmax -> masked_fill 0
+    -> dropout -> P V) in f64 autograd, on bf16-rounded operands and with the SAME Philox dropout mask.  Ragged key lengths,
+    query / key blocks that end inside the sequence, T not a multiple of 4 (the Philox block of an element then straddles rows).
+    Tolerances: bf16 rounding of P / dS before their second product (unit round-off 4e-3): 1e-2 of the tensor's norm."""
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    C, Z = H * dk, B * H
+    q, k, v, dout = (torch.randn(B, T, C, generator=g).to(DEV) for _ in range(4))
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    klen = lens.to(DEV)
+    seed, sid = 4242, 7
+    o, lse = K.attn_train_fwd(q, k, v, klen, H, p, seed, sid)
+    dq, dk_, dv = K.attn_train_bwd(q, k, v, o, lse, dout, klen, H, p, seed, sid)
+    keep = _dropout_keep(Z, T, p, seed, sid).view(B, H, T, T)
+    bf = lambda t: t.to(torch.bfloat16).double().cpu()                                            # noqa: E731
+    q64, k64, v64 = (bf(t).requires_grad_(True) for t in (q, k, v))
+    heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3)                                     # noqa: E731
+    s = heads(q64) @ heads(k64).transpose(-1, -2) / dk ** 0.5
+    mask = torch.arange(T)[None, None, None, :] >= lens[:, None, None, None]
+    P = torch.softmax(s.masked_fill(mask, float("-inf")), -1).masked_fill(mask, 0.0)
+    want = ((P * keep) @ heads(v64)).permute(0, 2, 1, 3).reshape(B, T, C)
+    want.backward(bf(dout))
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()        # noqa: E731
+    assert rel(o, want.detach()) < 1e-2
+    want_lse = torch.logsumexp(s.detach().masked_fill(mask, float("-inf")), -1).reshape(Z, T)
+    assert (lse.double().cpu() - want_lse).abs().max().item() < 2e-2
+    assert rel(dq, q64.grad) < 1.5e-2 and rel(dk_, k64.grad) < 1.5e-2 and rel(dv, v64.grad) < 1.5e-2
+    # keys past an utterance's length receive exactly zero gradient
+    for b in range(B):
+        assert torch.count_nonzero(dk_[b, int(lens[b]):]) == 0 and torch.count_nonzero(dv[b, int(lens[b]):]) == 0
+
+
+def test_attention_function_trains_through_the_fused_pair():
+    """In the performance mode AttentionFn routes a training call through the fused pair; same dropout mask as the unfused path,
+    so the two agree to the bf16 rounding of their operands (outputs and all three gradients)."""
+    from optispeech_amd import ops, precision
+    precision.set_precision("bf16")
+    keep = ops._FUSED_ATTN_TRAIN
+    try:
+        g = torch.Generator().manual_seed(11)
+        base = [torch.randn(2, 200, 256, generator=g).to(DEV) for _ in range(3)]
+        dout = torch.randn(2, 200, 256, generator=g).to(DEV)
+        klen = torch.tensor([200, 77], device=DEV)
+        res = {}
+        for fused in (True, False):
+            ops._FUSED_ATTN_TRAIN = fused
+            q, k, v = (t.clone().requires_grad_(True) for t in base)
+            o = ops.AttentionFn.apply(q, k, v, klen, 2, 0.2, 99, 3)
+            o.backward(dout)
+            res[fused] = (o.detach(), q.grad, k.grad, v.grad)
+        for a, b in zip(res[True], res[False]):
+            err = ((a - b).norm() / b.norm()).item()
+            assert err < 2e-2, err
+    finally:
+        ops._FUSED_ATTN_TRAIN = keep
         precision.set_precision("f32")

@@ -43,6 +43,9 @@ REPLACES = {
     "osp_adamw_clip": "torch.optim.AdamW.step + clip_gradients: base_lightning_module.py:96-105,116-125; configs/model/optimizer/adamw.yaml",
     "osp_attn_softmax_fwd": "MultiHeadedAttention.forward_attention masked softmax + dropout: generator/modules/_transformer/attention.py:75-97",
     "osp_attn_softmax_bwd": "autograd of the same (softmax' and the dropout mask regenerated from the Philox counter)",
+    "osp_attn_train_fwd": "MultiHeadedAttention.forward scores -> masked softmax -> dropout -> P V in ONE kernel (training): "
+                          "generator/modules/_transformer/attention.py:80-98,120-125; keeps the per-row log-sum-exp only",
+    "osp_attn_train_bwd": "autograd of the same: probabilities recomputed per tile from q, k and the log-sum-exp (no (T x T) tensor)",
     "osp_conv2d_gemm_bf16": "weight-normed Conv2d forward of DiscriminatorP / DiscriminatorR + F.leaky_relu: "
                             "vocoder/wavenext/disc/_discriminators.py:51-60,63-97 and :154-163,165-194",
     "osp_conv2d_dgrad_bf16": "autograd input gradients of the same strided Conv2d stacks (all stride phases in one launch)",
