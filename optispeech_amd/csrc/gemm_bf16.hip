@@ -13,212 +13,10 @@
 // buffering: the global loads of tile i+1 are in flight while tile i feeds the matrix pipe; one barrier per tile.
 // Sources whose reduction index is NOT the contiguous one (dgrad weights, both wgrad operands) go through a
 // transposing loader: 8 strided rows x float4 per thread, packed to k-contiguous 16-byte LDS slots.
-#include "gemm_bf16_common.h"
+#include "gemm_bf16_glds.h"
 
-// ---- direct-to-LDS variant (bf16 operands in HBM, Cin % 64 == 0): the staging tiles are written by the LDS-DMA path
-// (global_load_lds_dwordx4: 64 lanes x 16 B = 8 rows of 128 B per wave instruction), no VGPR round trip and no
-// ds_write pass.  The LDS image is unpadded 128-byte rows; bank conflicts are avoided with an XOR swizzle of the
-// 16-byte slot, applied on the SOURCE address when staging and on the read address (both-sides rule, guide section 5.4/21):
-//   physical slot = logical k-group ^ ((row >> 1) & 7)
-// Rows that fall into conv padding (or past M / N) read a zero page instead.
-__device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];
+// (the direct-to-LDS body: gemm_bf16_glds.h)
 
-// BM_ = 128: 4 waves of 64x64, two 32 KB stages, 2 workgroups / CU (prefetch distance 1; the second workgroup hides the wait).
-// BM_ = 256: 4 waves of 128x64 (128 accumulator registers), three 48 KB stages, 1 workgroup / CU, prefetch distance 2.
-//   Per k-slab a CU then reads (128 + 64) * 64 * 2 B * 4 waves = 96 KB of fragments for 2 * 256*128*64 flop, i.e. LDS
-//   traffic per flop is 2/3 of the 128x128 tile's (which is LDS-bandwidth bound: 96 KB + 32 KB DMA per 512 MFMA clocks).
-// NW = 8 (512 threads, two waves per SIMD): 256x256 tiles as 2 (M) x 4 (N) waves of 128x64 -- per k-step a wave reads
-//   (128 + 64) rows x 32 B of fragments for 8 MFMAs (the 4-wave 128x128 tile: (64 + 64) x 32 B for 4), and a CU stages
-//   (256 + 256) x 128 B per slab for 4x the flops of a 128x128 tile (2x fewer HBM / L2 bytes per flop); two 64 KB stages,
-//   one barrier per slab, 1 workgroup / CU whose second wave per SIMD covers the other's LDS latency.
-template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false>
-__device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem, const TileCtx tc) {
-    const GemmB pp = gemm_select_phase(pin, tc.z);
-    constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
-    constexpr int RA = BM_ / (8 * NW), RB = BN_ / (8 * NW), TM_ = BM_ / (32 * WM_), TN_ = BN_ / (32 * WN_);   // rows staged per thread (A, B); 32x32 tiles per wave
-    static_assert(TM_ == 2 || TM_ == 4, "wave tile is 64 or 128 rows");
-    unsigned short* As = smem;                       // [NST][BM_][64]
-    unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][BN_][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave / WN_) * (BM_ / WM_), wn0 = (wave % WN_) * (BN_ / WN_);
-    int mb_, nb_;
-    xcd_tile(tc, mb_, nb_);
-    const int m0 = mb_ * BM_, n0 = nb_ * BN_;
-    const int64_t bz = pp.nphase > 0 ? 0 : tc.z;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(pp.A) + bz * pp.sAb;
-    const unsigned short* B = reinterpret_cast<const unsigned short*>(pp.B) + bz * pp.sBb;
-    const int Cin = pp.Cin, Tin = pp.Tin, Hin = pp.Hin, KW = pp.KW, a_tapstep = pp.a_tapstep, a_tapstep_h = pp.a_tapstep_h;
-    const int taps = pp.taps;
-    const int64_t lda = pp.lda, sBn = pp.sBn, sBtap = pp.sBtap, sBtap_h = pp.sBtap_h;
-    const int K = taps * Cin;
-    const int rsub = lane >> 3, pslot = lane & 7;
-    // wave w stages rows 8 * (w * RA + i) + rsub of A (i < RA) and 8 * (w * RB + i) + rsub of B (i < RB)
-    // K ORDER: channel block outer, TAP INNER.  Consecutive k-slabs of a tile then read the same 64 channels of input rows
-    // shifted by one tap step -- 255 of 256 rows of a stride-1 conv were fetched one slab earlier and are L2 (TCP) hits.  In the
-    // tap-major order of round 2 a tile came back to the same rows Cin / 64 slabs later, i.e. after the XCD's co-resident
-    // tiles had streamed Cin / 64 x 32 KB x 32 tiles = 16 MB through its 4 MB L2: every tap re-fetched the activation panel
-    // from MALL / HBM (TCC_EA traffic 2.7x the algorithmic bytes, profiles/r02b_pmc_glds.json).
-    // Per row: the element offset of (tap 0, channel 0) -- may lie outside the tensor, only dereferenced when the tap's frame is
-    // in range -- plus the frame coordinates for the range test; a tap adds a wave-uniform (SGPR) offset.
-    int a_t[RA], a_h[RA]; int64_t a_off0[RA]; int64_t b_row[RB];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int r = 8 * (wave * RA + i) + rsub;
-        const int m = m0 + r;
-        if (m < pp.M) {
-            const int u = fd_div(m, pp.fd_trows), t = m - u * pp.Trows, th = fd_div(t, pp.fd_wrows), tw = t - th * pp.Wrows;
-            a_t[i] = tw * pp.a_step + pp.a_off;
-            a_h[i] = th * pp.a_step_h + pp.a_off_h;
-            a_off0[i] = ((int64_t)u * Hin * Tin + (int64_t)a_h[i] * Tin + a_t[i]) * lda + (pslot ^ ((r >> 1) & 7)) * 8;
-        } else { a_t[i] = -0x40000000; a_h[i] = 0; a_off0[i] = 0; }
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int r = 8 * (wave * RB + i) + rsub;
-        const int n = n0 + r;
-        b_row[i] = n < pp.N ? (int64_t)n * sBn + (pslot ^ ((r >> 1) & 7)) * 8 : -1;
-    }
-    // accumulators as 64-row halves: the epilogue is instantiated per half with compile-time indices only (one 512-byte
-    // array indexed through the epilogue's nested loops stayed a stack object and was stored to scratch every iteration)
-    f32x16 acc0[2][TN_], acc1[2][TN_];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN_; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
-    const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
-
-    // Staging state: per owned row the source pointer of the slab being staged (or the zero page).
-    const unsigned short* a_src[RA]; const unsigned short* b_src[RB];
-    auto set_tap = [&](int j, int cb) {
-        const int kh = (KW == taps) ? 0 : j / KW, kw = j - kh * KW;
-        const int dt = kw * a_tapstep, dh = kh * a_tapstep_h;                                  // wave-uniform
-        const int64_t offA = ((int64_t)dh * Tin + dt) * lda + cb;
-        const int64_t offB = (int64_t)kh * sBtap_h + (int64_t)kw * sBtap + cb;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const bool ok = (unsigned)(a_t[i] + dt) < (unsigned)Tin && (unsigned)(a_h[i] + dh) < (unsigned)Hin;
-            a_src[i] = ok ? A + a_off0[i] + offA : zero;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) b_src[i] = b_row[i] >= 0 ? B + b_row[i] + offB : zero;
-    };
-    int is_j = 0, is_cb = 0;                                   // (tap, channel offset) of the next k-slab to stage
-    // one of the RA + RB row loads of a slab (compile-time index): the loads are spread over the 4 k-steps of the MFMA
-    // phase -- issued back to back at the top of an iteration they queue behind each other in the texture-address unit
-    // (4 waves x 12 x 1 KB at 64 B/clk) and the MFMA pipe idles until the last one has been accepted.
-    auto issue_one = [&](int buf, auto idx) {
-        constexpr int I = decltype(idx)::value;
-        if constexpr (I < RA) {
-            unsigned short* dst = As + buf * BM_ * TBK + (wave * RA + I) * 8 * TBK;      // wave-uniform
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[I]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        } else {
-            constexpr int J = I - RA;
-            unsigned short* dst = Bs + buf * BN_ * TBK + (wave * RB + J) * 8 * TBK;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[J]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    auto issue_quarter = [&](int buf, auto qidx) {             // loads [Q * NL / 4, (Q + 1) * NL / 4)
-        constexpr int Q = decltype(qidx)::value, NL = RA + RB, L0 = Q * NL / 4, L1 = (Q + 1) * NL / 4;
-        if constexpr (L1 - L0 > 0) issue_one(buf, std::integral_constant<int, L0>{});
-        if constexpr (L1 - L0 > 1) issue_one(buf, std::integral_constant<int, L0 + 1>{});
-        if constexpr (L1 - L0 > 2) issue_one(buf, std::integral_constant<int, L0 + 2>{});
-    };
-    // The source pointers of a slab are computed right AFTER the previous slab's loads were issued (issue_end), i.e. in the
-    // shadow of that iteration's remaining MFMAs -- computed at the top of the iteration they delayed its first loads and
-    // first MFMA (8-wave kernel: 128 -> 139 us per launch when this order was introduced).
-    auto issue_begin = [&]() {};
-    auto issue_end = [&]() { ++is_j; if (is_j == taps) { is_j = 0; is_cb += TBK; } if (is_cb < Cin) set_tap(is_j, is_cb); };
-    set_tap(0, 0);
-    auto issue = [&](int buf) {
-        issue_begin();
-        issue_quarter(buf, std::integral_constant<int, 0>{}); issue_quarter(buf, std::integral_constant<int, 1>{});
-        issue_quarter(buf, std::integral_constant<int, 2>{}); issue_quarter(buf, std::integral_constant<int, 3>{});
-        issue_end();
-    };
-    // MFMA phase over slab `buf`; when `ld` >= 0 the next slab's loads go to buffer `ld`, a quarter per k-step
-    auto mma = [&](int buf, int ld) {
-        const unsigned short* as = As + buf * BM_ * TBK;
-        const unsigned short* bs = Bs + buf * BN_ * TBK;
-        const int l31 = lane & 31, lh = lane >> 5;
-        if (ld >= 0) issue_begin();
-        auto kstep = [&](auto ksidx) {
-            constexpr int ks = decltype(ksidx)::value;
-            bf16x8 a[TM_], b[TN_];
-#pragma unroll
-            for (int i = 0; i < TM_; ++i) {
-                const int row = wm0 + 32 * i + l31;
-                a[i] = *reinterpret_cast<const bf16x8*>(as + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
-            }
-#pragma unroll
-            for (int j = 0; j < TN_; ++j) {
-                const int row = wn0 + 32 * j + l31;
-                b[j] = *reinterpret_cast<const bf16x8*>(bs + row * TBK + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 3));
-            }
-            if constexpr (EARLY) {
-                // the whole next slab is requested during the first two k-steps, so the last load has two k-steps of MFMA
-                // time (>= 1000 cycles with two waves per SIMD) to land before the slab-closing vmcnt(0)
-                if (ld >= 0 && ks < 2) {
-                    issue_quarter(ld, std::integral_constant<int, 2 * (ks & 1)>{});
-                    issue_quarter(ld, std::integral_constant<int, 2 * (ks & 1) + 1>{});
-                }
-            } else {
-                if (ld >= 0) issue_quarter(ld, ksidx);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN_; ++j) {
-                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc0[i][j], 0, 0, 0);
-                    if constexpr (TM_ == 4) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + i], b[j], acc1[i][j], 0, 0, 0);
-                }
-        };
-        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
-        if constexpr (EARLY) { if (ld >= 0) issue_end(); }              // all loads of the slab are out: next pointers under k-steps 2-3
-        kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
-        if constexpr (!EARLY) { if (ld >= 0) issue_end(); }
-    };
-    const int nk = K / TBK;
-    if constexpr (NST == 2) {
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            mma(buf, kt + 1 < nk ? (buf ^ 1) : -1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    } else {
-        // three stages, prefetch distance 2: slab kt+2 is issued into the buffer slab kt-1 was read from (every wave has
-        // passed this iteration's barrier, hence finished computing kt-1); the wait leaves slab kt+1's loads in flight.
-        issue(0);
-        if (nk > 1) issue(1);
-        int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // bare s_barrier: __syncthreads() carries a workgroup fence that the compiler lowers to vmcnt(0), which would
-            // drain slab kt+1's LDS-DMA loads at every iteration (i.e. no prefetch at all).  Every wave has waited for its
-            // own slab-kt loads above, so after the barrier the whole slab is in LDS; all ds_reads of the previous
-            // iteration have been consumed by MFMAs (lgkmcnt(0)) before a wave arrives here.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            mma(buf, kt + 2 < nk ? (buf >= 1 ? buf - 1 : 2) : -1);
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-        __syncthreads();
-    }
-    constexpr int SP_ = 32 * TN_ + 8;
-    gemm_bf16_epilogue<2, TN_>(pp, acc0, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * SP_);
-    if constexpr (TM_ == 4) gemm_bf16_epilogue<2, TN_>(pp, acc1, m0, n0, wm0 + 64, wn0, lane, bz, smem + wave * (32 * TM_) * SP_ + 64 * SP_);
-}
-
-extern __shared__ __attribute__((aligned(1024))) unsigned short glds_smem[];
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp) {
     conv_gemm_bf16_glds_body<128, 2>(pp, glds_smem, grid_tile_ctx());
 }
@@ -226,47 +24,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const GemmB pp) {
     conv_gemm_bf16_glds_body<128, 2, 64>(pp, glds_smem, grid_tile_ctx());
 }
-// 8 waves, 256x256 tiles, two 64 KB stages (the epilogue's wave-private staging tiles need 144 KB: that is what is allocated)
-#define GLDS8_LDS (8 * 128 * (32 * 2 + 8) * 2)
-__global__ __launch_bounds__(512) void conv_gemm_bf16_glds8_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<256, 2, 256, 8>(pp, glds_smem, grid_tile_ctx());
-}
-__global__ __launch_bounds__(512) void conv_gemm_bf16_glds8e_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<256, 2, 256, 8, true>(pp, glds_smem, grid_tile_ctx());
-}
-// one workgroup per CU (144 KB of LDS): let the register allocator use the whole 512-entry file of a single wave / SIMD
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_gemm_bf16_glds256_kernel(const GemmB pp) {
-    conv_gemm_bf16_glds_body<256, 3>(pp, glds_smem, grid_tile_ctx());
-}
-
-// ---- GROUPED launch (round 3): up to GEMM_GROUP_MAX problems of the same kernel class in ONE grid -- the same layer of the five
-// DiscriminatorP (three DiscriminatorR) stacks, which differ in operand pointers and row counts only.  One period's 1024 -> 1024
-// layer is 51 x 4 = 204 tiles of 256 x 256 on 256 CUs (80 % of one round, and every number measured on it carried that 80 %);
-// the five together are 1 020 tiles = 3.98 rounds.  It also turns 5 (3) launches into one.  A workgroup finds its problem in the
-// prefix table (wave-uniform scalar work), takes that problem's parameter block out of the kernel-argument segment and runs the
-// unchanged body with a TileCtx of its own.
-#define GEMM_GROUP_MAX 5
-struct GemmGroup { int n; int tile_end[GEMM_GROUP_MAX]; int nb[GEMM_GROUP_MAX]; int mb[GEMM_GROUP_MAX]; GemmB p[GEMM_GROUP_MAX]; };
-__device__ __forceinline__ int group_pick(const GemmGroup& g, TileCtx& tc) {
-    const int bid = blockIdx.x;
-    int k = 0;
-    while (k < g.n - 1 && bid >= g.tile_end[k]) ++k;
-    const int local = bid - (k ? g.tile_end[k - 1] : 0), per = g.nb[k] * g.mb[k];
-    tc.NB = g.nb[k]; tc.MB = g.mb[k]; tc.z = local / per; tc.lin = local - tc.z * per;
-    return k;
-}
-__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_grp_kernel(const GemmGroup g) {
-    TileCtx tc; const int k = group_pick(g, tc);
-    conv_gemm_bf16_glds_body<128, 2>(g.p[k], glds_smem, tc);
-}
-__global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_grp_kernel(const GemmGroup g) {
-    TileCtx tc; const int k = group_pick(g, tc);
-    conv_gemm_bf16_glds_body<128, 2, 64>(g.p[k], glds_smem, tc);
-}
-__global__ __launch_bounds__(512) void conv_gemm_bf16_glds8e_grp_kernel(const GemmGroup g) {
-    TileCtx tc; const int k = group_pick(g, tc);
-    conv_gemm_bf16_glds_body<256, 2, 256, 8, true>(g.p[k], glds_smem, tc);
-}
+// (the 8-wave 256x256 kernels: gemm_bf16_w8.hip; the grouped launches of a discriminator family: gemm_bf16_grp.hip / _w8.hip)
 
 // C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
 // for t < Trows (rows M = utterances * Trows); a tap that leaves [0, Tin) contributes zero.
@@ -536,7 +294,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
     if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 128) {
         // 8-wave 256x256 tiles when they still give every CU work: OSP_GEMM_W8 = 0 (never) / 1 (whenever >= 1 tile per 2 CUs) /
         // unset: the measured crossover (tools/gemm_w8_probe.py)
-        static int w8 = -2, w8_attr = 0;
+        static int w8 = -2;
         static int64_t w8_min = 0;
         if (w8 == -2) {
             const char* e = getenv("OSP_GEMM_W8"); w8 = e ? atoi(e) : -1;
@@ -547,47 +305,26 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
         // 512->1024 and 1024->1024 DiscriminatorP layers at M ~ 13k: 760 -> 950-990 TFLOP/s), -20 % on short-K / narrow layers
         // (K = 640, N = 512: the 256x256 prologue / epilogue is not amortised), neutral at half batch (too few tiles: not taken)
         if (w8 != 0 && N >= 256 && t256 >= (w8 == 1 ? 128 : w8_min) && (w8 == 1 || taps * Cin >= 2304)) {
-            if (!w8_attr) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
-                w8_attr = 1;
-            }
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
             static int early = -1;
             if (kind_out && batch_in == 1) {
                 const char* e = getenv("OSP_GEMM_W8_EARLY");
                 if (!(e && atoi(e) == 0)) { *kind_out = GK_W8E; return OSP_OK; }
             }
-            if (early < 0) {
-                const char* e = getenv("OSP_GEMM_W8_EARLY"); early = (e && atoi(e) == 0) ? 0 : 1;      // +1..3 % in A/B runs (tools/gemm_quick.py)
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8e_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
-            }
-            osp_note_symbol(early ? "conv_gemm_bf16_glds8e_kernel" : "conv_gemm_bf16_glds8_kernel");
-            if (early) hipLaunchKernelGGL(conv_gemm_bf16_glds8e_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
-            else hipLaunchKernelGGL(conv_gemm_bf16_glds8_kernel, g8, dim3(512), GLDS8_LDS, stream, p);
-            OSP_LAUNCH_CHECK();
-            return OSP_OK;
+            if (early < 0) { const char* e = getenv("OSP_GEMM_W8_EARLY"); early = (e && atoi(e) == 0) ? 0 : 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py)
+            return osp_launch_glds8(p, g8, early != 0, stream);
         }
-        static int big = -1, attr_done = 0;
-        if (big < 0) { const char* e = getenv("OSP_GEMM_BIG"); big = (e && atoi(e) == 1) ? 1 : 0; }
+        static int attr_done = 0;
         if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds256_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + TBN) * TBK * 2);
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + TBN) * TBK * 2);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_LDS);
             attr_done = 1;
         }
-        // 256-row / three-stage variant: opt-in (OSP_GEMM_BIG=1).  Measured on MI355X it does not beat the 128x128
-        // kernel at 2 workgroups / CU (M=13056, N=1024, K=5120: 218 vs 209 us): with one wave per SIMD the barrier per
-        // k-slab and the LDS latency of the first k-step are exposed.  Kept for the next round's 8-wave version.
-        if (kind_out && batch_in == 1 && !big) { *kind_out = GK_GLDS; return OSP_OK; }
-        if (big && cdiv(M, 256) * cdiv(N, TBN) * batch >= 200) {
-            const dim3 g256((unsigned)cdiv(N, TBN), (unsigned)cdiv(M, 256), (unsigned)batch);
-            osp_note_symbol("conv_gemm_bf16_glds256_kernel");
-            hipLaunchKernelGGL(conv_gemm_bf16_glds256_kernel, g256, dim3(256), 3 * (256 + TBN) * TBK * 2, stream, p);
-        } else {
-            osp_note_symbol("conv_gemm_bf16_glds_kernel");
-            hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), 2 * (128 + TBN) * TBK * 2, stream, p);
-        }
+        // (a 256x128 three-stage variant at one wave per SIMD was measured in round 1 and did not beat this kernel at
+        // 2 workgroups / CU -- 218 vs 209 us at M = 13056, N = 1024, K = 5120 -- and was removed in round 3)
+        if (kind_out && batch_in == 1) { *kind_out = GK_GLDS; return OSP_OK; }
+        osp_note_symbol("conv_gemm_bf16_glds_kernel");
+        hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), GLDS_LDS, stream, p);
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
@@ -607,13 +344,6 @@ static int gemm_launch_group(GemmB* ps, int n, hipStream_t stream) {
         const int rc = gemm_launch(ps[i], 1, stream, &kind[i]);
         if (rc != OSP_OK) return rc;
     }
-    static int attr = 0;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_grp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + TBN) * TBK * 2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds_n64_grp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * TBK * 2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8e_grp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
-        attr = 1;
-    }
     for (int k = GK_GLDS; k <= GK_W8E; ++k) {
         GemmGroup g;
         g.n = 0;
@@ -630,16 +360,8 @@ static int gemm_launch_group(GemmB* ps, int n, hipStream_t stream) {
         }
         if (!g.n) continue;
         for (int i = g.n; i < GEMM_GROUP_MAX; ++i) { g.tile_end[i] = tiles; g.nb[i] = g.mb[i] = 1; }
-        if (k == GK_W8E) {
-            osp_note_symbol("conv_gemm_bf16_glds8e_grp_kernel");
-            hipLaunchKernelGGL(conv_gemm_bf16_glds8e_grp_kernel, dim3((unsigned)tiles), dim3(512), GLDS8_LDS, stream, g);
-        } else if (k == GK_N64) {
-            osp_note_symbol("conv_gemm_bf16_glds_n64_grp_kernel");
-            hipLaunchKernelGGL(conv_gemm_bf16_glds_n64_grp_kernel, dim3((unsigned)tiles), dim3(256), 2 * (128 + 64) * TBK * 2, stream, g);
-        } else {
-            osp_note_symbol("conv_gemm_bf16_glds_grp_kernel");
-            hipLaunchKernelGGL(conv_gemm_bf16_glds_grp_kernel, dim3((unsigned)tiles), dim3(256), 2 * (128 + TBN) * TBK * 2, stream, g);
-        }
+        const int rc = k == GK_W8E ? osp_launch_glds8e_grp(g, tiles, stream) : osp_launch_glds_grp(g, tiles, k == GK_N64, stream);
+        if (rc != OSP_OK) return rc;
     }
     OSP_LAUNCH_CHECK();
     return OSP_OK;

@@ -153,7 +153,7 @@ __device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, i
     if constexpr (EPI == BEPI_LRELU) out = v > 0.f ? v : v * pp.slope;
     if constexpr (EPI == BEPI_GELU) {
         if (aux_out) st_aux(aux_out, pp.aux_bf16, crow * pp.ld_aux + n, v);
-        out = gelu_f(v);
+        out = pp.c_bf16 ? gelu_fast_f(v) : gelu_f(v);            // bf16 destination: osp_common.h gelu_fast_parts
     }
     if constexpr (EPI == BEPI_SCALE_RES_MASK) {
         if (aux_out) st_aux(aux_out, pp.aux_bf16, crow * pp.ld_aux + n, v);
@@ -161,7 +161,10 @@ __device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, i
         out = (res[crow * pp.ldr + n] + rs * gam * v) * mk;
     }
     if constexpr (EPI == BEPI_GELU_BWD)
-        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gelu_grad_f(ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n));
+    {
+        const float uu = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n);
+        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * (pp.c_bf16 ? gelu_grad_fast_f(uu) : gelu_grad_f(uu));
+    }
     if constexpr (EPI == BEPI_RELU_BWD) out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? v : 0.f;
     if constexpr (EPI == BEPI_LRELU_BWD) {   // (acc + extra) * lrelu'(y)
         const float e = pp.res_any ? ld_elem(pp.res_any, pp.res_bf16, crow * pp.ldr + n) : 0.f;
@@ -202,6 +205,8 @@ __device__ __forceinline__ bool gemm_bf16_rows_ok(const GemmB& pp) {
                (!pp.res_any || (aligned16(pp.res_any) && (pp.ldr & 7) == 0));
     if constexpr (EPI == BEPI_GELU_BWD || EPI == BEPI_RELU_BWD)
         return pp.aux_in && aligned16(pp.aux_in) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0;
+    if constexpr (EPI == BEPI_GELU)                            // forward GELU that also writes the pre-activation (bf16 or f32 rows)
+        return !pp.aux_out || (aligned16(pp.aux_out) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0);
     return false;
 }
 
@@ -212,6 +217,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
     constexpr int CPR = 4 * TN_, RPI = 64 / CPR;               // 8-channel chunks per row, rows per wave instruction
     __bf16* Cb = reinterpret_cast<__bf16*>(pp.C) + bz * pp.sCb;
     const char* aux_in = reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4);
+    char* aux_out = pp.aux_out ? reinterpret_cast<char*>(pp.aux_out) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
     const int l31 = lane & 31, lh = lane >> 5, cc = lane % CPR, rr = lane / CPR;
     const int Trows = pp.Trows, Wrows = pp.Wrows, Tc = pp.Tc, Wc = pp.Wc, c_step = pp.c_step, c_off = pp.c_off,
               c_step_h = pp.c_step_h, c_off_h = pp.c_off_h, M = pp.M, N = pp.N;
@@ -240,7 +246,24 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                 const float4 v0 = *reinterpret_cast<const float4*>(stage + lrow * SPF + cc * 8);
                 const float4 v1 = *reinterpret_cast<const float4*>(stage + lrow * SPF + cc * 8 + 4);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, y[8], o[8];
-                ld8_f32(aux_in, pp.aux_bf16, crow * pp.ld_aux + n, y);
+                if constexpr (EPI == BEPI_GELU) {
+                    // pre-activation rows (the backward's GELU' operand) as 16-byte chunks: in the MFMA layout they were 2-byte
+                    // stores, 64 per lane and wave tile (+14 us on the 87 us decoder pwconv1 launch)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { y[k] = v[k] + bias[k]; o[k] = gelu_fast_f(y[k]); }
+                    if (aux_out) {
+                        if (pp.aux_bf16)
+                            st_rows(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(aux_out) + crow * pp.ld_aux + n),
+                                    make_uint4(pk2(y[0], y[1]), pk2(y[2], y[3]), pk2(y[4], y[5]), pk2(y[6], y[7])), pp.nt_out);
+                        else {
+                            float* up = reinterpret_cast<float*>(aux_out) + crow * pp.ld_aux + n;
+                            *reinterpret_cast<float4*>(up) = make_float4(y[0], y[1], y[2], y[3]);
+                            *reinterpret_cast<float4*>(up + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                        }
+                    }
+                } else {
+                    ld8_f32(aux_in, pp.aux_bf16, crow * pp.ld_aux + n, y);
+                }
                 if constexpr (EPI == BEPI_LRELU_BWD) {
                     float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     if (pp.res_any) ld8_f32(pp.res_any, pp.res_bf16, crow * pp.ldr + n, e);
@@ -254,7 +277,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                 if constexpr (EPI == BEPI_GELU_BWD) {
                     const float rs = pp.rowscale ? pp.rowscale[bz * M + m] : 1.f;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_f(y[k]);
+                    for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_fast_f(y[k]);   // bf16 destination
                 }
                 st_rows(reinterpret_cast<uint4*>(Cb + crow * pp.ldc + n),
                         make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7])), pp.nt_out);
@@ -289,7 +312,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     constexpr int SP = 32 * TN_ + 8;                                              // staging pitch (elements)
     const bool staged = stage != nullptr && pair_ok && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
     // (callers reserve max(32 * TM_, 64) bf16 rows per wave: one 32-row block of f32)
-    if constexpr (EPI == BEPI_LRELU_BWD || EPI == BEPI_GELU_BWD || EPI == BEPI_RELU_BWD) {
+    if constexpr (EPI == BEPI_LRELU_BWD || EPI == BEPI_GELU_BWD || EPI == BEPI_RELU_BWD || EPI == BEPI_GELU) {
         if (staged && gemm_bf16_rows_ok<EPI>(pp)) {                                   // kernel-uniform
             gemm_bf16_epilogue_rows<EPI, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
             return;

@@ -82,6 +82,22 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// erf-GELU for epilogues whose RESULT IS ROUNDED TO bf16 (the performance mode's I-wide intermediates): Abramowitz-Stegun 7.1.26,
+// |erf error| <= 1.5e-7 -- four orders below the bf16 unit round-off -- on one v_rcp_f32 and one v_exp_f32 plus 8 FMAs instead of the
+// ~50-instruction branchy library erff.  At the decoder shape (26 M GELUs per block and direction) the library call alone
+// was 37 of the 87 us of the pwconv1 launch (tools/convnext_pw_probe.py).  Phi(x) is formed without cancellation on the
+// negative side (Phi(x) = q / 2, x < 0; 1 - q / 2 otherwise; q = poly(t) exp(-x^2 / 2)); exp(-x^2 / 2) is shared with the pdf.
+__device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& e) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    e = __expf(-ax * ax);
+    const float hq = 0.5f * poly * e;
+    cdf = x < 0.f ? hq : 1.0f - hq;
+}
+__device__ __forceinline__ float gelu_fast_f(float x) { float c, e; gelu_fast_parts(x, c, e); return x * c; }
+__device__ __forceinline__ float gelu_grad_fast_f(float x) { float c, e; gelu_fast_parts(x, c, e); return fmaf(x * 0.39894228040143267794f, e, c); }
+
 // ---------------------------------------------------------------- counter-based RNG (dropout / drop-path)
 // Philox-4x32-10: (seed, stream) key, 64-bit counter -> 4 uniform u32.  Stateless, so a backward pass
 // regenerates the forward mask from (seed, stream, element index) instead of storing it.
