@@ -207,6 +207,11 @@ __device__ __forceinline__ bool gemm_bf16_rows_ok(const GemmB& pp) {
         return pp.aux_in && aligned16(pp.aux_in) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0;
     if constexpr (EPI == BEPI_GELU)                            // forward GELU that also writes the pre-activation (bf16 or f32 rows)
         return !pp.aux_out || (aligned16(pp.aux_out) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0);
+    // kinds that read nothing of the output's shape: the row domain still wins on instruction count -- one ds_write_b32 per
+    // accumulator, then 8 channels per lane (bias add, activation, pack, ONE 16-byte store, row geometry once per 8 values)
+    // against ~12 VALU + a DPP swap + a 4-byte LDS store per value in the MFMA layout.  The 256x256 tile's epilogue was ~10 of
+    // the 21.7 us a one-slab launch takes (tools/epi_probe.py).
+    if constexpr (EPI == BEPI_NONE || EPI == BEPI_RELU || EPI == BEPI_LRELU || EPI == BEPI_MASK) return true;
     return false;
 }
 
@@ -261,6 +266,16 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                             *reinterpret_cast<float4*>(up + 4) = make_float4(y[4], y[5], y[6], y[7]);
                         }
                     }
+                } else if constexpr (EPI == BEPI_NONE || EPI == BEPI_RELU || EPI == BEPI_LRELU || EPI == BEPI_MASK) {
+                    const float mk = (EPI == BEPI_MASK && pp.rowmask) ? pp.rowmask[bz * M + m] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float sv = v[k] + bias[k];
+                        if constexpr (EPI == BEPI_NONE) o[k] = sv;
+                        if constexpr (EPI == BEPI_RELU) o[k] = fmaxf(sv, 0.f);
+                        if constexpr (EPI == BEPI_LRELU) o[k] = sv > 0.f ? sv : sv * slope;
+                        if constexpr (EPI == BEPI_MASK) o[k] = sv * mk;
+                    }
                 } else {
                     ld8_f32(aux_in, pp.aux_bf16, crow * pp.ld_aux + n, y);
                 }
@@ -312,7 +327,7 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     constexpr int SP = 32 * TN_ + 8;                                              // staging pitch (elements)
     const bool staged = stage != nullptr && pair_ok && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
     // (callers reserve max(32 * TM_, 64) bf16 rows per wave: one 32-row block of f32)
-    if constexpr (EPI == BEPI_LRELU_BWD || EPI == BEPI_GELU_BWD || EPI == BEPI_RELU_BWD || EPI == BEPI_GELU) {
+    if constexpr (EPI != BEPI_SCALE_RES_MASK && EPI != BEPI_AXMY) {
         if (staged && gemm_bf16_rows_ok<EPI>(pp)) {                                   // kernel-uniform
             gemm_bf16_epilogue_rows<EPI, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
             return;

@@ -37,10 +37,22 @@ void osp_note_bytes(double bytes);
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- wave / block reductions
+// Round 3: DPP row operations + one v_readlane instead of six ds_bpermute_b32 round trips (what __shfl_xor compiles to: ~100
+// cycles of LDS-pipe latency each, 1 296 of them in convnext.hip alone; a LayerNorm row = two DEPENDENT reductions).  The tree
+// is the xor butterfly's -- quads, 8s (row_half_mirror), 16s (row_mirror), then the rows through row_bcast:15 / row_bcast:31 --
+// so the sums are bit-identical to the round-2 ones.  The total lands in lane 63 and comes back wave-uniform (SGPR).
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float dpp_get(float oldv, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_get<0xB1>(0.f, v);            // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(0.f, v);            // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(0.f, v);           // row_half_mirror
+    v += dpp_get<0x140>(0.f, v);           // row_mirror: every lane of a 16-lane row holds the row's sum
+    v += dpp_get<0x142, 0xA>(0.f, v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_get<0x143, 0xC>(0.f, v);      // row_bcast:31 into rows 2 and 3: lane 63 = total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -48,9 +60,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_get<0xB1>(v, v));
+    v = fmaxf(v, dpp_get<0x4E>(v, v));
+    v = fmaxf(v, dpp_get<0x141>(v, v));
+    v = fmaxf(v, dpp_get<0x140>(v, v));
+    v = fmaxf(v, dpp_get<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_get<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // block reduction through LDS scratch (>= 16 floats); result valid in all threads
 __device__ __forceinline__ float block_sum(float v, float* scratch) {

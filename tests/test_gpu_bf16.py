@@ -299,11 +299,15 @@ def test_gan_components_bf16_vs_f32_grads(golden, comp):
     finally:
         precision.set_precision("f32")
     assert abs(la - lb) <= 5e-3 * abs(la), (la, lb)
+    nmax = max(v.norm().item() for v in a.values())
     for k in a:
         na, nb = a[k].norm().item(), b[k].norm().item()
         if na < 1e-7:
             continue
-        assert abs(na - nb) <= 6e-2 * na, (k, na, nb)
+        # 6 % of the tensor's own norm, plus an absolute floor of 1e-3 of the LARGEST vocoder gradient: the LayerNorm affine
+        # gradients of the last blocks are sums of almost cancelling terms (norm 3e-3 here), their bf16 noise does not shrink
+        # with them (6.4 % seen once on convnext.3.norm.weight after the epilogue's GELU changed its last-bit rounding)
+        assert abs(na - nb) <= 6e-2 * na + 1e-3 * nmax, (k, na, nb, nmax)
         cos = torch.nn.functional.cosine_similarity(a[k].flatten(), b[k].flatten(), dim=0).item()
         assert cos > 0.98, (k, cos)
 
