@@ -153,7 +153,8 @@ __device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, i
     if constexpr (EPI == BEPI_LRELU) out = v > 0.f ? v : v * pp.slope;
     if constexpr (EPI == BEPI_GELU) {
         if (aux_out) st_aux(aux_out, pp.aux_bf16, crow * pp.ld_aux + n, v);
-        out = pp.c_bf16 ? gelu_fast_f(v) : gelu_f(v);            // bf16 destination: osp_common.h gelu_fast_parts
+        if (pp.c_bf16) out = gelu_fast_f(v);                    // bf16 destination: osp_common.h gelu_fast_parts
+        else out = gelu_f(v);
     }
     if constexpr (EPI == BEPI_SCALE_RES_MASK) {
         if (aux_out) st_aux(aux_out, pp.aux_bf16, crow * pp.ld_aux + n, v);
@@ -163,7 +164,10 @@ __device__ __forceinline__ float gemm_bf16_epi_value(const GemmB& pp, float v, i
     if constexpr (EPI == BEPI_GELU_BWD)
     {
         const float uu = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n);
-        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * (pp.c_bf16 ? gelu_grad_fast_f(uu) : gelu_grad_f(uu));
+        float gp;
+        if (pp.c_bf16) gp = gelu_grad_fast_f(uu);
+        else gp = gelu_grad_f(uu);
+        out = (pp.rowscale ? pp.rowscale[mr] : 1.f) * v * gp;
     }
     if constexpr (EPI == BEPI_RELU_BWD) out = ld_elem(aux_in, pp.aux_bf16, crow * pp.ld_aux + n) > 0.f ? v : 0.f;
     if constexpr (EPI == BEPI_LRELU_BWD) {   // (acc + extra) * lrelu'(y)
@@ -212,6 +216,11 @@ __device__ __forceinline__ bool gemm_bf16_rows_ok(const GemmB& pp) {
     // against ~12 VALU + a DPP swap + a 4-byte LDS store per value in the MFMA layout.  The 256x256 tile's epilogue was ~10 of
     // the 21.7 us a one-slab launch takes (tools/epi_probe.py).
     if constexpr (EPI == BEPI_NONE || EPI == BEPI_RELU || EPI == BEPI_LRELU || EPI == BEPI_MASK) return true;
+    if constexpr (EPI == BEPI_SCALE_RES_MASK)                  // ConvNeXt pwconv2: f32 residual rows in, optional z rows out
+        return pp.res && aligned16(pp.res) && (pp.ldr & 7) == 0 && ((pp.sXb * 4) & 15) == 0 &&
+               (!pp.aux_out || (aligned16(pp.aux_out) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0));
+    if constexpr (EPI == BEPI_AXMY)
+        return pp.aux_in && aligned16(pp.aux_in) && (pp.ld_aux & 7) == 0 && ((pp.sXb * (pp.aux_bf16 ? 2 : 4)) & 15) == 0;
     return false;
 }
 
@@ -220,18 +229,23 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                                                         int lane, int64_t bz, float* stage) {
     constexpr int SPF = 32 * TN_ + 8;                          // f32 staging pitch: 4 rows apart = 32 banks apart
     constexpr int CPR = 4 * TN_, RPI = 64 / CPR;               // 8-channel chunks per row, rows per wave instruction
-    __bf16* Cb = reinterpret_cast<__bf16*>(pp.C) + bz * pp.sCb;
+    const bool c_bf16 = pp.c_bf16 != 0;
+    char* Cb = reinterpret_cast<char*>(pp.C) + bz * pp.sCb * (c_bf16 ? 2 : 4);
     const char* aux_in = reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4);
     char* aux_out = pp.aux_out ? reinterpret_cast<char*>(pp.aux_out) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
+    const float* res = pp.res ? pp.res + bz * pp.sXb : nullptr;
     const int l31 = lane & 31, lh = lane >> 5, cc = lane % CPR, rr = lane / CPR;
     const int Trows = pp.Trows, Wrows = pp.Wrows, Tc = pp.Tc, Wc = pp.Wc, c_step = pp.c_step, c_off = pp.c_off,
               c_step_h = pp.c_step_h, c_off_h = pp.c_off_h, M = pp.M, N = pp.N;
     const FastDiv fd_trows = pp.fd_trows, fd_wrows = pp.fd_wrows;
     const int n = n0 + wn0 + cc * 8;
     const bool n_ok = n < N;                                   // N % 8 == 0: a chunk is inside or outside as a whole
-    float bias[8];
+    float bias[8], gam[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias[k] = (pp.bias && n_ok) ? pp.bias[n + k] : 0.f;
+    for (int k = 0; k < 8; ++k) {
+        bias[k] = (pp.bias && n_ok) ? pp.bias[n + k] : 0.f;
+        gam[k] = (EPI == BEPI_SCALE_RES_MASK && pp.gamma && n_ok) ? pp.gamma[n + k] : 1.f;
+    }
     const float slope = pp.slope;
 #pragma unroll
     for (int i = 0; i < TM_; ++i) {
@@ -255,7 +269,15 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                     // pre-activation rows (the backward's GELU' operand) as 16-byte chunks: in the MFMA layout they were 2-byte
                     // stores, 64 per lane and wave tile (+14 us on the 87 us decoder pwconv1 launch)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { y[k] = v[k] + bias[k]; o[k] = gelu_fast_f(y[k]); }
+                    for (int k = 0; k < 8; ++k) y[k] = v[k] + bias[k];
+                    // two loops under a wave-uniform branch: as a per-element select the compiler evaluated BOTH (55.8 -> 69 us)
+                    if (c_bf16) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = gelu_fast_f(y[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = gelu_f(y[k]);
+                    }
                     if (aux_out) {
                         if (pp.aux_bf16)
                             st_rows(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(aux_out) + crow * pp.ld_aux + n),
@@ -264,6 +286,22 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                             float* up = reinterpret_cast<float*>(aux_out) + crow * pp.ld_aux + n;
                             *reinterpret_cast<float4*>(up) = make_float4(y[0], y[1], y[2], y[3]);
                             *reinterpret_cast<float4*>(up + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                        }
+                    }
+                } else if constexpr (EPI == BEPI_SCALE_RES_MASK) {
+                    const int64_t mr = bz * M + m;
+                    const float rs = pp.rowscale ? pp.rowscale[mr] : 1.f, mk = pp.rowmask ? pp.rowmask[mr] : 1.f;
+                    ld8_f32(res, 0, crow * pp.ldr + n, y);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float sv = v[k] + bias[k]; v[k] = sv; o[k] = (y[k] + rs * gam[k] * sv) * mk; }
+                    if (aux_out) {                              // z = W2 g + b2: the operand of the layer-scale gradient
+                        if (pp.aux_bf16)
+                            st_rows(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(aux_out) + crow * pp.ld_aux + n),
+                                    make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])), pp.nt_out);
+                        else {
+                            float* up = reinterpret_cast<float*>(aux_out) + crow * pp.ld_aux + n;
+                            *reinterpret_cast<float4*>(up) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(up + 4) = make_float4(v[4], v[5], v[6], v[7]);
                         }
                     }
                 } else if constexpr (EPI == BEPI_NONE || EPI == BEPI_RELU || EPI == BEPI_LRELU || EPI == BEPI_MASK) {
@@ -292,10 +330,31 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                 if constexpr (EPI == BEPI_GELU_BWD) {
                     const float rs = pp.rowscale ? pp.rowscale[bz * M + m] : 1.f;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_fast_f(y[k]);   // bf16 destination
+                    if (c_bf16) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_fast_f(y[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_f(y[k]);
+                    }
                 }
-                st_rows(reinterpret_cast<uint4*>(Cb + crow * pp.ldc + n),
-                        make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7])), pp.nt_out);
+                if constexpr (EPI == BEPI_AXMY) {
+                    const float rs = pp.rowscale ? pp.rowscale[bz * M + m] : 1.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = rs * y[k] - (v[k] + bias[k]);
+                }
+                if (c_bf16) {
+                    st_rows(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(Cb) + crow * pp.ldc + n),
+                            make_uint4(pk2(o[0], o[1]), pk2(o[2], o[3]), pk2(o[4], o[5]), pk2(o[6], o[7])), pp.nt_out);
+                } else {                                        // f32 rows: two 16-byte stores per lane (32 B x 8 lanes = a 256-byte run)
+                    float* cp = reinterpret_cast<float*>(Cb) + crow * pp.ldc + n;
+                    if (pp.accumulate) {
+                        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+                        o[0] += c0.x; o[1] += c0.y; o[2] += c0.z; o[3] += c0.w; o[4] += c1.x; o[5] += c1.y; o[6] += c1.z; o[7] += c1.w;
+                    }
+                    *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(cp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -327,8 +386,11 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     constexpr int SP = 32 * TN_ + 8;                                              // staging pitch (elements)
     const bool staged = stage != nullptr && pair_ok && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
     // (callers reserve max(32 * TM_, 64) bf16 rows per wave: one 32-row block of f32)
-    if constexpr (EPI != BEPI_SCALE_RES_MASK && EPI != BEPI_AXMY) {
-        if (staged && gemm_bf16_rows_ok<EPI>(pp)) {                                   // kernel-uniform
+    // row-domain path: bf16 rows as before; f32 rows (pwconv2 / dh of the ConvNeXt block, the accumulate form) when 8-channel chunks
+    // are 16-byte addressable
+    const bool rows_f32 = stage != nullptr && !c_bf16 && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
+    {
+        if ((staged || rows_f32) && gemm_bf16_rows_ok<EPI>(pp)) {                                   // kernel-uniform
             gemm_bf16_epilogue_rows<EPI, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
             return;
         }
