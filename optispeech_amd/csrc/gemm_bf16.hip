@@ -152,6 +152,58 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
                          (pp.ldc & 7) == 0 && (pp.ld_aux & 7) == 0 && (pp.ldr & 7) == 0 &&
                          ((reinterpret_cast<uintptr_t>(pp.C) | reinterpret_cast<uintptr_t>(pp.aux_in) |
                            reinterpret_cast<uintptr_t>(pp.res_any)) & 15) == 0;
+    if (vec_epi && pp.taps <= 3) {
+        // the conv_post dgrad (Cin = 1, 3 taps, LeakyReLU' on bf16 rows): 4 rows per trip with every load -- the taps' dy scalars,
+        // the y and extra rows -- requested before the first use (round 2 walked one row at a time: a full memory latency per row
+        // and 32 bytes in flight per thread, 61 us for the 1024-channel layer = 1.3 TB/s), multiply-high dividers for the row maps
+        constexpr int UN = 4;
+        const int64_t rstride = (int64_t)gridDim.x * rpb;
+        for (int64_t m0 = (int64_t)blockIdx.x * rpb + rgrp; m0 < pp.M; m0 += rstride * UN) {
+            float as[UN][3];
+            uint4 yv[UN], ev[UN];
+            int64_t crow[UN];
+            bool live[UN];
+#pragma unroll
+            for (int i = 0; i < UN; ++i) {
+                const int64_t mm = m0 + i * rstride;
+                live[i] = mm < pp.M;
+                const int m = live[i] ? (int)mm : (int)m0;
+                const int u = fd_div(m, pp.fd_trows), t = m - u * pp.Trows, th = fd_div(t, pp.fd_wrows), tw = t - th * pp.Wrows;
+                const int at = tw * pp.a_step + pp.a_off, ah = th * pp.a_step_h + pp.a_off_h;
+                const int64_t base = (int64_t)u * pp.Hin * pp.Tin;
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const int tp = tap < pp.taps ? tap : 0, kh = tp / pp.KW, kw = tp - kh * pp.KW;
+                    const int hh = ah + kh * pp.a_tapstep_h, tt = at + kw * pp.a_tapstep;
+                    const bool ok = tap < pp.taps && (unsigned)hh < (unsigned)pp.Hin && (unsigned)tt < (unsigned)pp.Tin;
+                    const int64_t row = ok ? base + (int64_t)hh * pp.Tin + tt : 0;
+                    const float a = ld_elem(pp.A, pp.a_bf16, row * pp.lda);
+                    as[i][tap] = ok ? a : 0.f;
+                }
+                crow[i] = (int64_t)u * pp.Tc + (int64_t)(th * pp.c_step_h + pp.c_off_h) * pp.Wc + (int64_t)tw * pp.c_step + pp.c_off;
+                yv[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(pp.aux_in) + crow[i] * pp.ld_aux + n);
+                ev[i] = make_uint4(0, 0, 0, 0);
+                if (pp.res_any) ev[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(pp.res_any) + crow[i] * pp.ldr + n);
+            }
+#pragma unroll
+            for (int i = 0; i < UN; ++i) {
+                if (!live[i]) continue;
+                const unsigned yy[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w}, ee[4] = {ev[i].x, ev[i].y, ev[i].z, ev[i].w};
+                unsigned oo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a0 = bias[2 * q], a1 = bias[2 * q + 1];
+#pragma unroll
+                    for (int tap = 0; tap < 3; ++tap) { a0 = fmaf(as[i][tap], w[tap][2 * q], a0); a1 = fmaf(as[i][tap], w[tap][2 * q + 1], a1); }
+                    const float y0 = __uint_as_float(yy[q] << 16), y1 = __uint_as_float(yy[q] & 0xffff0000u);
+                    const float v0 = a0 + __uint_as_float(ee[q] << 16), v1 = a1 + __uint_as_float(ee[q] & 0xffff0000u);
+                    oo[q] = pk2(y0 > 0.f ? v0 : v0 * pp.slope, y1 > 0.f ? v1 : v1 * pp.slope);
+                }
+                st_rows(reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(pp.C) + crow[i] * pp.ldc + n), make_uint4(oo[0], oo[1], oo[2], oo[3]), pp.nt_out);
+            }
+        }
+        return;
+    }
     for (int m = blockIdx.x * rpb + rgrp; m < pp.M; m += gridDim.x * rpb) {
         const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
         const int at = tw * pp.a_step + pp.a_off, ah = th * pp.a_step_h + pp.a_off_h;

@@ -224,7 +224,9 @@ __device__ __forceinline__ bool gemm_bf16_rows_ok(const GemmB& pp) {
     return false;
 }
 
-template <int EPI, int TM_, int TN_>
+// FASTG (GELU kinds only): the Abramowitz-Stegun GELU for bf16 destinations, the library erff otherwise -- a template parameter,
+// not a run-time select: under `c_bf16 ? fast : exact` (and even under an if / else around two loops) the compiler evaluated both.
+template <int EPI, int TM_, int TN_, bool FASTG = true>
 __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 (&acc)[TM_][TN_], int m0, int n0, int wm0, int wn0,
                                                         int lane, int64_t bz, float* stage) {
     constexpr int SPF = 32 * TN_ + 8;                          // f32 staging pitch: 4 rows apart = 32 banks apart
@@ -270,14 +272,8 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                     // stores, 64 per lane and wave tile (+14 us on the 87 us decoder pwconv1 launch)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) y[k] = v[k] + bias[k];
-                    // two loops under a wave-uniform branch: as a per-element select the compiler evaluated BOTH (55.8 -> 69 us)
-                    if (c_bf16) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = gelu_fast_f(y[k]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = gelu_f(y[k]);
-                    }
+                    for (int k = 0; k < 8; ++k) { if constexpr (FASTG) o[k] = gelu_fast_f(y[k]); else o[k] = gelu_f(y[k]); }
                     if (aux_out) {
                         if (pp.aux_bf16)
                             st_rows(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(aux_out) + crow * pp.ld_aux + n),
@@ -330,12 +326,9 @@ __device__ __forceinline__ void gemm_bf16_epilogue_rows(const GemmB& pp, f32x16 
                 if constexpr (EPI == BEPI_GELU_BWD) {
                     const float rs = pp.rowscale ? pp.rowscale[bz * M + m] : 1.f;
 #pragma unroll
-                    if (c_bf16) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_fast_f(y[k]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) o[k] = rs * (v[k] + bias[k]) * gelu_grad_f(y[k]);
+                    for (int k = 0; k < 8; ++k) {
+                        if constexpr (FASTG) o[k] = rs * (v[k] + bias[k]) * gelu_grad_fast_f(y[k]);
+                        else o[k] = rs * (v[k] + bias[k]) * gelu_grad_f(y[k]);
                     }
                 }
                 if constexpr (EPI == BEPI_AXMY) {
@@ -391,7 +384,12 @@ __device__ __forceinline__ void gemm_bf16_epilogue_t(const GemmB& pp, f32x16 (&a
     const bool rows_f32 = stage != nullptr && !c_bf16 && (ldc & 7) == 0 && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0) && (N & 7) == 0;
     {
         if ((staged || rows_f32) && gemm_bf16_rows_ok<EPI>(pp)) {                                   // kernel-uniform
-            gemm_bf16_epilogue_rows<EPI, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
+            if constexpr (EPI == BEPI_GELU || EPI == BEPI_GELU_BWD) {
+                if (c_bf16) gemm_bf16_epilogue_rows<EPI, TM_, TN_, true>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
+                else gemm_bf16_epilogue_rows<EPI, TM_, TN_, false>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
+            } else {
+                gemm_bf16_epilogue_rows<EPI, TM_, TN_>(pp, acc, m0, n0, wm0, wn0, lane, bz, reinterpret_cast<float*>(stage));
+            }
             return;
         }
     }

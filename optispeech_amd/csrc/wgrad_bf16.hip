@@ -596,6 +596,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
     }
 }
 
+int osp_launch_wgrad_n1(const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin,
+                        int64_t Tin, int64_t Cin, int64_t taps, int64_t KW, int64_t pad, int64_t pad_h, int64_t x_step, int64_t x_step_h,
+                        const float* arow, const float* oscale, float* dW, float* db, hipStream_t stream);      // wgrad_n1.hip
+
 static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
                                    int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
                                    int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
@@ -614,6 +618,13 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);          // measurement aid (api.cpp)
     osp_note_bytes((double)batch * ((double)M * N * (y_bf16 ? 2.0 : 4.0) + (double)(M / Trows) * d2[1] * Tin * Cin * (x_bf16 ? 2.0 : 4.0) +
                                     (double)N * taps * Cin * 4.0));
+    // one output channel (the discriminators' conv_post): a dY-weighted column sum, not a GEMM (wgrad_n1.hip)
+    static int use_n1 = -1;
+    if (use_n1 < 0) { const char* e = getenv("OSP_WGRAD_N1"); use_n1 = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_n1 && N == 1 && y_bf16 && x_bf16 && batch == 1 && Cin % 64 == 0 && taps <= 9 && ldx % 8 == 0 &&
+        (reinterpret_cast<uintptr_t>(X) & 15) == 0)
+        return osp_launch_wgrad_n1(dY, ldy, X, ldx, M, Trows, d2[0], d2[1], Tin, Cin, taps, d2[2], pad, d2[4], x_step, d2[3], arow, oscale,
+                                   dW, db, stream);
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
