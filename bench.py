@@ -297,6 +297,27 @@ def hbm_kernel_rooflines(model, dev, reps=50):
         # p, g, m, v read; p, m, v written: 28 bytes per parameter
         "adamw_clip": (n_adam * 28, lambda: call("osp_adamw_clip", p, gr, m1, m2, n_adam, ss, None, None, 2e-4, 0.8, 0.99, 1e-8, 0.01, 7, 10.0, 1.0)),
     }
+    # the pointwise half of the same ConvNeXt block (A1b / A1c and their input gradients) at the decoder shape: K = 256 or an output
+    # 256 wide -- 13 GFLOP over 80-130 MB, i.e. HBM-bound on the matrix-core kernels (their epilogues decide the time)
+    I = 1024
+    bf = lambda t: t.to(torch.bfloat16)                                                         # noqa: E731
+    hb, W1, W2 = bf(rn(M, C)), bf(rn(I, C) * 0.05), bf(rn(C, I) * 0.05)
+    W2t, W1t = W2.t().contiguous(), W1.t().contiguous()
+    b1, b2, gam = torch.zeros(I, device=dev), torch.zeros(C, device=dev), torch.full((C,), 0.25, device=dev)
+    ub, gb_ = torch.empty(M, I, device=dev, dtype=torch.bfloat16), torch.empty(M, I, device=dev, dtype=torch.bfloat16)
+    zf, yf, dhf = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev), torch.empty(M, C, device=dev)
+    dys, dub = bf(rn(M, C)), torch.empty(M, I, device=dev, dtype=torch.bfloat16)
+    x2 = x.view(M, C)
+    cases.update({
+        # h (bf16), W1 read; g = gelu(u) and u written (bf16): pwconv1 + GELU
+        "pwconv1_gelu": (M * C * 2 + I * C * 2 + 2 * M * I * 2, lambda: K.conv_gemm_bf16(hb, W1, I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU, bias=b1, aux_out=ub, out=gb_, out_bf16=True)),
+        # g (bf16), W2, x (f32 residual) read; y and z written (f32): pwconv2 + layer scale + residual + mask
+        "pwconv2_scale_res": (M * I * 2 + I * C * 2 + 3 * M * C * 4, lambda: K.conv_gemm_bf16(gb_, W2, C, M=M, Trows=M, Tin=M, cin=I, epi=K.EPI_SCALE_RES_MASK, bias=b2, gamma=gam, res=x2, rowmask=rm, rowscale=rm, aux_out=zf, out=yf)),
+        # dy (bf16), W2^T, u read; du written (bf16): input gradient of pwconv2 through GELU'
+        "pw_du_gelu_bwd": (M * C * 2 + I * C * 2 + 2 * M * I * 2, lambda: K.conv_gemm_bf16(dys, W2t, I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU_BWD, aux_in=ub, out=dub, out_bf16=True)),
+        # du (bf16), W1^T read; dh written (f32): input gradient of pwconv1
+        "pw_dh": (M * I * 2 + I * C * 2 + M * C * 4, lambda: K.conv_gemm_bf16(dub, W1t, C, M=M, Trows=M, Tin=M, cin=I, out=dhf)),
+    })
     out = {}
     for key, (nbytes, fn) in cases.items():
         for _ in range(5):
@@ -312,7 +333,8 @@ def hbm_kernel_rooflines(model, dev, reps=50):
         gbs = nbytes / (us * 1e-6) / 1e9
         out[key] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": us, "launches_timed": reps,
-                    "shape": f"{Bn} x {T} x {C}" if key != "adamw_clip" else f"{n_adam} parameters (generator arena)"}
+                    "shape": (f"{n_adam} parameters (generator arena)" if key == "adamw_clip" else
+                              f"{Bn} x {T} frames, {C} <-> {I} channels" if key.startswith("pw") else f"{Bn} x {T} x {C}")}
     out["how"] = f"{reps} back-to-back launches of each kernel between two HIP events on the launch stream, after the timed region"
     return out
 

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
     }
 }
 
-int osp_launch_wgrad_n1(const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin,
+int osp_launch_wgrad_n1(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t ldx, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin,
                         int64_t Tin, int64_t Cin, int64_t taps, int64_t KW, int64_t pad, int64_t pad_h, int64_t x_step, int64_t x_step_h,
                         const float* arow, const float* oscale, float* dW, float* db, hipStream_t stream);      // wgrad_n1.hip
 
@@ -621,9 +621,9 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     // one output channel (the discriminators' conv_post): a dY-weighted column sum, not a GEMM (wgrad_n1.hip)
     static int use_n1 = -1;
     if (use_n1 < 0) { const char* e = getenv("OSP_WGRAD_N1"); use_n1 = (e && atoi(e) == 0) ? 0 : 1; }
-    if (use_n1 && N == 1 && y_bf16 && x_bf16 && batch == 1 && Cin % 64 == 0 && taps <= 9 && ldx % 8 == 0 &&
+    if (use_n1 && N == 1 && x_bf16 && batch == 1 && Cin % 64 == 0 && taps <= 9 && ldx % 8 == 0 &&
         (reinterpret_cast<uintptr_t>(X) & 15) == 0)
-        return osp_launch_wgrad_n1(dY, ldy, X, ldx, M, Trows, d2[0], d2[1], Tin, Cin, taps, d2[2], pad, d2[4], x_step, d2[3], arow, oscale,
+        return osp_launch_wgrad_n1(dY, y_bf16, ldy, X, ldx, M, Trows, d2[0], d2[1], Tin, Cin, taps, d2[2], pad, d2[4], x_step, d2[3], arow, oscale,
                                    dW, db, stream);
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);

@@ -12,7 +12,7 @@
 
 #define WN1_MAXT 9
 struct WgradN1 {
-    const unsigned short* dY; int64_t ldy; const unsigned short* X; int64_t ldx;
+    const void* dY; int y_bf16; int64_t ldy; const unsigned short* X; int64_t ldx;
     int M, Trows, Wrows, Hin, Tin, Cin, taps, KW, pad, pad_h, x_step, x_step_h;
     const float* arow; const float* oscale; float* dW; float* db; int nslices, rows_per_split;
 };
@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_n1_kernel(const WgradN1 p) {
             const bool live = m < mend;
             const int ms = live ? m : mbeg;
             const int u = ms / p.Trows, t = ms - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
-            float d = __uint_as_float(((unsigned)p.dY[(int64_t)ms * p.ldy]) << 16);
+            float d = p.y_bf16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(p.dY)[(int64_t)ms * p.ldy]) << 16)
+                               : reinterpret_cast<const float*>(p.dY)[(int64_t)ms * p.ldy];
             if (p.arow) d *= p.arow[ms];
             dy[i] = live ? d : 0.f;
             const int64_t base = (int64_t)u * p.Hin * p.Tin;
@@ -94,12 +95,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_n1_kernel(const WgradN1 p) {
     }
 }
 
-// Called by the weight-gradient dispatcher (wgrad_bf16.hip) for N == 1, bf16 operands, Cin % 64 == 0, taps <= 9, one problem.
-int osp_launch_wgrad_n1(const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin,
+// Called by the weight-gradient dispatcher (wgrad_bf16.hip) for N == 1, bf16 X (dY bf16 or f32: the score gradient), Cin % 64 == 0, taps <= 9, one problem.
+int osp_launch_wgrad_n1(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t ldx, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin,
                         int64_t Tin, int64_t Cin, int64_t taps, int64_t KW, int64_t pad, int64_t pad_h, int64_t x_step, int64_t x_step_h,
                         const float* arow, const float* oscale, float* dW, float* db, hipStream_t stream) {
     WgradN1 p;
-    p.dY = reinterpret_cast<const unsigned short*>(dY); p.ldy = ldy; p.X = reinterpret_cast<const unsigned short*>(X); p.ldx = ldx;
+    p.dY = dY; p.y_bf16 = (int)y_bf16; p.ldy = ldy; p.X = reinterpret_cast<const unsigned short*>(X); p.ldx = ldx;
     p.M = (int)M; p.Trows = (int)Trows; p.Wrows = (int)Wrows; p.Hin = (int)Hin; p.Tin = (int)Tin; p.Cin = (int)Cin; p.taps = (int)taps;
     p.KW = (int)KW; p.pad = (int)pad; p.pad_h = (int)pad_h; p.x_step = (int)x_step; p.x_step_h = (int)x_step_h;
     p.arow = arow; p.oscale = oscale; p.dW = dW; p.db = db;
