@@ -49,6 +49,33 @@ __device__ __forceinline__ void stage_rows(unsigned short* dst, const float* __r
     }
 }
 
+// The same in two halves for software pipelining: the NEXT tile's rows are requested into registers before the current tile is
+// computed (a tile's global loads then fly under ~1 000 cycles of MFMA work instead of stalling the whole workgroup at the
+// staging barrier), converted and written to LDS at the top of the next iteration.
+template <int DK, int NT>
+__device__ __forceinline__ void load_rows_regs(float4 (&r)[32 * (DK / 4) / NT], const float* __restrict__ src, int64_t base, int C, int row0, int nvalid, int tid) {
+#pragma unroll
+    for (int it = 0; it < 32 * (DK / 4) / NT; ++it) {
+        const int i = tid + it * NT;
+        const int rw = i / (DK / 4), c4 = i - rw * (DK / 4);
+        const int rr = row0 + rw;
+        r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < nvalid) r[it] = *reinterpret_cast<const float4*>(src + base + (int64_t)rr * C + 4 * c4);
+    }
+}
+template <int DK, int NT>
+__device__ __forceinline__ void store_rows_lds(unsigned short* dst, const float4 (&r)[32 * (DK / 4) / NT], int tid) {
+    constexpr int LD = DK + 8;
+#pragma unroll
+    for (int it = 0; it < 32 * (DK / 4) / NT; ++it) {
+        const int i = tid + it * NT;
+        const int rw = i / (DK / 4), c4 = i - rw * (DK / 4);
+        bf16x2_t a, b;
+        a[0] = (__bf16)r[it].x; a[1] = (__bf16)r[it].y; b[0] = (__bf16)r[it].z; b[1] = (__bf16)r[it].w;
+        *reinterpret_cast<uint2*>(dst + rw * LD + 4 * c4) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    }
+}
+
 // register fragments (B operand of a score-type product) of row `row` (clamped by the caller): d = 16 s + 8 half .. + 7
 template <int DK>
 __device__ __forceinline__ void load_frags(bf16x8_t (&f)[DK / 16], const float* __restrict__ p, int half) {
@@ -114,6 +141,34 @@ __device__ __forceinline__ void dropout4(float (&f)[4], uint64_t seed, uint32_t 
     }
 }
 
+// Column-entity variant (dK / dV kernel: a lane owns one KEY and 16 query rows): the 4 elements of a lane's row group are 4
+// different rows, i.e. 4 different Philox blocks -- but the 4 lanes of a quad own the 4 keys of ONE block.  Each lane of the
+// quad draws the block of ONE of the 4 rows; the words are then transposed inside the quad (DPP quad broadcasts), so a lane
+// computes one Philox block per 4 elements instead of four (16 -> 4 per tile: the generator was ~2/3 of the kernel's instructions).
+// Needs T % 4 == 0 (row starts on a block boundary) and key0 % 4 == 0; the caller falls back to dropout_factor otherwise.
+template <int E>
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, E * 0x55, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void dropout_rows4_quad(float (&f)[4], uint64_t seed, uint32_t stream, uint64_t zT, int q_first, int T, int key, int lane, float p) {
+    const int c = lane & 3;
+    const uint64_t idx = (zT + (uint64_t)(q_first + c)) * (uint64_t)T + (uint64_t)(key & ~3);      // block of row q_first + c
+    const uint4 r = philox4(seed, idx >> 2, stream);
+    const float ks = 1.0f / (1.0f - p);
+    // all 16 broadcasts are executed by every lane BEFORE any select (a DPP read from a lane that sits out a branch returns 0)
+    const unsigned x0 = quad_bcast<0>(r.x), y0 = quad_bcast<0>(r.y), z0 = quad_bcast<0>(r.z), w0 = quad_bcast<0>(r.w);
+    const unsigned x1 = quad_bcast<1>(r.x), y1 = quad_bcast<1>(r.y), z1 = quad_bcast<1>(r.z), w1 = quad_bcast<1>(r.w);
+    const unsigned x2 = quad_bcast<2>(r.x), y2 = quad_bcast<2>(r.y), z2 = quad_bcast<2>(r.z), w2 = quad_bcast<2>(r.w);
+    const unsigned x3 = quad_bcast<3>(r.x), y3 = quad_bcast<3>(r.y), z3 = quad_bcast<3>(r.z), w3 = quad_bcast<3>(r.w);
+    unsigned w[4];
+    w[0] = c == 0 ? x0 : c == 1 ? y0 : c == 2 ? z0 : w0;
+    w[1] = c == 0 ? x1 : c == 1 ? y1 : c == 2 ? z1 : w1;
+    w[2] = c == 0 ? x2 : c == 1 ? y2 : c == 2 ? z2 : w2;
+    w[3] = c == 0 ? x3 : c == 1 ? y3 : c == 2 ? z3 : w3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = u32_to_unit(w[e]) < p ? 0.f : ks;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------- forward
@@ -146,12 +201,21 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __rest
     float m_run = -3.0e38f, l_run = 0.f;
     const uint64_t row_idx = ((uint64_t)z * T + (uint64_t)(qi < T ? qi : 0)) * (uint64_t)T;
     const int ntiles = (kl + 31) / 32;
+    float4 kreg[32 * (DK / 4) / 256], vreg[32 * (DK / 4) / 256];
+    if (ntiles > 0) {
+        load_rows_regs<DK, 256>(kreg, k, base, C, 0, kl, tid);
+        load_rows_regs<DK, 256>(vreg, v, base, C, 0, kl, tid);
+    }
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * 32;
+        __syncthreads();                                                          // the previous tile's LDS reads are done
+        store_rows_lds<DK, 256>(k_l, kreg, tid);
+        store_rows_lds<DK, 256>(v_l, vreg, tid);
         __syncthreads();
-        stage_rows<DK, 256>(k_l, k, base, C, k0, kl, tid);
-        stage_rows<DK, 256>(v_l, v, base, C, k0, kl, tid);
-        __syncthreads();
+        if (tile + 1 < ntiles) {                                                  // next tile's rows: in flight under this tile's MFMAs
+            load_rows_regs<DK, 256>(kreg, k, base, C, k0 + 32, kl, tid);
+            load_rows_regs<DK, 256>(vreg, v, base, C, k0 + 32, kl, tid);
+        }
         const f32x16_t st = score_product<DK>(k_l, qf, l31, half);
         float mx = -3.0e38f;
         float sc[16];
@@ -257,12 +321,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
         for (int i = 0; i < 16; ++i) acc[d][i] = 0.f;
     const uint64_t row_idx = ((uint64_t)z * T + (uint64_t)qc) * (uint64_t)T;
     const int ntiles = (kl + 31) / 32;
+    float4 kreg[32 * (DK / 4) / 256], vreg[32 * (DK / 4) / 256];
+    if (ntiles > 0) {
+        load_rows_regs<DK, 256>(kreg, k, base, C, 0, kl, tid);
+        load_rows_regs<DK, 256>(vreg, v, base, C, 0, kl, tid);
+    }
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * 32;
+        __syncthreads();                                                          // the previous tile's LDS reads are done
+        store_rows_lds<DK, 256>(k_l, kreg, tid);
+        store_rows_lds<DK, 256>(v_l, vreg, tid);
         __syncthreads();
-        stage_rows<DK, 256>(k_l, k, base, C, k0, kl, tid);
-        stage_rows<DK, 256>(v_l, v, base, C, k0, kl, tid);
-        __syncthreads();
+        if (tile + 1 < ntiles) {                                                  // next tile's rows: in flight under this tile's MFMAs
+            load_rows_regs<DK, 256>(kreg, k, base, C, k0 + 32, kl, tid);
+            load_rows_regs<DK, 256>(vreg, v, base, C, k0 + 32, kl, tid);
+        }
         const f32x16_t st = score_product<DK>(k_l, qf, l31, half);              // S^T: rows = keys, column = this lane's query
         const f32x16_t dpt = score_product<DK>(v_l, dof, l31, half);            // dPd^T
         bf16x8_t dsf[2];
@@ -323,17 +396,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         load_frags<DK>(vf, v + base + (int64_t)kc * C, half);
         const bool key_ok = key < kl;
         const int ntiles = (T + 31) / 32;
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const int q0 = tile * 32;
-            __syncthreads();
-            stage_rows<DK, 256>(q_l, q, base, C, q0, T, tid);
-            stage_rows<DK, 256>(do_l, dout, base, C, q0, T, tid);
+        float4 qreg[32 * (DK / 4) / 256], doreg[32 * (DK / 4) / 256];
+        float lse_r = 3.0e38f, d_r = 0.f;
+        auto prefetch = [&](int q0) {
+            load_rows_regs<DK, 256>(qreg, q, base, C, q0, T, tid);
+            load_rows_regs<DK, 256>(doreg, dout, base, C, q0, T, tid);
             if (tid < 32) {
                 const int qi = q0 + tid;
-                lse_l[tid] = qi < T ? lse[(int64_t)z * T + qi] : 3.0e38f;
-                d_l[tid] = qi < T ? Dbuf[(int64_t)z * T + qi] : 0.f;
+                lse_r = qi < T ? lse[(int64_t)z * T + qi] : 3.0e38f;
+                d_r = qi < T ? Dbuf[(int64_t)z * T + qi] : 0.f;
             }
+        };
+        prefetch(0);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int q0 = tile * 32;
+            __syncthreads();                                                      // the previous tile's LDS reads are done
+            store_rows_lds<DK, 256>(q_l, qreg, tid);
+            store_rows_lds<DK, 256>(do_l, doreg, tid);
+            if (tid < 32) { lse_l[tid] = lse_r; d_l[tid] = d_r; }
             __syncthreads();
+            if (tile + 1 < ntiles) prefetch(q0 + 32);                             // in flight under this tile's 32 MFMAs per wave
             const f32x16_t s = score_product<DK>(q_l, kf, l31, half);            // S: rows = queries of the tile, column = this lane's key
             const f32x16_t dp = score_product<DK>(do_l, vf, l31, half);          // dPd
             bf16x8_t pdf[2], dsf[2];
@@ -342,13 +424,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                 const float4 l4 = *reinterpret_cast<const float4*>(&lse_l[g * 8 + 4 * half]);
                 const float4 d4 = *reinterpret_cast<const float4*>(&d_l[g * 8 + 4 * half]);
                 const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+                float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop_p > 0.f) {
+                    if ((T & 3) == 0) {
+                        dropout_rows4_quad(keep4, seed, stream_id, (uint64_t)z * T, q0 + g * 8 + 4 * half, T, key, lane, drop_p);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            keep4[e] = dropout_factor(seed, stream_id, ((uint64_t)z * T + (uint64_t)(q0 + g * 8 + 4 * half + e)) * (uint64_t)T + (uint64_t)key, drop_p);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g + e;
-                    const int qi = q0 + g * 8 + 4 * half + e;
                     const float p = key_ok ? __expf(s[i] * scale - lr[e]) : 0.f;   // rows past T carry lse = +3e38: p = 0
-                    float keep = 1.f;
-                    if (drop_p > 0.f) keep = dropout_factor(seed, stream_id, ((uint64_t)z * T + (uint64_t)qi) * (uint64_t)T + (uint64_t)key, drop_p);
+                    const float keep = keep4[e];
                     pdf[i >> 3][i & 7] = (__bf16)(p * keep);
                     dsf[i >> 3][i & 7] = (__bf16)(scale * p * (dp[i] * keep - dr[e]));
                 }

@@ -65,7 +65,21 @@ __global__ __launch_bounds__(256) void l1_multi_kernel(MultiPtr d, float* __rest
     const float gsc = MODE ? gscale[0] * d.scale[it] : 0.f;
     (void)es;
     if (vec) {
-        for (long long i = base + threadIdx.x * 8; i + 8 <= end; i += 256 * 8) {
+        long long i = base + threadIdx.x * 8;
+        if (MODE == 0) {
+            // four 16-byte pairs per trip, all eight loads requested before the first subtraction (one pair per trip kept 32 bytes
+            // per thread in flight: 1.4 TB/s over the ~0.6 GB of feature maps of a family)
+            for (; i + 3 * 2048 + 8 <= end; i += 4 * 2048) {
+                float x[4][8], y[4][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ld8(a, bf, i + q * 2048, x[q]); ld8(b, bf, i + q * 2048, y[q]); }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += fabsf(x[q][k] - y[q][k]);
+            }
+        }
+        for (; i + 8 <= end; i += 256 * 8) {
             float x[8], y[8];
             ld8(a, bf, i, x); ld8(b, bf, i, y);
             if (MODE == 0) {

@@ -172,6 +172,12 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         if constexpr (!EARLY) { if (ld >= 0) issue_end(); }
     };
     const int nk = K / TBK;
+    // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, "two waves per SIMD", item 4): the
+    // younger wave of every SIMD loses the VALU / issue arbitration on every segment.  Compile-time switch OSP_GLDS_PRIO, OFF:
+#ifndef OSP_GLDS_PRIO
+#define OSP_GLDS_PRIO 0                // measured: no gain on this loop (DiscriminatorP 1024->1024 forward 136-141 us either way)
+#endif
+    if constexpr (NW == 8 && OSP_GLDS_PRIO) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     if constexpr (NST == 2) {
         issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
