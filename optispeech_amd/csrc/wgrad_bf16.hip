@@ -638,13 +638,15 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     static int use_tr = -1;
     if (use_tr < 0) { const char* e = getenv("OSP_WGRAD_TR"); use_tr = (e && atoi(e) == 0) ? 0 : 1; }
     if (use_tr && fast && N % 64 == 0 && Cin % 64 == 0) {
-        // 128-tiles when both channel counts allow it, 64-tiles otherwise (DiscriminatorR).  The frames are split so that
-        // the grid is close to a multiple of the resident workgroup count (2 / CU for T = 128, 4 / CU for T = 64);
-        // partial sums meet in f32 atomics
+        // 128-tiles when both channel counts allow it, 64-tiles otherwise (DiscriminatorR).  The frames are split until the grid
+        // has about `target` workgroups; partial sums meet in f32 atomics, and every split adds a tile's worth of them: round 3
+        // lowered the targets from 1024 / 2048 (two to four rounds of resident workgroups) to 256 / 512 (ONE workgroup per CU and
+        // four times fewer atomics): DiscriminatorR 64 -> 64 (3, 9) 95 -> 73 us, DiscriminatorP 128 -> 512 89 -> 60 us
+        // (tools/mrd_bench.py, tools/mpd_bench.py with OSP_WGRAD_TARGET = 128 ... 2048)
         const int64_t T_ = (N % 128 == 0 && Cin % 128 == 0) ? 128 : 64;
         static int64_t tgt_env = -1;
         if (tgt_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET"); tgt_env = e ? atoll(e) : 0; }
-        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = tgt_env > 0 ? (T_ == 128 ? tgt_env : 2 * tgt_env) : (T_ == 128 ? 1024 : 2048);
+        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = tgt_env > 0 ? (T_ == 128 ? tgt_env : 2 * tgt_env) : (T_ == 128 ? 256 : 512);
         int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
         if (ch < 4 * TBK) ch = 4 * TBK;
