@@ -434,6 +434,36 @@ def test_conv_gemm_bf16_gelu_relu_bwd_epilogues(M, cin, n_out, aux_bf16):
     assert relerr(got.float(), want_relu) < 1e-2
 
 
+@pytest.mark.parametrize("dy_bf16", [False, True])
+@pytest.mark.parametrize("U,H,W,cin,KH,KW,ph,pw", [(37, 1, 103, 1024, 1, 3, 0, 1), (5, 9, 40, 64, 3, 3, 1, 1), (3, 1, 7, 128, 1, 3, 0, 1),
+                                                   (64, 1, 204, 1024, 1, 3, 0, 1)])
+def test_conv_post_wgrad_one_output_channel(U, H, W, cin, KH, KW, ph, pw, dy_bf16):
+    """conv_wgrad_n1_kernel (csrc/wgrad_n1.hip): the weight / bias gradient of the discriminators' conv_post layers
+    (Conv2d(C, 1, (3, 1)) / Conv2d(C, 1, (3, 3)), _discriminators.py:60, :160) as a dY-weighted column sum, against torch's conv2d
+    gradients on the same bf16-rounded activations; dY as the f32 score gradient (the training step) and as bf16; accumulation
+    semantics (a second call adds); row counts that do not fill a trip, a split or a slice."""
+    from optispeech_amd import disc_ops as D
+    x = bfr(rnd(U, cin, H, W, seed=1))
+    w = rnd(1, cin, KH, KW, seed=2, scale=0.02).requires_grad_(True)
+    b = torch.zeros(1, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=1, padding=(ph, pw))
+    dy = rnd(*y.shape, seed=3)
+    if dy_bf16:
+        dy = bfr(dy)
+    y.backward(dy)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if dy_bf16:
+        dyg = dyg.to(torch.bfloat16)
+    dw, db = D.conv2d_wgrad(dyg, xg, KH, KW, 1, 1, ph, pw)
+    assert relerr(dw.permute(0, 3, 1, 2), w.grad) < 1e-4 and relerr(db, b.grad) < 1e-4      # f32 products of bf16 values, f32 sums
+    from optispeech_amd import kernels as K
+    Ho, Wo = y.shape[2], y.shape[3]
+    K.conv2d_wgrad_bf16(dyg.view(-1, 1), xg.view(-1, cin), dw, db, M=U * Ho * Wo, Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=1, cin=cin,
+                        taps=KH * KW, KW=KW, pad_h=ph, pad_w=pw, step_h=1, step_w=1)
+    assert relerr(dw.permute(0, 3, 1, 2), 2 * w.grad) < 1e-4 and relerr(db, 2 * b.grad) < 1e-4
+
+
 @pytest.mark.parametrize("U,W,cin,cout,sw", [(40, 331, 512, 1024, 3), (70, 64, 1024, 1024, 1), (33, 200, 256, 256, 1)])
 def test_conv_wgrad_bf16_8wave_tiles(U, W, cin, cout, sw):
     """The 8-wave 256x256 weight-gradient kernel (conv_wgrad_bf16_tr8_kernel: N, Cin multiples of 256, >= 4096 rows, bf16 operands)
