@@ -12,7 +12,7 @@
 #define SC_MAXTAPS 40
 
 struct SmallCin {
-    const float* x; const void* y; int y_bf16; const float* w; const float* b; float* dw; float* db;
+    const float* x; const void* y; int y_bf16; const float* w; const float* b; float* dw; float* db; float* ws;
     int M, Trows, Wrows, Hin, Win, Cout, taps, KW, sh, sw, ph, pw; float slope; int lrelu;
 };
 
@@ -125,6 +125,7 @@ typedef __bf16 sc_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int KSTEPS, int NT>
 __global__ __launch_bounds__(256) void smallcin_fwd_mfma_kernel(SmallCin p) {
+    __shared__ __attribute__((aligned(16))) unsigned short stage[4][32 * (NT * 32 + 8)];
     const int lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5;
     sc_bf16x8 bw[KSTEPS][NT];
     int toff[KSTEPS][8], tdh[KSTEPS][8], tdw[KSTEPS][8];
@@ -182,16 +183,33 @@ __global__ __launch_bounds__(256) void smallcin_fwd_mfma_kernel(SmallCin p) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bw[ks][nt], acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bw[ks][nt], acc[nt], 0, 0, 0);
             }
-        const int row0 = tile * 32 + kg * 4;
+        // Output rows through a wave-private LDS tile: in the MFMA layout a lane owns one channel, i.e. 2-byte stores, 32 per lane
+        // and tile, each instruction touching 64-byte pieces of two rows; row-major out of LDS a lane stores 16 bytes (8 channels)
+        // and the tile leaves in 4 instructions (2 for 32 channels) of whole rows.
+        constexpr int SP = NT * 32 + 8;                                          // bf16 elements per staged row
+        unsigned short* st = stage[threadIdx.x >> 6];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r >> 2) * 8 + (r & 3);
+                const int lrow = kg * 4 + (r >> 2) * 8 + (r & 3);
                 float v = acc[nt][r] + bias[nt];
                 if (p.lrelu) v = v > 0.f ? v : v * p.slope;
-                if (row < p.M) y[(int64_t)row * p.Cout + nt * 32 + li] = (__bf16)v;
+                st[lrow * SP + nt * 32 + li] = __builtin_bit_cast(unsigned short, (__bf16)v);
             }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int CPR = NT * 4, RPI = 64 / CPR;                              // 16-byte chunks per row, rows per wave instruction
+        const int cc = lane % CPR, rr = lane / CPR;
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int lrow = it * RPI + rr, row = tile * 32 + lrow;
+            if (row < p.M)
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(y) + (int64_t)row * p.Cout + cc * 8) =
+                    *reinterpret_cast<const uint4*>(st + lrow * SP + cc * 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -199,6 +217,7 @@ __global__ __launch_bounds__(256) void smallcin_fwd_mfma_kernel(SmallCin p) {
 template <int TT, int NT>
 __global__ __launch_bounds__(256) void smallcin_wgrad_mfma_kernel(SmallCin p) {
     __shared__ float red[TT * NT * 16 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned short dy_stage[4][16 * (NT * 32 + 8)];
     const int lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5, wv = threadIdx.x >> 6;
     int tdh[TT], tdw[TT], toff[TT];
     float tfill[TT];                                                          // value of a non-tap column: 1 for the bias column
@@ -218,32 +237,62 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_mfma_kernel(SmallCin p) {
     const unsigned short* __restrict__ dy = reinterpret_cast<const unsigned short*>(p.y);
     const int Ho = p.Trows / p.Wrows;
     const int nsteps = (p.M + 15) >> 4, nwaves = gridDim.x * 4;
+    // dY rows of a step (16 rows x Cout bf16) are fetched as 16-byte chunks (whole rows) into a wave-private LDS tile and read
+    // back TRANSPOSED as the B operand (ds_read_b64_tr_b16, the addressing of attention_train.hip's value_product): in the MFMA
+    // layout a lane owns one channel and 8 rows, i.e. eight 2-byte loads at a row stride -- 16 load instructions per step for
+    // 2 KB.  The k index e of both operands is row 8 (e >> 2) + 4 kg + (e & 3) of the step.
+    constexpr int LD = NT * 32 + 8, CPR = NT * 4;                              // staged row pitch (bf16), 16-byte chunks per row
+    unsigned short* dyl = dy_stage[wv];
+    const int r16 = lane & 15, g16 = (lane >> 4) & 1;
     for (int step = blockIdx.x * 4 + wv; step < nsteps; step += nwaves) {
-        const int m0 = step * 16 + kg * 8;
-        int u = m0 / p.Trows, t = m0 - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
+        const int ms = step * 16;
+#pragma unroll
+        for (int c = lane; c < 16 * CPR; c += 64) {
+            const int rowl = c / CPR, cc = c - rowl * CPR, m = ms + rowl;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < p.M) v = *reinterpret_cast<const uint4*>(dy + (int64_t)m * p.Cout + cc * 8);
+            *reinterpret_cast<uint4*>(dyl + rowl * LD + cc * 8) = v;
+        }
         sc_bf16x8 a[TT], al[TT], b[NT];                                        // x as hi + lo bf16 halves (see the forward kernel)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int m = m0 + q;
-            const bool valid = m < p.M;
-            const int h0 = th * p.sh - p.ph, w0 = tw * p.sw - p.pw;
-            const int xbase = (u * p.Hin + h0) * p.Win + w0;
+        for (int run = 0; run < 2; ++run) {
+            const int m0 = ms + 8 * run + 4 * kg;
+            int u = m0 / p.Trows, t = m0 - u * p.Trows, th = t / p.Wrows, tw = t - th * p.Wrows;
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-                const int hh = h0 + tdh[tt], ww = w0 + tdw[tt];
-                const bool ok = valid && (unsigned)hh < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win;   // tdh = 2^20 for non-taps
-                const float xv = p.x[ok ? xbase + toff[tt] : 0];                   // unconditional load, index select (no branch)
-                const float xs = ok ? xv : (valid ? tfill[tt] : 0.f);
-                a[tt][q] = (__bf16)xs;
-                al[tt][q] = (__bf16)(xs - (float)a[tt][q]);
-            }
+            for (int qq = 0; qq < 4; ++qq) {
+                const int q = 4 * run + qq, m = m0 + qq;
+                const bool valid = m < p.M;
+                const int h0 = th * p.sh - p.ph, w0 = tw * p.sw - p.pw;
+                const int xbase = (u * p.Hin + h0) * p.Win + w0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const unsigned short raw = dy[(valid ? m : 0) * p.Cout + nt * 32 + li];
-                b[nt][q] = __builtin_bit_cast(__bf16, valid ? raw : (unsigned short)0);
+                for (int tt = 0; tt < TT; ++tt) {
+                    const int hh = h0 + tdh[tt], ww = w0 + tdw[tt];
+                    const bool ok = valid && (unsigned)hh < (unsigned)p.Hin && (unsigned)ww < (unsigned)p.Win;   // tdh = 2^20 for non-taps
+                    const float xv = p.x[ok ? xbase + toff[tt] : 0];               // unconditional load, index select (no branch)
+                    const float xs = ok ? xv : (valid ? tfill[tt] : 0.f);
+                    a[tt][q] = (__bf16)xs;
+                    al[tt][q] = (__bf16)(xs - (float)a[tt][q]);
+                }
+                if (++tw == p.Wrows) { tw = 0; if (++th == Ho) { th = 0; ++u; } }
             }
-            if (++tw == p.Wrows) { tw = 0; if (++th == Ho) { th = 0; ++u; } }
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = nt * 32 + 16 * g16 + 4 * (r16 & 3);
+            const unsigned short* a0 = dyl + (4 * kg + (r16 >> 2)) * LD + col;
+            const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned short*)a0;
+            typedef short s16x4_sc __attribute__((ext_vector_type(4)));
+            s16x4_sc lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(8 * LD * 2) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+            union { struct { s16x4_sc l, h; } s2; sc_bf16x8 vv; } uu;
+            uu.s2.l = lo; uu.s2.h = hi;
+            b[nt] = uu.vv;
+        }
+        __builtin_amdgcn_wave_barrier();                                      // the tile is free for the next step's rows
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
@@ -267,12 +316,48 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_mfma_kernel(SmallCin p) {
         }
         __syncthreads();
     }
+    if (p.ws) {
+        // two-stage reduction: every workgroup STORES its partial tile; smallcin_wgrad_reduce_kernel (next launch) sums the
+        // workgroups.  With atomics the 256 workgroups added into the same 2 304 addresses (taps x Cout + Cout): same-address
+        // atomics serialise at the memory side, and the kernel's time was proportional to the NUMBER OF WORKGROUPS
+        // (256 / 512 / 1024 workgroups: 170 / 215 / 350 us for the 1 -> 64 (7, 5) layer).
+        for (int e = threadIdx.x; e < TT * NT * 16 * 64; e += 256) p.ws[(int64_t)blockIdx.x * (TT * NT * 16 * 64) + e] = red[e];
+        return;
+    }
     for (int e = threadIdx.x; e < TT * NT * 16 * 64; e += 256) {
         const int l = e & 63, r = (e >> 6) & 15, tile = e >> 10, nt = tile % NT, tt = tile / NT;
         const int tap = tt * 32 + (r >> 2) * 8 + (l >> 5) * 4 + (r & 3), n = nt * 32 + (l & 31);
         if (tap < p.taps) atomicAdd(p.dw + n * p.taps + tap, red[e]);
         else if (tap == p.taps && p.db) atomicAdd(p.db + n, red[e]);
     }
+}
+
+// stage 2: a workgroup owns 64 consecutive accumulator entries (same (tap, n) map as above); its 4 waves each sum a quarter of the
+// `nblocks` partial tiles with 8 loads in flight per lane (coalesced 256-byte rows), meet in LDS, and the first wave adds to
+// dw / db -- a plain read-modify-write, every entry has one owner
+__global__ __launch_bounds__(256) void smallcin_wgrad_reduce_kernel(const float* __restrict__ ws, int nblocks, int E, int NT, int taps,
+                                                                    float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int per = (nblocks + 3) >> 2, b0 = wv * per, b1 = min(nblocks, b0 + per);
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += ws[(int64_t)(b + k) * E + e];
+    }
+    for (; b < b1; ++b) s[0] += ws[(int64_t)b * E + e];
+    part[wv][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (wv) return;
+    const float tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int l = e & 63, r = (e >> 6) & 15, tile = e >> 10, nt = tile % NT, tt = tile / NT;
+    const int tap = tt * 32 + (r >> 2) * 8 + (l >> 5) * 4 + (r & 3), n = nt * 32 + (l & 31);
+    if (tap < taps) dw[n * taps + tap] += tot;
+    else if (tap == taps && db) db[n] += tot;
 }
 
 static int smallcin_fill(SmallCin& p, int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin, int64_t Win, int64_t Cout,
@@ -294,7 +379,7 @@ extern "C" int osp_smallcin_conv_fwd(const float* x, const float* w, const float
     SmallCin p;
     OSP_CHECK_ARG(smallcin_fill(p, M, Trows, Wrows, Hin, Win, Cout, taps, KW, sh, sw, ph, pw), "unsupported small-Cin geometry");
     OSP_CHECK_ARG(M * Cout < (1ll << 31) && (M / Trows) * Hin * Win < (1ll << 31), "small-Cin operand exceeds 32-bit indexing");
-    p.x = x; p.w = w; p.b = b; p.y = y; p.y_bf16 = (int)y_bf16; p.dw = nullptr; p.db = nullptr; p.lrelu = (int)lrelu; p.slope = slope;
+    p.x = x; p.w = w; p.b = b; p.y = y; p.y_bf16 = (int)y_bf16; p.dw = nullptr; p.db = nullptr; p.ws = nullptr; p.lrelu = (int)lrelu; p.slope = slope;
     if (y_bf16 && (Cout == 32 || Cout == 64) && taps <= 48 && !getenv("OSP_SMALLCIN_VALU")) {
         const int64_t tiles = cdiv(M, 32), nb = cdiv(tiles, 4);
         const dim3 grid((unsigned)(nb < 512 ? nb : 512)), block(256);       // 2 blocks / CU: the per-wave weight prologue is amortised
@@ -313,22 +398,31 @@ extern "C" int osp_smallcin_conv_fwd(const float* x, const float* w, const float
     return OSP_OK;
 }
 
-// dw (Cout, taps) and db (Cout) are accumulated (f32 atomics).
+// dw (Cout, taps) and db (Cout) are accumulated.  ws (optional): ws_floats >= 256 * 4096 floats of scratch for the two-stage
+// reduction of the MFMA variant (without it: f32 atomics from every workgroup).
 extern "C" int osp_smallcin_conv_wgrad(const float* x, const void* dy, int64_t y_bf16, float* dw, float* db, int64_t M,
                                        int64_t Trows, int64_t Wrows, int64_t Hin, int64_t Win, int64_t Cout, int64_t taps,
-                                       int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, hipStream_t stream) {
+                                       int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, float* ws, int64_t ws_floats,
+                                       hipStream_t stream) {
     OSP_CHECK_ARG(x && dy && dw, "null operand");
     SmallCin p;
     OSP_CHECK_ARG(smallcin_fill(p, M, Trows, Wrows, Hin, Win, Cout, taps, KW, sh, sw, ph, pw), "unsupported small-Cin geometry");
     OSP_CHECK_ARG(M * Cout < (1ll << 31) && (M / Trows) * Hin * Win < (1ll << 31), "small-Cin operand exceeds 32-bit indexing");
-    p.x = x; p.w = nullptr; p.b = nullptr; p.y = dy; p.y_bf16 = (int)y_bf16; p.dw = dw; p.db = db; p.lrelu = 0; p.slope = 0.f;
+    p.x = x; p.w = nullptr; p.b = nullptr; p.y = dy; p.y_bf16 = (int)y_bf16; p.dw = dw; p.db = db; p.lrelu = 0; p.slope = 0.f; p.ws = nullptr;
     if (y_bf16 && (Cout == 32 || Cout == 64) && taps < 64 && !getenv("OSP_SMALLCIN_VALU")) {
         const int64_t steps = cdiv(M, 16), nb = cdiv(steps, 4 * 8);
-        const dim3 grid((unsigned)(nb < 256 ? nb : 256)), block(256);       // one atomic epilogue per block: keep the grid at 1 / CU
+        static int64_t wg_cap = 0;
+        if (!wg_cap) { const char* e = getenv("OSP_SMALLCIN_WG"); wg_cap = e ? atoll(e) : 256; }
+        const dim3 grid((unsigned)(nb < wg_cap ? nb : wg_cap)), block(256);  // one atomic epilogue per block
+        const int tt_ = taps < 32 ? 1 : 2, nt_ = Cout == 32 ? 1 : 2, E = tt_ * nt_ * 1024;
+        if (ws && ws_floats >= (int64_t)grid.x * E) p.ws = ws;
 #define SC_WG(TT_, NT_) hipLaunchKernelGGL((smallcin_wgrad_mfma_kernel<TT_, NT_>), grid, block, 0, stream, p)
         if (Cout == 32) { if (taps < 32) SC_WG(1, 1); else SC_WG(2, 1); }
         else            { if (taps < 32) SC_WG(1, 2); else SC_WG(2, 2); }
 #undef SC_WG
+        if (p.ws)
+            hipLaunchKernelGGL(smallcin_wgrad_reduce_kernel, dim3((unsigned)(E / 64)), dim3(256), 0, stream, (const float*)ws, (int)grid.x, E,
+                               nt_, (int)taps, dw, db);
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }

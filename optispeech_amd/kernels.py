@@ -785,8 +785,9 @@ def smallcin_fwd(x, w, b, *, U, Hin, Win, Ho, Wo, cout, KH, KW, sh, sw, ph, pw, 
 
 
 def smallcin_wgrad(x, dy, dw, db, *, U, Hin, Win, Ho, Wo, cout, KH, KW, sh, sw, ph, pw):
+    ws = torch.empty((256 * 4096,), device=x.device, dtype=torch.float32) if _isbf(dy) else None     # two-stage reduction scratch (4 MB)
     call("osp_smallcin_conv_wgrad", x, dy, _isbf(dy), dw, db, U * Ho * Wo, Ho * Wo, Wo, Hin, Win, cout, KH * KW, KW, sh, sw, ph,
-         pw)
+         pw, ws, 0 if ws is None else ws.numel())
 
 
 # ------------------------------------------------------------------------------------------------ weight norm / L1
