@@ -52,11 +52,16 @@ __device__ __forceinline__ unsigned pk2b(float a, float b) {
 }
 
 // MODE 0: out[0] += scale * sum |a - b|           MODE 1: o[i] = gscale * scale * sign(b - a)
+// MODE 0 runs with a bounded grid: a workgroup walks chunks blockIdx.x, + gridDim.x, ... and adds ONE value to out[0] at its end.
+// One atomic per 8 192-element chunk meant ~90 k same-address atomics for a family's feature maps; they serialise at the memory
+// side and the sum took 212 us where the sign kernel (MODE 1: same reads PLUS a write, no atomic) takes 130.
 template <int MODE>
 __global__ __launch_bounds__(256) void l1_multi_kernel(MultiPtr d, float* __restrict__ out, const float* __restrict__ gscale) {
     __shared__ float scratch[16];
-    const int it = find_item(d.first, d.count, blockIdx.x);
-    const long long n = d.n[it], base = (long long)(blockIdx.x - d.first[it]) * CHUNK;
+    float wg_total = 0.f;
+  for (int blk = blockIdx.x; blk < d.first[d.count]; blk += gridDim.x) {
+    const int it = find_item(d.first, d.count, blk);
+    const long long n = d.n[it], base = (long long)(blk - d.first[it]) * CHUNK;
     const void* a = d.a[it]; const void* b = d.b[it];
     const int bf = d.bf[it], es = bf ? 2 : 4;
     const bool vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | (MODE ? reinterpret_cast<uintptr_t>(d.o[it]) : 0)) & 15) == 0;
@@ -108,9 +113,11 @@ __global__ __launch_bounds__(256) void l1_multi_kernel(MultiPtr d, float* __rest
             if (bf) reinterpret_cast<bf16_t*>(d.o[it])[i] = (bf16_t)r; else reinterpret_cast<float*>(d.o[it])[i] = r;
         }
     }
+    if (MODE == 0) wg_total += s * d.scale[it];                // per-thread partial, already scaled for its item
+  }
     if (MODE == 0) {
-        s = block_sum(s, scratch);
-        if (threadIdx.x == 0) atomicAdd(out, s * d.scale[it]);
+        wg_total = block_sum(wg_total, scratch);
+        if (threadIdx.x == 0) atomicAdd(out, wg_total);
     }
 }
 
@@ -159,7 +166,7 @@ extern "C" int osp_l1_sum_multi(const int64_t* a_host, const int64_t* b_host, co
     for (int64_t lo = 0; lo < count; lo += MULTI_MAX) {
         MultiPtr d;
         const int blocks = fill_multi(d, a_host, b_host, nullptr, n_host, scale_host, nullptr, lo, lo + MULTI_MAX < count ? lo + MULTI_MAX : count, bf16_host);
-        if (blocks > 0) hipLaunchKernelGGL(l1_multi_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, d, out, (const float*)nullptr);
+        if (blocks > 0) hipLaunchKernelGGL(l1_multi_kernel<0>, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, d, out, (const float*)nullptr);
     }
     OSP_LAUNCH_CHECK();
     return OSP_OK;
@@ -337,13 +344,31 @@ __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restric
     const int c4 = C >> 2, col = threadIdx.x % c4, sub = threadIdx.x / c4, nsub = 256 / c4;   // c4 <= 256
     const int64_t m0 = (int64_t)blockIdx.x * rows_per_block, m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sub < nsub)
-        for (int64_t m = m0 + sub; m < m1; m += nsub) {
+    if (sub < nsub) {
+        int64_t m = m0 + sub;
+        // four rows per trip, their loads requested before the first FMA (one row per trip = two dependent 16-byte loads in flight)
+        for (; m + 3 * nsub < m1; m += 4 * nsub) {
+            float4 x[4], y[4]; float r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t mq = m + q * nsub;
+                x[q] = *reinterpret_cast<const float4*>(a + mq * C + col * 4);
+                y[q] = b ? *reinterpret_cast<const float4*>(b + mq * C + col * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                r[q] = rowf ? rowf[mq] : 1.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc.x = fmaf(r[q] * x[q].x, y[q].x, acc.x); acc.y = fmaf(r[q] * x[q].y, y[q].y, acc.y);
+                acc.z = fmaf(r[q] * x[q].z, y[q].z, acc.z); acc.w = fmaf(r[q] * x[q].w, y[q].w, acc.w);
+            }
+        }
+        for (; m < m1; m += nsub) {
             const float4 x = *reinterpret_cast<const float4*>(a + m * C + col * 4);
             const float4 y = b ? *reinterpret_cast<const float4*>(b + m * C + col * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
             const float r = rowf ? rowf[m] : 1.f;
             acc.x = fmaf(r * x.x, y.x, acc.x); acc.y = fmaf(r * x.y, y.y, acc.y); acc.z = fmaf(r * x.z, y.z, acc.z); acc.w = fmaf(r * x.w, y.w, acc.w);
         }
+    }
     // combine the nsub row groups through LDS, one component at a time
     for (int k = 0; k < 4; ++k) {
         red[threadIdx.x] = k == 0 ? acc.x : k == 1 ? acc.y : k == 2 ? acc.z : acc.w;
@@ -360,8 +385,12 @@ extern "C" int osp_colsum_prod(const float* a, const float* b, const float* rowf
     OSP_CHECK_ARG(a && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "C must be a multiple of 4, <= 1024");
     // ~1024 workgroups whatever M is (the encoder / vocoder calls have M = 2-4k rows: 256 rows per block left 8-16 blocks on a
     // 256-CU part, 54 us per launch); at least 8 rows per block so the atomics stay few
-    int64_t rpb = cdiv(M, 1024);
-    rpb = rpb < 8 ? 8 : (rpb > 256 ? 256 : rpb);
+    // (round 3: ~64 workgroups, not 1024 -- 1024 / 256 / 128 / 64 / 32 workgroups: 35.4 / 27.6 / 15.7 / 11.3 / 11.7 us per launch averaged over a step's 12 launches: every workgroup adds into the SAME C addresses, and same-address atomics serialise at the
+    // memory side -- the kernel's tail was proportional to the number of workgroups, see smallcin.hip's two-stage note)
+    static int64_t wg_target = 0;
+    if (!wg_target) { const char* e = getenv("OSP_COLSUM_WG"); wg_target = e ? atoll(e) : 64; }
+    int64_t rpb = cdiv(M, wg_target);
+    rpb = rpb < 8 ? 8 : rpb;
     hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream, a, b, rowf, out, M, (int)C, (int)rpb);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
