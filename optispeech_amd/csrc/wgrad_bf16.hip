@@ -645,8 +645,10 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         // (tools/mrd_bench.py, tools/mpd_bench.py with OSP_WGRAD_TARGET = 128 ... 2048)
         const int64_t T_ = (N % 128 == 0 && Cin % 128 == 0) ? 128 : 64;
         static int64_t tgt_env = -1;
+        static int64_t tgt64_env = -1;
         if (tgt_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET"); tgt_env = e ? atoll(e) : 0; }
-        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = tgt_env > 0 ? (T_ == 128 ? tgt_env : 2 * tgt_env) : (T_ == 128 ? 256 : 512);
+        if (tgt64_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET64"); tgt64_env = e ? atoll(e) : 0; }
+        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = T_ == 128 ? (tgt_env > 0 ? tgt_env : 256) : (tgt64_env > 0 ? tgt64_env : (tgt_env > 0 ? 2 * tgt_env : 512));
         int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
         if (ch < 4 * TBK) ch = 4 * TBK;
