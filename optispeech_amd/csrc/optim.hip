@@ -4,13 +4,21 @@
 //   osp_adamw_clip   one pass over (p, g, m, v): global-norm clip factor read from the device scalar (no host sync),
 //                    decoupled weight decay, bias-corrected Adam update.  HBM-bound: 4 reads + 3 writes per element.
 #include "osp_common.h"
+#include <stdlib.h>
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
     __shared__ float scratch[16];
     float s = 0.f;
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {               // four 16-byte loads in flight per thread
+        const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+        s += (v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w) +
+             (v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w) + (v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w);
+    }
+    for (; i < n4; i += stride) {
         const float4 v = g4[i];
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
@@ -24,7 +32,9 @@ extern "C" int osp_sumsq(const float* g, int64_t n, double* out, hipStream_t str
     OSP_CHECK_ARG(g && out && n > 0, "bad args");
     OSP_CHECK_ARG((reinterpret_cast<uintptr_t>(g) & 15) == 0, "gradient arena must be 16-byte aligned");
     const int64_t blocks = cdiv(n, 256 * 16);
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, stream, g, n, out);
+    static int64_t cap = 0;
+    if (!cap) { const char* e = getenv("OSP_SUMSQ_WG"); cap = e ? atoll(e) : 256; }         // every workgroup ends with one f64 atomic into `out`: 128 / 256 / 512 / 1024 workgroups = 38 / 28 / 29 / 35 us
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap)), dim3(256), 0, stream, g, n, out);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
