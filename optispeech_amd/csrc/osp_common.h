@@ -45,7 +45,15 @@ template <int CTRL, int ROWMASK = 0xf>
 __device__ __forceinline__ float dpp_get(float oldv, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
 }
+// (a wave that is only partly active -- a 32-thread workgroup, a divergent caller -- takes the shuffle butterfly: the DPP tree
+// ends in lane 63, which must have executed it)
+__device__ __forceinline__ bool wave_is_full() { return __builtin_amdgcn_read_exec() == ~0ull; }
 __device__ __forceinline__ float wave_sum(float v) {
+    if (!wave_is_full()) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
     v += dpp_get<0xB1>(0.f, v);            // quad_perm [1,0,3,2]
     v += dpp_get<0x4E>(0.f, v);            // quad_perm [2,3,0,1]
     v += dpp_get<0x141>(0.f, v);           // row_half_mirror
@@ -60,6 +68,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+    if (!wave_is_full()) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        return v;
+    }
     v = fmaxf(v, dpp_get<0xB1>(v, v));
     v = fmaxf(v, dpp_get<0x4E>(v, v));
     v = fmaxf(v, dpp_get<0x141>(v, v));
