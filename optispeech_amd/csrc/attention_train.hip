@@ -173,9 +173,10 @@ __device__ __forceinline__ void dropout_rows4_quad(float (&f)[4], uint64_t seed,
 
 // ------------------------------------------------------------------------------------------------------------- forward
 // One workgroup = 4 waves = 128 queries of one (b, h); a wave owns 32 queries; keys / values in tiles of 32.
-template <int DK>
+template <int DK, bool BIAS>
 __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                             const int64_t* __restrict__ klen, float* __restrict__ o, float* __restrict__ lse,
+                                                             const int64_t* __restrict__ klen, const float* __restrict__ sbias,
+                                                             float* __restrict__ o, float* __restrict__ lse,
                                                              int H, int T, float scale, float drop_p, uint64_t seed,
                                                              const int64_t* __restrict__ seed_dev, uint32_t stream_id) {
     constexpr int LD = DK + 8, DB = DK / 32;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __rest
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
     float m_run = -3.0e38f, l_run = 0.f;
     const uint64_t row_idx = ((uint64_t)z * T + (uint64_t)(qi < T ? qi : 0)) * (uint64_t)T;
+    const int64_t brow = (int64_t)row_idx;                                        // start of this query's row in a (Z, T, T) tensor
     const int ntiles = (kl + 31) / 32;
     float4 kreg[32 * (DK / 4) / 256], vreg[32 * (DK / 4) / 256];
     if (ntiles > 0) {
@@ -216,13 +218,19 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __rest
             load_rows_regs<DK, 256>(kreg, k, base, C, k0 + 32, kl, tid);
             load_rows_regs<DK, 256>(vreg, v, base, C, k0 + 32, kl, tid);
         }
+        float sb[16];                                                             // additive score term (relative-position attention), requested before the MFMAs
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kr = k0 + (i >> 2) * 8 + 4 * half + (i & 3);
+            sb[i] = (BIAS && kr < kl) ? sbias[brow + kr] : 0.f;
+        }
         const f32x16_t st = score_product<DK>(k_l, qf, l31, half);
         float mx = -3.0e38f;
         float sc[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kr = k0 + (i >> 2) * 8 + 4 * half + (i & 3);
-            sc[i] = kr < kl ? st[i] * scale : -3.0e38f;
+            sc[i] = kr < kl ? (st[i] + sb[i]) * scale : -3.0e38f;
             mx = fmaxf(mx, sc[i]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -278,10 +286,11 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------- backward: dQ (+ D)
-template <int DK>
+template <int DK, bool BIAS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                           const float* __restrict__ o, const float* __restrict__ dout,
                                                           const float* __restrict__ lse, const int64_t* __restrict__ klen,
+                                                          const float* __restrict__ sbias, float* __restrict__ dsbias,
                                                           float* __restrict__ dq, float* __restrict__ Dbuf, int H, int T, float scale,
                                                           float drop_p, uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id) {
     constexpr int LD = DK + 8, DB = DK / 32, DS = DK / 16;
@@ -320,6 +329,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[d][i] = 0.f;
     const uint64_t row_idx = ((uint64_t)z * T + (uint64_t)qc) * (uint64_t)T;
+    const int64_t brow = (int64_t)row_idx;
     const int ntiles = (kl + 31) / 32;
     float4 kreg[32 * (DK / 4) / 256], vreg[32 * (DK / 4) / 256];
     if (ntiles > 0) {
@@ -336,6 +346,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
             load_rows_regs<DK, 256>(kreg, k, base, C, k0 + 32, kl, tid);
             load_rows_regs<DK, 256>(vreg, v, base, C, k0 + 32, kl, tid);
         }
+        float sb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kr = k0 + (i >> 2) * 8 + 4 * half + (i & 3);
+            sb[i] = (BIAS && kr < kl) ? sbias[brow + kr] : 0.f;
+        }
         const f32x16_t st = score_product<DK>(k_l, qf, l31, half);              // S^T: rows = keys, column = this lane's query
         const f32x16_t dpt = score_product<DK>(v_l, dof, l31, half);            // dPd^T
         bf16x8_t dsf[2];
@@ -347,12 +363,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * g + e;
                 const int kr = k0 + g * 8 + 4 * half + e;
-                const float p = kr < kl ? __expf(st[i] * scale - lse_q) : 0.f;
-                dsf[i >> 3][i & 7] = (__bf16)(scale * p * (dpt[i] * keep[e] - Dq));
+                const float p = kr < kl ? __expf((st[i] + sb[i]) * scale - lse_q) : 0.f;
+                const float ds = scale * p * (dpt[i] * keep[e] - Dq);
+                dsf[i >> 3][i & 7] = (__bf16)ds;
+                if (BIAS && dsbias && qi < T && kr < T) dsbias[brow + kr] = ds;         // the score term's gradient IS dS (f32, before the bf16 rounding)
             }
         }
         value_product<DK>(acc, dsf, k_l, lane);                                 // dQ += dS K
     }
+    if (BIAS && dsbias && qi < T)                                                // keys past the last processed tile: zero gradient
+        for (int kr = ntiles * 32 + 4 * half; kr < T; kr += 8)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kr + e < T) dsbias[brow + kr + e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int qr = q0 + (i >> 2) * 8 + 4 * half + (i & 3);
@@ -365,10 +388,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------------------- backward: dK, dV
 // One workgroup = 4 waves = 128 keys of one (b, h); a wave owns 32 keys (K / V fragments in registers) and walks the query tiles.
-template <int DK>
+template <int DK, bool BIAS>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                            const float* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ Dbuf, const int64_t* __restrict__ klen,
+                                                           const float* __restrict__ sbias,
                                                            float* __restrict__ dk, float* __restrict__ dv, int H, int T, float scale,
                                                            float drop_p, uint64_t seed, const int64_t* __restrict__ seed_dev, uint32_t stream_id) {
     constexpr int LD = DK + 8, DB = DK / 32, DS = DK / 16;
@@ -437,7 +461,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * g + e;
-                    const float p = key_ok ? __expf(s[i] * scale - lr[e]) : 0.f;   // rows past T carry lse = +3e38: p = 0
+                    const int qrow = q0 + g * 8 + 4 * half + e;
+                    const float sbv = (BIAS && key_ok && qrow < T) ? sbias[((int64_t)z * T + qrow) * T + key] : 0.f;
+                    const float p = key_ok ? __expf((s[i] + sbv) * scale - lr[e]) : 0.f;   // rows past T carry lse = +3e38: p = 0
                     const float keep = keep4[e];
                     pdf[i >> 3][i & 7] = (__bf16)(p * keep);
                     dsf[i >> 3][i & 7] = (__bf16)(scale * p * (dp[i] * keep - dr[e]));
@@ -462,8 +488,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 
 // q, k, v (B, T, H*DK) f32; klen (B) int64; o (B, T, H*DK); lse (B*H, T).  drop_p in [0, 1); seed / seed_dev / stream_id as in
 // osp_attn_softmax_fwd (the same Philox key and element indices: the fused and the unfused path draw identical masks).
-extern "C" int osp_attn_train_fwd(const float* q, const float* k, const float* v, const int64_t* klen, float* o, float* lse,
-                                  int64_t B, int64_t H, int64_t T, int64_t DK, float scale, float drop_p, int64_t seed,
+// sbias (optional): (B*H, T, T) f32 added to q k^T BEFORE the scaling -- the relative-position term of RelPositionMultiHeadedAttention
+// (_transformer/attention.py:290-313).
+extern "C" int osp_attn_train_fwd(const float* q, const float* k, const float* v, const int64_t* klen, const float* sbias, float* o,
+                                  float* lse, int64_t B, int64_t H, int64_t T, int64_t DK, float scale, float drop_p, int64_t seed,
                                   const int64_t* seed_dev, int64_t stream_id, hipStream_t stream) {
     OSP_CHECK_ARG(q && k && v && klen && o && lse && B > 0 && H > 0 && T > 0, "bad args");
     OSP_CHECK_ARG(DK == 32 || DK == 64 || DK == 128, "head width must be 32, 64 or 128");
@@ -471,33 +499,38 @@ extern "C" int osp_attn_train_fwd(const float* q, const float* k, const float* v
     const dim3 grid((unsigned)cdiv(T, 128), (unsigned)(B * H));
     osp_note_symbol("attn_train_fwd_kernel");
     osp_note_flops(4.0 * (double)B * H * T * T * DK);
-#define L(D_) hipLaunchKernelGGL((attn_train_fwd_kernel<D_>), grid, dim3(256), 0, stream, q, k, v, klen, o, lse, (int)H, (int)T, scale, \
-                                 drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id)
-    if (DK == 128) L(128); else if (DK == 64) L(64); else L(32);
+#define L(D_, B_) hipLaunchKernelGGL((attn_train_fwd_kernel<D_, B_>), grid, dim3(256), 0, stream, q, k, v, klen, sbias, o, lse, (int)H, (int)T, scale, \
+                                     drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id)
+    if (sbias) { if (DK == 128) L(128, true); else if (DK == 64) L(64, true); else L(32, true); }
+    else       { if (DK == 128) L(128, false); else if (DK == 64) L(64, false); else L(32, false); }
 #undef L
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
 
 // dout (B, T, H*DK); dq, dk, dv (B, T, H*DK) are fully written; Dbuf (B*H, T) scratch (written by the dQ kernel, read by dK/dV).
+// sbias / dsbias (optional): the score term of the forward and its gradient ((B*H, T, T) f32, fully written).
 extern "C" int osp_attn_train_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* dout,
-                                  const int64_t* klen, float* dq, float* dk, float* dv, float* Dbuf, int64_t B, int64_t H, int64_t T,
+                                  const int64_t* klen, const float* sbias, float* dsbias, float* dq, float* dk, float* dv, float* Dbuf,
+                                  int64_t B, int64_t H, int64_t T,
                                   int64_t DK, float scale, float drop_p, int64_t seed, const int64_t* seed_dev, int64_t stream_id,
                                   hipStream_t stream) {
     OSP_CHECK_ARG(q && k && v && o && lse && dout && klen && dq && dk && dv && Dbuf && B > 0 && H > 0 && T > 0, "bad args");
+    OSP_CHECK_ARG(!dsbias || sbias, "a score-term gradient needs the score term");
     OSP_CHECK_ARG(DK == 32 || DK == 64 || DK == 128, "head width must be 32, 64 or 128");
     OSP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "dropout probability");
     const dim3 grid((unsigned)cdiv(T, 128), (unsigned)(B * H));
     osp_note_symbol("attn_bwd_dq_kernel");
     osp_note_flops(14.0 * (double)B * H * T * T * DK);
-#define L(D_)                                                                                                                          \
+#define L(D_, B_)                                                                                                                      \
     do {                                                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D_>), grid, dim3(256), 0, stream, q, k, v, o, dout, lse, klen, dq, Dbuf, (int)H, (int)T,  \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D_, B_>), grid, dim3(256), 0, stream, q, k, v, o, dout, lse, klen, sbias, dsbias, dq, Dbuf, (int)H, (int)T,  \
                            scale, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id);                                              \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_>), grid, dim3(256), 0, stream, q, k, v, dout, lse, Dbuf, klen, dk, dv, (int)H, (int)T, \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, B_>), grid, dim3(256), 0, stream, q, k, v, dout, lse, Dbuf, klen, sbias, dk, dv, (int)H, (int)T, \
                            scale, drop_p, (uint64_t)seed, seed_dev, (uint32_t)stream_id);                                              \
     } while (0)
-    if (DK == 128) L(128); else if (DK == 64) L(64); else L(32);
+    if (sbias) { if (DK == 128) L(128, true); else if (DK == 64) L(64, true); else L(32, true); }
+    else       { if (DK == 128) L(128, false); else if (DK == 64) L(64, false); else L(32, false); }
 #undef L
     OSP_LAUNCH_CHECK();
     return OSP_OK;

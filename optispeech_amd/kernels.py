@@ -839,7 +839,7 @@ def attn_fused_fwd(q, k, v, klen, H):
     return o
 
 
-def attn_train_fwd(q, k, v, klen, H, drop_p=0.0, seed=0, stream_id=0):
+def attn_train_fwd(q, k, v, klen, H, drop_p=0.0, seed=0, stream_id=0, sbias=None):
     """Fused training forward (csrc/attention_train.hip): (B, T, H*dk) f32 q, k, v -> (o, lse); the (T x T) scores never exist.
     The dropout mask is the one osp_attn_softmax_fwd would draw from the same (seed, stream_id)."""
     _f32(q, k, v)
@@ -849,12 +849,16 @@ def attn_train_fwd(q, k, v, klen, H, drop_p=0.0, seed=0, stream_id=0):
     o = torch.empty_like(q)
     lse = torch.empty((B * H, T), device=q.device, dtype=torch.float32)
     sh, sd = _seed(seed)
-    call("osp_attn_train_fwd", q, k, v, klen, o, lse, B, H, T, dk, 1.0 / float(dk) ** 0.5, float(drop_p), sh, sd, int(stream_id))
+    if sbias is not None:
+        _f32(sbias)
+        assert sbias.is_contiguous() and sbias.numel() == B * H * T * T
+    call("osp_attn_train_fwd", q, k, v, klen, sbias, o, lse, B, H, T, dk, 1.0 / float(dk) ** 0.5, float(drop_p), sh, sd, int(stream_id))
     return o, lse
 
 
-def attn_train_bwd(q, k, v, o, lse, dout, klen, H, drop_p=0.0, seed=0, stream_id=0):
-    """Fused backward: recomputes the probabilities tile by tile; returns (dq, dk, dv) in the (B, T, H*dk) layout."""
+def attn_train_bwd(q, k, v, o, lse, dout, klen, H, drop_p=0.0, seed=0, stream_id=0, sbias=None, want_dsbias=False):
+    """Fused backward: recomputes the probabilities tile by tile; returns (dq, dk, dv) in the (B, T, H*dk) layout (+ the score
+    term's gradient when ``sbias`` is given: (B*H, T, T), or None unless ``want_dsbias``)."""
     _f32(q, k, v, o, dout)
     B, T, C = q.shape
     dk = C // H
@@ -862,9 +866,10 @@ def attn_train_bwd(q, k, v, o, lse, dout, klen, H, drop_p=0.0, seed=0, stream_id
     dq, dkk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     dbuf = torch.empty_like(lse)
     sh, sd = _seed(seed)
-    call("osp_attn_train_bwd", q, k, v, o, lse, dout, klen, dq, dkk, dv, dbuf, B, H, T, dk, 1.0 / float(dk) ** 0.5, float(drop_p),
-         sh, sd, int(stream_id))
-    return dq, dkk, dv
+    dsb = torch.empty_like(sbias) if (want_dsbias and sbias is not None) else None
+    call("osp_attn_train_bwd", q, k, v, o, lse, dout, klen, sbias, dsb, dq, dkk, dv, dbuf, B, H, T, dk, 1.0 / float(dk) ** 0.5,
+         float(drop_p), sh, sd, int(stream_id))
+    return (dq, dkk, dv, dsb) if sbias is not None else (dq, dkk, dv)
 
 
 def attn_softmax_bwd(P, dPd, scale, drop_p=0.0, seed=0, stream_id=0):

@@ -692,15 +692,17 @@ class AttentionFn(torch.autograd.Function):
             # no-grad / inference: one flash-style kernel, the (B*H, T, T) scores never exist (csrc/attention.hip)
             return K.attn_fused_fwd(q.contiguous(), k.contiguous(), v.contiguous(), klen, H)
         ctx.fused = False
-        if (_FUSED_ATTN_TRAIN and sbias is None and q.is_cuda and _precision.is_bf16() and dk in (32, 64, 128)):
+        if (_FUSED_ATTN_TRAIN and q.is_cuda and _precision.is_bf16() and dk in (32, 64, 128)):
             # training, performance mode: fused forward that keeps the per-row log-sum-exp, fused recomputing backward
             # (csrc/attention_train.hip) -- no (B*H, T, T) tensor in either direction, no head-major copies
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-            o, lse = K.attn_train_fwd(q, k, v, klen, H, drop_p, seed, stream_id)
-            if any(ctx.needs_input_grad[:3]):
-                ctx.save_for_backward(q, k, v, o, lse, klen)
+            sb = None if sbias is None else sbias.reshape(Z, T, T).contiguous()      # relative-position score term (Conformer)
+            o, lse = K.attn_train_fwd(q, k, v, klen, H, drop_p, seed, stream_id, sbias=sb)
+            if any(ctx.needs_input_grad[:3]) or (sb is not None and ctx.needs_input_grad[8]):
+                ctx.save_for_backward(q, k, v, o, lse, klen, *([] if sb is None else [sb]))
                 ctx.cfg = (H, drop_p, seed, stream_id)
                 ctx.fused = True
+                ctx.bias_shape = None if sbias is None else sbias.shape
             return o
         heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)      # noqa: E731
         qh, kh, vh = heads(q), heads(k), heads(v)
@@ -719,10 +721,14 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         if ctx.fused:
-            q, k, v, o, lse, klen = ctx.saved_tensors
+            saved = ctx.saved_tensors
+            q, k, v, o, lse, klen = saved[:6]
+            sb = saved[6] if len(saved) > 6 else None
             H, drop_p, seed, stream_id = ctx.cfg
-            dq, dk_, dv = K.attn_train_bwd(q, k, v, o, lse, dout.contiguous(), klen, H, drop_p, seed, stream_id)
-            return dq, dk_, dv, None, None, None, None, None, None
+            res = K.attn_train_bwd(q, k, v, o, lse, dout.contiguous(), klen, H, drop_p, seed, stream_id, sbias=sb,
+                                   want_dsbias=sb is not None and ctx.needs_input_grad[8])
+            dsb = res[3].view(ctx.bias_shape) if (sb is not None and res[3] is not None) else None
+            return res[0], res[1], res[2], None, None, None, None, None, dsb
         qh, kh, vh, P, Pd = ctx.saved_tensors
         B, T, H, dk, scale, drop_p, seed, stream_id = ctx.cfg
         Z = B * H

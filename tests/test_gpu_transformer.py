@@ -220,3 +220,64 @@ def test_attention_function_trains_through_the_fused_pair():
     finally:
         ops._FUSED_ATTN_TRAIN = keep
         precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("B,T,H,dk,p", [(2, 130, 2, 64, 0.2), (2, 257, 4, 32, 0.0), (1, 800, 2, 128, 0.1)])
+def test_fused_attention_with_a_score_term_vs_f64(B, T, H, dk, p):
+    """The relative-position form (RelPositionMultiHeadedAttention, _transformer/attention.py:290-313: scores = (q k^T + bd) / sqrt(dk)):
+    the fused pair with an additive (B*H, T, T) score term against f64 autograd -- output, dq / dk / dv and the term's own gradient
+    (= dS, written by the dQ kernel in f32), ragged key lengths (the gradient is exactly zero on masked keys)."""
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 1000 + T + 5)
+    C, Z = H * dk, B * H
+    q, k, v, dout = (torch.randn(B, T, C, generator=g).to(DEV) for _ in range(4))
+    sb = (torch.randn(Z, T, T, generator=g) * 2.0).to(DEV)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    klen = lens.to(DEV)
+    seed, sid = 77, 5
+    o, lse = K.attn_train_fwd(q, k, v, klen, H, p, seed, sid, sbias=sb)
+    dq, dk_, dv, dsb = K.attn_train_bwd(q, k, v, o, lse, dout, klen, H, p, seed, sid, sbias=sb, want_dsbias=True)
+    keep = _dropout_keep(Z, T, p, seed, sid).view(B, H, T, T)
+    bf = lambda t: t.to(torch.bfloat16).double().cpu()                                            # noqa: E731
+    q64, k64, v64 = (bf(t).requires_grad_(True) for t in (q, k, v))
+    sb64 = sb.double().cpu().view(B, H, T, T).requires_grad_(True)
+    heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3)                                     # noqa: E731
+    s = (heads(q64) @ heads(k64).transpose(-1, -2) + sb64) / dk ** 0.5
+    mask = torch.arange(T)[None, None, None, :] >= lens[:, None, None, None]
+    P = torch.softmax(s.masked_fill(mask, float("-inf")), -1).masked_fill(mask, 0.0)
+    want = ((P * keep) @ heads(v64)).permute(0, 2, 1, 3).reshape(B, T, C)
+    want.backward(bf(dout))
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()        # noqa: E731
+    assert rel(o, want.detach()) < 1e-2
+    assert rel(dq, q64.grad) < 1.5e-2 and rel(dk_, k64.grad) < 1.5e-2 and rel(dv, v64.grad) < 1.5e-2
+    assert rel(dsb.view(B, H, T, T), sb64.grad) < 1.5e-2
+    for b in range(B):
+        assert torch.count_nonzero(dsb.view(B, H, T, T)[b, :, :, int(lens[b]):]) == 0
+
+
+def test_attention_function_with_score_term_fused_vs_unfused():
+    """AttentionFn with sbias (the Conformer's call): fused pair vs the unfused kernels in the performance mode, same dropout mask."""
+    from optispeech_amd import ops, precision
+    precision.set_precision("bf16")
+    keep = ops._FUSED_ATTN_TRAIN
+    try:
+        g = torch.Generator().manual_seed(12)
+        base = [torch.randn(2, 150, 256, generator=g).to(DEV) for _ in range(3)]
+        sb0 = torch.randn(2 * 4, 150, 150, generator=g).to(DEV)
+        dout = torch.randn(2, 150, 256, generator=g).to(DEV)
+        klen = torch.tensor([150, 61], device=DEV)
+        res = {}
+        for fused in (True, False):
+            ops._FUSED_ATTN_TRAIN = fused
+            q, k, v = (t.clone().requires_grad_(True) for t in base)
+            sb = sb0.clone().requires_grad_(True)
+            o = ops.AttentionFn.apply(q, k, v, klen, 4, 0.1, 99, 3, sb)
+            o.backward(dout)
+            res[fused] = (o.detach(), q.grad, k.grad, v.grad, sb.grad)
+        for a, b in zip(res[True], res[False]):
+            err = ((a - b).norm() / b.norm()).item()
+            assert err < 2e-2, err
+    finally:
+        ops._FUSED_ATTN_TRAIN = keep
+        precision.set_precision("f32")
