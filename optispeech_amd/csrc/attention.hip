@@ -157,18 +157,30 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(const float* __rest
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
     float m_run = -3.0e38f, l_run = 0.f;                         // of query (q0 + l31); both halves keep identical copies
     const int ntiles = (kl + 31) / 32;
+    // K / V rows of the NEXT tile are requested into registers before this tile's MFMAs (round 3, as in attention_train.hip): a
+    // tile's global latency flies under compute instead of stalling the workgroup at the staging barrier
+    constexpr int NR = 32 * (DK / 4) / 256;
+    float4 kreg[NR], vreg[NR];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int i = tid + it * 256, r = i / (DK / 4), c4 = i - r * (DK / 4), kr = k0 + r;
+            kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[it] = kreg[it];
+            if (kr < kl) {
+                kreg[it] = *reinterpret_cast<const float4*>(k + base + (int64_t)kr * C + 4 * c4);
+                vreg[it] = *reinterpret_cast<const float4*>(v + base + (int64_t)kr * C + 4 * c4);
+            }
+        }
+    };
+    if (ntiles > 0) fetch(0);
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * 32;
         __syncthreads();                                          // the previous tile's reads are done
         // stage K and V rows k0 .. k0 + 31 (zero rows beyond the valid keys), f32 -> bf16
-        for (int i = tid; i < 32 * (DK / 4); i += 256) {
-            const int r = i / (DK / 4), c4 = i - r * (DK / 4);
-            const int kr = k0 + r;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (kr < kl) {
-                kv = *reinterpret_cast<const float4*>(k + base + (int64_t)kr * C + 4 * c4);
-                vv = *reinterpret_cast<const float4*>(v + base + (int64_t)kr * C + 4 * c4);
-            }
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int i = tid + it * 256, r = i / (DK / 4), c4 = i - r * (DK / 4);
+            const float4 kv = kreg[it], vv = vreg[it];
             typedef __bf16 b2 __attribute__((ext_vector_type(2)));
             b2 k01, k23, v01, v23;
             k01[0] = (__bf16)kv.x; k01[1] = (__bf16)kv.y; k23[0] = (__bf16)kv.z; k23[1] = (__bf16)kv.w;
@@ -177,6 +189,7 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(const float* __rest
             *reinterpret_cast<uint2*>(v_l + r * LD + 4 * c4) = make_uint2(__builtin_bit_cast(unsigned, v01), __builtin_bit_cast(unsigned, v23));
         }
         __syncthreads();
+        if (tile + 1 < ntiles) fetch(k0 + 32);
         // S^T tile: rows = keys (A operand: lane (key l31, half) holds d = 16 s + 8 half ..), columns = this wave's queries
         f32x16_a st;
 #pragma unroll
