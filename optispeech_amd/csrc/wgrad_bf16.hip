@@ -697,7 +697,9 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
              ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0 && (sYb % 4 == 0) && (sXb % 4 == 0)) {
         // f32 operands (generator): 64-channel tiles through registers; small problems -> many splits
         const int64_t tl = (N / 64) * taps * (Cin / 64) * batch;
-        int64_t sp = tl >= 960 ? 1 : (2048 + tl / 2) / tl;
+        static int64_t tgt32 = 0;
+        if (!tgt32) { const char* e = getenv("OSP_WGRAD_TARGET_F32"); tgt32 = e ? atoll(e) : 512; }    // 256 / 512 / 1024 / 2048 workgroups: 78 / 34 / 39 / 52 us per launch (16 per step; 2048 was the round-2 value)
+        int64_t sp = tl >= tgt32 / 2 - 64 ? 1 : (tgt32 + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
         if (ch < 2 * TBK) ch = 2 * TBK;
         sp = cdiv(M, ch);
