@@ -626,7 +626,9 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         return osp_launch_wgrad_n1(dY, y_bf16, ldy, X, ldx, M, Trows, d2[0], d2[1], Tin, Cin, taps, d2[2], pad, d2[4], x_step, d2[3], arow, oscale,
                                    dW, db, stream);
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
-    int64_t splits = tiles >= 192 ? 1 : cdiv(512, tiles);
+    static int64_t tgt_gen = 0;
+    if (!tgt_gen) { const char* e = getenv("OSP_WGRAD_TARGET_GEN"); tgt_gen = e ? atoll(e) : 512; }
+    int64_t splits = tiles >= 192 ? 1 : cdiv(tgt_gen, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
     if (chunk < 2 * TBK) chunk = 2 * TBK;
     splits = cdiv(M, chunk);
