@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
     __shared__ __attribute__((aligned(1024))) unsigned short smem[2 * 2 * SK * T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * (T / 2), wn0 = (wave & 1) * (T / 2);
-    const int ctiles = p.Cin / T;
+    const int ctiles = (p.Cin + T - 1) / T;                 // (Cin = 32 with T = 64, BUF form only: the upper half of the tile reads zeros)
     const int j = blockIdx.y / ctiles, c0 = (blockIdx.y - j * ctiles) * T;
     const int n0 = blockIdx.x * T;
     const int bz = blockIdx.z / p.splits, sp = blockIdx.z - bz * p.splits;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, yo, 0, 0, 0);
             const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, th = fd_div(t, p.fd_wrows), tw = t - th * p.Wrows;
             const int tt = tw * p.x_step + blk_kw - p.pad, hh = th * p.x_step_h + blk_kh - p.pad_h;
-            const bool xv = mv && (unsigned)tt < (unsigned)p.Tin && (unsigned)hh < (unsigned)p.Hin;
+            const bool xv = mv && (unsigned)tt < (unsigned)p.Tin && (unsigned)hh < (unsigned)p.Hin && (c0 + lslot * 8 < p.Cin);
             const unsigned xo = xv ? (unsigned)(((u * p.Hin + hh) * p.Tin + tt) * ldx32) * 2u + xcol2 : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, xo, 0, 0, 0);
             return;
@@ -426,8 +426,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_tr_kernel(WgradB p) {
                 const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float* dst = dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c;
                 const float val = (p.oscale ? p.oscale[n] : 1.f) * acc[i][jj][r];
-                if (p.splits == 1) *dst += val;            // this block owns the tile: no atomics
-                else atomicAdd(dst, val);
+                if (c < p.Cin) {
+                    if (p.splits == 1) *dst += val;        // this block owns the tile: no atomics
+                    else atomicAdd(dst, val);
+                }
             }
         }
     if (do_bias && wn0 == 0 && l31 == 0) {
@@ -639,7 +641,13 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
                       (sYb % 8 == 0) && (sXb % 8 == 0);
     static int use_tr = -1;
     if (use_tr < 0) { const char* e = getenv("OSP_WGRAD_TR"); use_tr = (e && atoi(e) == 0) ? 0 : 1; }
-    if (use_tr && fast && N % 64 == 0 && Cin % 64 == 0) {
+    // 32-channel inputs (DiscriminatorP 32 -> 128): the 64-tile kernel with the upper half of every X row reading zeros through the
+    // buffer descriptor -- half the MFMA work is padding, but the generic tile kernel below (no DMA, no double buffering) took
+    // 84 us for the same layer
+    const bool cin32 = Cin == 32 && N % 64 == 0 && ((int64_t)(M / Trows) * d2[1] * Tin * ldx) * 2 < (int64_t)0x7fffff00 &&
+                       (M * ldy) * 2 < (int64_t)0x7fffff00 && !getenv("OSP_WGRAD_NO_CIN32") &&
+                       !(getenv("OSP_WGRAD_BUF") && atoi(getenv("OSP_WGRAD_BUF")) == 0);      // needs the descriptor's bounds check
+    if (use_tr && fast && N % 64 == 0 && (Cin % 64 == 0 || cin32)) {
         // 128-tiles when both channel counts allow it, 64-tiles otherwise (DiscriminatorR).  The frames are split until the grid
         // has about `target` workgroups; partial sums meet in f32 atomics, and every split adds a tile's worth of them: round 3
         // lowered the targets from 1024 / 2048 (two to four rounds of resident workgroups) to 256 / 512 (ONE workgroup per CU and
@@ -650,13 +658,13 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         static int64_t tgt64_env = -1;
         if (tgt_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET"); tgt_env = e ? atoll(e) : 0; }
         if (tgt64_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET64"); tgt64_env = e ? atoll(e) : 0; }
-        const int64_t tl = (N / T_) * taps * (Cin / T_) * batch, target = T_ == 128 ? (tgt_env > 0 ? tgt_env : 256) : (tgt64_env > 0 ? tgt64_env : (tgt_env > 0 ? 2 * tgt_env : 512));
+        const int64_t tl = (N / T_) * taps * cdiv(Cin, T_) * batch, target = T_ == 128 ? (tgt_env > 0 ? tgt_env : 256) : (tgt64_env > 0 ? tgt64_env : (tgt_env > 0 ? 2 * tgt_env : 512));
         int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
         if (ch < 4 * TBK) ch = 4 * TBK;
         sp = cdiv(M, ch);
         p.chunk = (int)ch; p.splits = (int)sp;
-        const dim3 g((unsigned)(N / T_), (unsigned)(taps * (Cin / T_)), (unsigned)(sp * batch));
+        const dim3 g((unsigned)(N / T_), (unsigned)(taps * cdiv(Cin, T_)), (unsigned)(sp * batch));
         // buffer-resource loads when one batch slice of each operand is addressable with 31-bit byte offsets
         const int64_t rows_x = (M / Trows) * (int64_t)p.Hin * Tin;
         const int64_t yb = ((M - 1) * ldy + N) * 2, xb = ((rows_x - 1) * ldx + Cin) * 2;
