@@ -382,7 +382,9 @@ extern "C" int osp_smallcin_conv_fwd(const float* x, const float* w, const float
     p.x = x; p.w = w; p.b = b; p.y = y; p.y_bf16 = (int)y_bf16; p.dw = nullptr; p.db = nullptr; p.ws = nullptr; p.lrelu = (int)lrelu; p.slope = slope;
     if (y_bf16 && (Cout == 32 || Cout == 64) && taps <= 48 && !getenv("OSP_SMALLCIN_VALU")) {
         const int64_t tiles = cdiv(M, 32), nb = cdiv(tiles, 4);
-        const dim3 grid((unsigned)(nb < 512 ? nb : 512)), block(256);       // 2 blocks / CU: the per-wave weight prologue is amortised
+        static int64_t fcap = 0;
+        if (!fcap) { const char* e = getenv("OSP_SMALLCIN_FWD_WG"); fcap = e ? atoll(e) : 512; }
+        const dim3 grid((unsigned)(nb < fcap ? nb : fcap)), block(256);     // 2 blocks / CU: the per-wave weight prologue is amortised
         const int ks = (int)cdiv(taps, 16);
 #define SC_FWD(KS, NT_) hipLaunchKernelGGL((smallcin_fwd_mfma_kernel<KS, NT_>), grid, block, 0, stream, p)
         if (Cout == 32) { if (ks == 1) SC_FWD(1, 1); else if (ks == 2) SC_FWD(2, 1); else SC_FWD(3, 1); }
