@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial schedule: do not issue the discriminator phase from its own stream (OptiSpeech.pipeline_steps)")
     ap.add_argument("--backbone", choices=["convnext", "transformer"], default="convnext",
-                    help="transformer = BASELINE configs[4] encoder/decoder (secondary datapoint; the headline is convnext)")
+                    help="transformer = BASELINE configs[3] encoder/decoder (secondary datapoint; the headline is convnext)")
     ap.add_argument("--precision", choices=["bf16", "f32", "mixed"], default=os.environ.get("OSP_PRECISION", "bf16"),
                     help="bf16 = BASELINE config[1] (bf16 MFMA operands, f32 accumulate, f32 master weights); "
                          "f32 = exact-f32 parity mode; mixed = generator exactly as f32 (wav_hat / mel within north_star's 1e-3), "
@@ -403,11 +403,15 @@ def main():
     _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments = False, False, False, False
     from optispeech_amd import ops as _ops
     keep_wg, _ops._WG["on"] = _ops._WG["on"], False            # weight-gradient kernels inline too: events sit on the launch stream
+    from optispeech_amd import tape as _tape
+    tape_stats = _tape.stats()                                 # of the timed region (and its set-up / warm-up)
+    keep_tape, _tape.ENABLED = _tape.ENABLED, False            # the bracketed steps run eagerly: a replayed call list has no per-call hook
     timer.enabled = True
     for i in range(3):
         model.training_step(batch, a.warmup + a.steps + i)
     sync()
     timer.enabled = False
+    _tape.ENABLED = keep_tape
     _ops._WG["on"] = keep_wg
     _disc._DISC_STREAMS, model.graph_steps, model.pipeline_steps, model.graph_segments = keep_streams, keep_graph, keep_pipe, keep_seg
     ksum = timer.summary()
@@ -569,12 +573,16 @@ def main():
                "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.precision, "data": "synthetic",
-               "config": {"workload": ("configs[4]: Transformer backbone" if a.backbone == "transformer" else "configs[1]: ConvNeXt backbone") + ", synthetic LJSpeech-shaped batch=32 per GPU "
+               "config": {"workload": ("configs[3]: Transformer backbone" if a.backbone == "transformer" else "configs[1]: ConvNeXt backbone") + ", synthetic LJSpeech-shaped batch=32 per GPU "
                                       "(T_text=128, T_mel=800, 22.05 kHz), full GAN training step "
                                       "(G phase + D phase + 2x AdamW), train mode",
                           "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}", "schedule": sched,
                           "lengths": "ragged" if a.ragged else "fixed"},
-               "per_gpu": value / world, "host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "roofline": roof, "cpu_baseline": cpu,
+               "per_gpu": value / world, "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
+               "call_tapes": {"enabled": bool(keep_tape and _tape.available()), **tape_stats,
+                              "note": "regions of the step recorded once as C-ABI call lists and replayed from C (optispeech_amd/tape.py); "
+                                      "counts cover set-up + warm-up + timed steps"},
+               "roofline": roof, "cpu_baseline": cpu,
                "am_only_step": am_only, "replay_disc_forward_step": replay, "graph_replay_step": graph_fig,
                "parity_mode_step": parity_fig,
                "synthesise": None if (a.no_infer or not secondary) else synthesise_rtf(model, dev),

@@ -57,7 +57,7 @@ class _Lib:
         self._fn = {}
         self._sigs = _header_signatures()
         # native argument marshalling (optispeech_amd/fastcall.py): same library, ~5x less interpreter time per call
-        self._fcall, self._fidx, self._fcall_rows = None, {}, None
+        self._fcall, self._fidx, self._fcall_rows, self._fast = None, {}, None, None
         if os.environ.get("OSP_CTYPES_CALL", "0") != "1":
             fast = _load_fast()
             if fast is not None and fast.HEADER_SHA1 != _header_sha1():
@@ -67,6 +67,7 @@ class _Lib:
                 fast = None
             if fast is not None:
                 fast.set_guard(os.environ.get("OSP_FAST_CALL", "0") != "1")
+                self._fast = fast
                 self._fcall = fast.call
                 self._fcall_rows = getattr(fast, "call_rows", None)
                 self._fidx = {n: fast.index(n) for n in self._sigs if fast.index(n) is not None}
@@ -103,9 +104,11 @@ class _Lib:
             if rc != 0:
                 raise OspError(f"{name} failed ({rc}): {self.cdll.osp_last_error().decode()}")
             return
+        if self._fast is not None and hasattr(self._fast, "tape_recording") and self._fast.tape_recording():
+            raise OspError(f"{name} has no native marshalling entry (include/osp.h changed?): it cannot be recorded on a tape")
         f = self._fn.get(name) or self.fn(name)
         T = torch.Tensor
-        cargs = [a.data_ptr() if isinstance(a, T) else a for a in args]
+        cargs = [a.data_ptr() if isinstance(a, T) else (a.ctypes.data if hasattr(a, "ctypes") else a) for a in args]
         if _GUARD and any(isinstance(a, T) and not a.is_cuda for a in args):
             raise OspError(f"{name}: tensor argument is not on the GPU")
         cargs.append(_STREAM_OVERRIDE[0] or _raw_stream(dev))      # torch's current HIP stream (raw handle)

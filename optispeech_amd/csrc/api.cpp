@@ -49,7 +49,10 @@ extern "C" int osp_kernel_note_bytes_host(double* bytes_host) {
     g_note_bytes = 0.0;
     return 0;
 }
-extern "C" int osp_abi_version() { return 1; }
+// ABI history: 1 = rounds 1-2; 2 = round 3 added trailing workspace parameters to osp_layernorm_bwd / osp_ln_dwconv7_bwd /
+// osp_smallcin_conv_wgrad (a consumer built against the version-1 header would pass its stream in the workspace slot) and round 4
+// added osp_memset / osp_copy / osp_store_i64 / the fused block entry points.  Bump whenever an EXISTING signature changes.
+extern "C" int osp_abi_version() { return 2; }
 
 // Content hash of the sources (and flags) this library was compiled from: optispeech_amd/build.py passes it on the command line
 // of this file and compares it with the sources next to a shipped library (the marker prefix makes it findable without dlopen).
@@ -66,5 +69,38 @@ extern "C" int osp_stream_handover(void* event_host_handle, void* dst_stream_hos
     hipError_t e = hipEventRecord(reinterpret_cast<hipEvent_t>(event_host_handle), stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(reinterpret_cast<hipStream_t>(dst_stream_host_handle), reinterpret_cast<hipEvent_t>(event_host_handle), 0);
     if (e != hipSuccess) { osp_set_error("osp_stream_handover: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// ---- plumbing entry points of the call tapes (optispeech_amd/tape.py): a recorded region of the step may contain nothing but
+// C-ABI calls, so the fills and copies torch would launch in between have their own entry points.
+extern "C" int osp_memset(void* dst, int64_t value, int64_t nbytes, hipStream_t stream) {
+    if (!dst || nbytes < 0) { osp_set_error("osp_memset: bad args"); return -1; }
+    if (nbytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(dst, (int)(value & 0xff), (size_t)nbytes, stream);
+    if (e != hipSuccess) { osp_set_error("osp_memset: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+extern "C" int osp_copy(void* dst, const void* src, int64_t nbytes, hipStream_t stream) {
+    if (!dst || !src || nbytes < 0) { osp_set_error("osp_copy: bad args"); return -1; }
+    if (nbytes == 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) { osp_set_error("osp_copy: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+// Test aid of the tape machinery: adds `add` into *counter ON THE HOST, synchronously (no device work, no GPU needed) -- lets the
+// CPU test suite record, patch and replay tapes.  `counter` is a host address in this one entry point.
+extern "C" int osp_tape_selftest(int64_t* counter, int64_t add, hipStream_t stream) {
+    if (!counter) { osp_set_error("osp_tape_selftest: null counter"); return -1; }
+    *counter += add + (int64_t)(intptr_t)stream;
+    return 0;
+}
+// Second test aid: vals_host[i] are HOST addresses of int64 values; their sum is added into *counter (host).  Exercises the tape's
+// copy of a host descriptor table and the patching of addresses inside it.
+extern "C" int osp_tape_selftest_table(const int64_t* vals_host, int64_t count, int64_t* counter, hipStream_t stream) {
+    if (!vals_host || !counter || count < 0) { osp_set_error("osp_tape_selftest_table: bad args"); return -1; }
+    int64_t acc = 0;
+    for (int64_t i = 0; i < count; ++i) acc += *reinterpret_cast<const int64_t*>(static_cast<intptr_t>(vals_host[i]));
+    *counter += acc;
     return 0;
 }

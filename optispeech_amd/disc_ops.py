@@ -9,6 +9,15 @@ the epilogue, activations kept in bf16.  The whole stack is ONE autograd Functio
 import torch
 
 from . import kernels as K
+from . import tape as _tape
+
+
+def _stack_tapes(v0):
+    """The call-tape cache of one sub-discriminator stack, kept on its first weight_v Parameter (dies with the module)."""
+    d = getattr(v0, "_osp_tapes", None)
+    if d is None:
+        d = v0._osp_tapes = {}
+    return d
 
 
 def _tout(tin, taps, stride, pad):
@@ -115,13 +124,13 @@ def transpose_weight2d(w):
     return t if t.dtype == torch.bfloat16 else K.cast_bf16(t)
 
 
-def conv2d_dgrad(dy, wt, H, W, KH, KW, sh, sw, ph, pw, *, lrelu_y=None, extra=None, slope=0.1, out_bf16=False):
+def conv2d_dgrad(dy, wt, H, W, KH, KW, sh, sw, ph, pw, *, lrelu_y=None, extra=None, slope=0.1, out_bf16=False, out=None):
     """dx (U,H,W,Cin) of a strided conv2d.  Each output phase (h % sh, w % sw) only sees a sub-sampled kernel; all phases
     run in ONE launch (osp_conv2d_dgrad_bf16, csrc/gemm_bf16.hip), with the LeakyReLU backward of the previous layer and
-    its feature-matching gradient (``extra``) fused into the epilogue."""
+    its feature-matching gradient (``extra``) fused into the epilogue.  ``out``: contiguous destination (U,H,W,Cin) or None."""
     U, Ho, Wo, Cout = dy.shape
     Cin = wt.shape[0]
-    dx = torch.empty((U, H, W, Cin), device=dy.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dx = out if out is not None else torch.empty((U, H, W, Cin), device=dy.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     isbf = lambda t: int(t is not None and t.dtype == torch.bfloat16)                 # noqa: E731
     K.call("osp_conv2d_dgrad_bf16", dy, isbf(dy), wt, isbf(wt), dx, isbf(dx), U, H, W, Ho, Wo, Cin, Cout, KH, KW, sh, sw, ph, pw,
            K.EPI_LRELU_BWD if lrelu_y is not None else K.EPI_NONE, lrelu_y, isbf(lrelu_y), extra, isbf(extra), float(slope))
@@ -153,7 +162,7 @@ def wnorm_packed(v, g, want_f32, want_t):
         return hit[1]
     if hit is not None and hit[0] == stamp:                       # same weights, more outputs wanted: keep the union
         want_f32, want_t = want_f32 or hit[1][1] is not None, want_t or hit[1][2] is not None
-    pack = K.wnorm_fwd(v.detach(), g.detach(), want_f32=want_f32, want_t=want_t)
+    pack = K.wnorm_fwd_multi([(v.detach(), g.detach(), want_f32, want_t)], reuse=[hit[1] if hit is not None else None])[0]
     v._osp_wn_pack = (stamp, pack)
     return pack
 
@@ -174,11 +183,13 @@ def wnorm_pack_many(convs, want_f32):
         hit = getattr(v, "_osp_wn_pack", None)
         if hit is not None and hit[0] == stamp and (hit[1][1] is not None or not f32) and hit[1][2] is not None:
             continue
-        todo.append((v, g, f32, stamp))
+        todo.append((v, g, f32, stamp, hit[1] if hit is not None else None))
     if not todo:
         return False
-    packs = K.wnorm_fwd_multi([(v.detach(), g.detach(), f32, True) for v, g, f32, _ in todo])
-    for (v, g, f32, stamp), pack in zip(todo, packs):
+    # the buffers of a stale pack are REWRITTEN (same addresses over the epochs: the stacks' call tapes hold them); ordering: this
+    # launch is queued after everything that read the old contents (the caller joins the discriminator streams first)
+    packs = K.wnorm_fwd_multi([(v.detach(), g.detach(), f32, True) for v, g, f32, _, _ in todo], reuse=[t[4] for t in todo])
+    for (v, g, f32, stamp, _), pack in zip(todo, packs):
         v._osp_wn_pack = (stamp, pack)
     return True
 
@@ -213,24 +224,39 @@ class ConvStackFn(torch.autograd.Function):
         need_w = [bool(ctx.needs_input_grad[3 + 3 * i]) for i in range(6)]
         need_x = bool(ctx.needs_input_grad[0])
         packs = []
-        acts, h = [], x.contiguous()
+        x = x.contiguous()
         for i in range(6):
             KH, KW, sh, sw, ph, pw = spec[i]
             cout, cin = vs[i].shape[0], vs[i].shape[1]
             small = (cin == 1 and cout in (16, 32, 64) and KH * KW <= cout)
             # the transposed (dgrad) pack is always produced: the no-grad real pass of the generator phase comes first
             # and would otherwise force a second osp_wnorm_fwd for the generated pass
-            wn, wn32, wt, inv = wnorm_packed(vs[i], gs[i], small, True)
-            packs.append((wn, wn32, wt, inv))
-            lr = slope if i < 5 else None
-            if small:
-                U, H, W = h.shape[0], h.shape[1], h.shape[2]
-                Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
-                h = K.smallcin_fwd(h, wn32.view(cout, -1), bs[i].detach(), U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo, cout=cout, KH=KH,
-                                   KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=lr, out_bf16=i < 5).view(U, Ho, Wo, cout)
-            else:
-                h = conv2d_fwd(h, wn, bs[i].detach(), KH, KW, sh, sw, ph, pw, lr, i < 5)
-            acts.append(h)
+            packs.append(wnorm_packed(vs[i], gs[i], small, True))
+        biases = [b.detach() for b in bs]
+
+        def layers(xin):
+            """The stack's six launches: a pure kernel sequence (recorded once per shape as a call tape, optispeech_amd/tape.py)."""
+            out, h = [], xin
+            for i in range(6):
+                KH, KW, sh, sw, ph, pw = spec[i]
+                cout, cin = vs[i].shape[0], vs[i].shape[1]
+                wn, wn32, wt, inv = packs[i]
+                lr = slope if i < 5 else None
+                if wn32 is not None and cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
+                    U, H, W = h.shape[0], h.shape[1], h.shape[2]
+                    Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+                    h = K.smallcin_fwd(h, wn32.view(cout, -1), biases[i], U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo, cout=cout, KH=KH,
+                                       KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=lr, out_bf16=i < 5).view(U, Ho, Wo, cout)
+                else:
+                    h = conv2d_fwd(h, wn, biases[i], KH, KW, sh, sw, ph, pw, lr, i < 5)
+                out.append(h)
+            return tuple(out)
+
+        # (the generator-phase and the discriminator-phase pass of a step see the same shapes: ``any(need_w)`` keeps their
+        # activation buffers apart, as the eager allocations were)
+        key = ("fwd", tuple(x.shape), spec, float(slope), any(need_w), tuple(t.data_ptr() for pk in packs for t in pk if t is not None),
+               tuple(b.data_ptr() for b in biases))
+        acts = list(_tape.run(_stack_tapes(vs[0]), key, [x], layers, "disc stack forward"))
         if need_x or any(need_w):
             ctx.save_for_backward(x[u0:], *[a[u0:] for a in acts[:5]],
                                   *[t for pk in packs for t in (pk[0], pk[2], pk[3]) if t is not None])
@@ -262,68 +288,92 @@ class ConvStackFn(torch.autograd.Function):
             for flag in has:
                 item.append(rest.pop(0) if flag else None)
             packs.append(item)                                  # (wn, wt, inv)
-        g = _stack_backward(x, acts, packs, ctx.params, spec, slope, need_x, need_w, (d1, d2, d3, d4, d5), ds)
-        if need_x and ctx.u0:                                    # gradient of the whole input: zeros for the no-grad head
-            # the head rows belong to the real waves, which carry no gradient: whatever stands there is narrowed away by the
-            # backward of the torch.cat that built the batch (per-sample ops only in between), so they are not zero-filled
-            # (zeros, not empty: one memset keeps NaN/Inf of uninitialised memory away from anything that might reduce
-            # over the batch dimension later)
-            full = torch.zeros((ctx.U,) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
-            full[ctx.u0:] = g
-            g = full
+        # the gradient of the WHOLE input (need_x with a no-grad head): the head rows belong to the real waves, which carry no
+        # gradient -- zeros there (one memset keeps NaN / Inf of uninitialised memory away from anything that might reduce over
+        # the batch dimension later); the last dgrad launch writes the rest in place
+        g = _stack_backward(x, acts, packs, ctx.params, spec, slope, need_x, need_w, (d1, d2, d3, d4, d5), ds,
+                            full_rows=ctx.U if (need_x and ctx.u0) else 0)
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)
 
 
-def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds):
+def _stack_backward(x, acts, packs, params, spec, slope, need_x, need_w, dfm, ds, full_rows=0):
     """Backward of a conv stack over (x, activations y1..y5): weight gradients into the arena (gsink), returns d x or None.
-    ``dfm`` = gradients w.r.t. the feature maps y1..y5 (or None), ``ds`` = gradient w.r.t. the score map."""
+    ``dfm`` = gradients w.r.t. the feature maps y1..y5 (or None), ``ds`` = gradient w.r.t. the score map.  ``full_rows`` > 0: d x is
+    returned for that many rows, the leading ``full_rows - x.shape[0]`` of them (a no-grad head of the forward) zero.
+
+    The launches themselves are a pure kernel sequence (``launches`` below): recorded once per shape as a call tape and replayed
+    (optispeech_amd/tape.py); what is not a launch -- the data-parallel ready signal, the stream join -- stays here."""
     from .ops import gsink
     vs, gs, bs = params[0::3], params[1::3], params[2::3]
-    extras = [d.contiguous() if d is not None else None for d in dfm]
-    if ds is None:
-        ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
-    g = ds.contiguous()
-    # one zero-filled buffer for the native-layout weight gradients of all layers (one fill instead of six)
     sizes = [vs[i].numel() if need_w[i] else 0 for i in range(6)]
-    flat = torch.zeros((sum(sizes),), device=g.device, dtype=torch.float32) if sum(sizes) else None
     offs = [sum(sizes[:i]) for i in range(6)]
-    wn_items = []                                             # (dW native f32, v, g, 1/||v||, dv, dg) of every layer: ONE launch
-    for i in range(5, -1, -1):
-        inp = acts[i - 1] if i > 0 else x
-        KH, KW, sh, sw, ph, pw = spec[i]
-        wn, wt, inv = packs[i]
-        cout, cin = vs[i].shape[0], vs[i].shape[1]
-        if need_w[i]:
-            dw = flat[offs[i]:offs[i] + sizes[i]].view(cout, KH, KW, cin)
-            db = gsink(bs[i])
-            if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
-                K.smallcin_wgrad(inp, g, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
-                                 Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+    sinks = [(gsink(vs[i]), gsink(gs[i]), gsink(bs[i])) if need_w[i] else None for i in range(6)]
+    n_in = 6
+    ins = [x] + list(acts) + [None if ds is None else ds.contiguous()] + [d.contiguous() if d is not None else None for d in dfm]
+    for k, t in enumerate(ins):                                  # (the tape patches f32 / bf16 buffers by address: dtype is part of the key)
+        if t is not None and k >= n_in and t.dtype not in (torch.float32, torch.bfloat16):
+            ins[k] = t.float()
+
+    def launches(x, a1, a2, a3, a4, a5, ds, e1, e2, e3, e4, e5):
+        acts, extras = (a1, a2, a3, a4, a5), (e1, e2, e3, e4, e5)
+        if ds is None:
+            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
+        g = ds
+        # one zero-filled buffer for the native-layout weight gradients of all layers (one fill instead of six)
+        flat = torch.zeros((sum(sizes),), device=g.device, dtype=torch.float32) if sum(sizes) else None
+        wn_items = []                                             # (dW native f32, v, g, 1/||v||, dv, dg) of every layer: ONE launch
+        for i in range(5, -1, -1):
+            inp = acts[i - 1] if i > 0 else x
+            KH, KW, sh, sw, ph, pw = spec[i]
+            wn, wt, inv = packs[i]
+            cout, cin = vs[i].shape[0], vs[i].shape[1]
+            if need_w[i]:
+                dw = flat[offs[i]:offs[i] + sizes[i]].view(cout, KH, KW, cin)
+                dv, dg, db = sinks[i]
+                if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
+                    K.smallcin_wgrad(inp, g, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=g.shape[1],
+                                     Wo=g.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
+                else:
+                    U, Ho, Wo = g.shape[0], g.shape[1], g.shape[2]
+                    H, W = inp.shape[1], inp.shape[2]
+                    K.conv2d_wgrad_bf16(g.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
+                                        Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
+                                        pad_w=pw, step_h=sh, step_w=sw)
+                wn_items.append((dw, vs[i].detach(), gs[i].detach(), inv, dv, dg))
+            if i > 0 and (need_x or any(need_w[:i])):
+                g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp, extra=extras[i - 1],
+                                 slope=slope, out_bf16=True)
+            elif i == 0 and need_x:
+                out = None
+                if full_rows:
+                    full = torch.empty((full_rows,) + tuple(inp.shape[1:]), device=g.device, dtype=torch.float32)
+                    head = full_rows - inp.shape[0]
+                    K.call("osp_memset", full, 0, head * inp[0].numel() * 4)
+                    out = full[head:]
+                g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, out_bf16=False, out=out)
+                if full_rows:
+                    g = full
             else:
-                U, Ho, Wo = g.shape[0], g.shape[1], g.shape[2]
-                H, W = inp.shape[1], inp.shape[2]
-                K.conv2d_wgrad_bf16(g.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
-                                    Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
-                                    pad_w=pw, step_h=sh, step_w=sw)
-            wn_items.append((dw, vs[i].detach(), gs[i].detach(), inv, gsink(vs[i]), gsink(gs[i])))
-        if i > 0 and (need_x or any(need_w[:i])):
-            g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp, extra=extras[i - 1],
-                             slope=slope, out_bf16=True)
-        elif i == 0 and need_x:
-            g = conv2d_dgrad(g, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, out_bf16=False)
-        else:
-            g = None
-            break
-    if wn_items:
-        K.wnorm_bwd_multi(wn_items)
+                g = None
+                break
+        if wn_items:
+            K.wnorm_bwd_multi(wn_items)
+        return g
+
+    key = ("bwd", tuple(x.shape), spec, float(slope), need_x, tuple(need_w), full_rows,
+           tuple(None if t is None else (tuple(t.shape), t.dtype) for t in ins[n_in:]),
+           tuple(t.data_ptr() for pk in packs for t in pk if t is not None),
+           tuple(t.data_ptr() for sk in sinks if sk is not None for t in sk))
+    g = _tape.run(_stack_tapes(vs[0]), key, ins, launches, "disc stack backward")
+    if any(need_w):
         if all(need_w):
             from .dp import reduce_ready
-            reduce_ready(list(params))                       # data parallel: this stack's gradient slice is complete -> all-reduce it now
-    if any(need_w) and g_stream_is_side():
-        # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
-        # engine does not know that the stream backward() was called from must wait for this node's stream: say so.
-        side = torch.cuda.current_stream()
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
+            reduce_ready(list(params))                           # data parallel: this stack's gradient slice is complete -> all-reduce it now
+        if g_stream_is_side():
+            # Parameter gradients are written straight into the gradient arena (no AccumulateGrad node), so the autograd
+            # engine does not know that the stream backward() was called from must wait for this node's stream: say so.
+            side = torch.cuda.current_stream()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
     return g
 
 

@@ -136,7 +136,7 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
     for rk2 in dead:
         del _PACK_REG[rk2]
     d = np.asarray(rows, dtype=np.int64)
-    call("osp_pack_bf16_multi", d.ctypes.data, len(rows))
+    call("osp_pack_bf16_multi", d, len(rows))
     for dct, k2, out in fills:
         dct[k2] = out
     return p._osp_packs[1][key]
@@ -441,7 +441,7 @@ def drop_path_rows(drop_p, rowmask, B, T, seed, stream_id, device):
         _f32(rowmask)
     hs, ds = _seed(seed)
     p = _host_f32(drop_p)
-    call("osp_drop_path_rows", p.ctypes.data, rowmask, L, B, T, hs, ds, int(stream_id), scale, rowf)
+    call("osp_drop_path_rows", p, rowmask, L, B, T, hs, ds, int(stream_id), scale, rowf)
     return scale, rowf
 
 
@@ -570,7 +570,7 @@ def l1_sum_multi(targets, ys, out):
     a, b = _host_i64([t.data_ptr() for t in targets]), _host_i64([t.data_ptr() for t in ys])
     n, sc = _host_i64([t.numel() for t in ys]), _host_f32([1.0 / t.numel() for t in ys])
     bf = _host_i64([_isbf(t) for t in ys])
-    call("osp_l1_sum_multi", a.ctypes.data, b.ctypes.data, n.ctypes.data, sc.ctypes.data, bf.ctypes.data, len(ys), out)
+    call("osp_l1_sum_multi", a, b, n, sc, bf, len(ys), out)
 
 
 def l1_sign_multi(targets, ys, gscale):
@@ -580,21 +580,21 @@ def l1_sign_multi(targets, ys, gscale):
     o, n = _host_i64([t.data_ptr() for t in gbs]), _host_i64([t.numel() for t in ys])
     sc = _host_f32([1.0 / t.numel() for t in ys])
     bf = _host_i64([_isbf(t) for t in ys])
-    call("osp_l1_sign_multi", a.ctypes.data, b.ctypes.data, o.ctypes.data, n.ctypes.data, sc.ctypes.data, bf.ctypes.data, len(ys), gscale)
+    call("osp_l1_sign_multi", a, b, o, n, sc, bf, len(ys), gscale)
     return gbs
 
 
 def hinge_sum_multi(xs, sgns, out):
     x, n = _host_i64([t.data_ptr() for t in xs]), _host_i64([t.numel() for t in xs])
     sg, sc = _host_f32(sgns), _host_f32([1.0 / t.numel() for t in xs])
-    call("osp_hinge_sum_multi", x.ctypes.data, n.ctypes.data, sg.ctypes.data, sc.ctypes.data, len(xs), out)
+    call("osp_hinge_sum_multi", x, n, sg, sc, len(xs), out)
 
 
 def hinge_grad_multi(xs, sgns, gscale):
     dxs = [torch.empty_like(t) for t in xs]
     x, o = _host_i64([t.data_ptr() for t in xs]), _host_i64([t.data_ptr() for t in dxs])
     n, sg, sc = _host_i64([t.numel() for t in xs]), _host_f32(sgns), _host_f32([1.0 / t.numel() for t in xs])
-    call("osp_hinge_grad_multi", x.ctypes.data, o.ctypes.data, n.ctypes.data, sg.ctypes.data, sc.ctypes.data, len(xs), gscale)
+    call("osp_hinge_grad_multi", x, o, n, sg, sc, len(xs), gscale)
     return dxs
 
 
@@ -604,20 +604,26 @@ def _wn_desc(rows):
     return np.asarray([[ptr(r[k]) for k in range(9)] + list(r[9:13]) for r in rows], dtype=np.int64)
 
 
-def wnorm_fwd_multi(items):
-    """items: [(v, g, want_f32, want_t)] -> [(wn, wn32, wt, inv)]: the weight-norm packs of many convs in one launch per 32."""
+def wnorm_fwd_multi(items, reuse=None):
+    """items: [(v, g, want_f32, want_t)] -> [(wn, wn32, wt, inv)]: the weight-norm packs of many convs in one launch per 32.
+    ``reuse``: per item the previous pack tuple (or None) -- its buffers are written in place when they have what is wanted, so a
+    conv's packs keep their addresses over the optimizer epochs (the call tapes of the stacks hold those addresses)."""
     outs, rows = [], []
-    for v, g, want_f32, want_t in items:
+    for k, (v, g, want_f32, want_t) in enumerate(items):
         Cout, Cin, P, Q = v.shape
         dev = v.device
-        wn = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.bfloat16)
-        wn32 = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.float32) if want_f32 else None
-        wt = torch.empty((Cin, Q, P, Cout), device=dev, dtype=torch.bfloat16) if want_t else None
-        inv = torch.empty((Cout,), device=dev, dtype=torch.float32)
+        old = reuse[k] if reuse is not None else None
+        if old is not None and old[0] is not None and old[0].device == dev and (old[1] is not None or not want_f32) and (old[2] is not None or not want_t):
+            wn, wn32, wt, inv = old
+        else:
+            wn = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.bfloat16)
+            wn32 = torch.empty((Cout, Q, P, Cin), device=dev, dtype=torch.float32) if want_f32 else None
+            wt = torch.empty((Cin, Q, P, Cout), device=dev, dtype=torch.bfloat16) if want_t else None
+            inv = torch.empty((Cout,), device=dev, dtype=torch.float32)
         outs.append((wn, wn32, wt, inv))
         rows.append((v, g, wn, wn32, wt, inv, None, None, None, Cout, Cin, P, Q))
     d = _wn_desc(rows)
-    call("osp_wnorm_fwd_multi", d.ctypes.data, len(rows))
+    call("osp_wnorm_fwd_multi", d, len(rows))
     return outs
 
 
@@ -628,7 +634,7 @@ def wnorm_bwd_multi(items):
         Cout, Cin, P, Q = v.shape
         rows.append((v, g, None, None, None, inv, dwn, dv, dg, Cout, Cin, P, Q))
     d = _wn_desc(rows)
-    call("osp_wnorm_bwd_multi", d.ctypes.data, len(rows))
+    call("osp_wnorm_bwd_multi", d, len(rows))
 
 
 def param_bf16(p, transposed=False):
@@ -674,7 +680,7 @@ def param_bf16_many(requests):
     if not rows:
         return
     d = np.asarray(rows, dtype=np.int64)
-    call("osp_pack_bf16_multi", d.ctypes.data, len(rows))
+    call("osp_pack_bf16_multi", d, len(rows))
     for dct, key, out in fills:
         dct[key] = out
 

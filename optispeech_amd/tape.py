@@ -1,0 +1,374 @@
+"""Call tapes: a region of the training step recorded ONCE as a list of C-ABI calls and replayed from one C loop.
+
+Why: the eager step needs 15-18 ms of host time to enqueue ~820 launches -- Python wrappers,
+``torch.empty``, autograd bookkeeping, argument marshalling -- for ~17 ms of GPU time; hipGraph replay removes the host time but the
+ROCm 7.2 runtime executes a captured multi-stream graph almost serially.  A tape keeps the eager schedule --
+the same entry points, on the same streams, in the same order -- and removes the interpreter: ``_ospfast.tape_replay`` walks the
+recorded calls in C (~1 us per call plus the launch itself).
+
+What a region is: a Python callable that, given its input tensors, issues C-ABI calls (``_lib.call``), allocates with ``torch.empty``
+and takes views -- nothing else.  While it is recorded
+
+  * every C-ABI call is executed AND appended to the tape (entry index, marshalled arguments, stream);
+  * pointers INTO the region's inputs are stored relative to the input and patched with the inputs' addresses at replay: inputs may
+    live anywhere on the next step; every other tensor the calls saw is kept alive by the tape, so buffers allocated inside the region
+    are persistent and weights / packs / gradient-arena slots keep their addresses by construction;
+  * ATen operators are intercepted (``TorchDispatchMode``): allocation and view operators pass, the handful of element-wise / copy
+    operators autograd and the host code still use are RE-ROUTED to entry points of csrc/ew.hip (so they land on the tape), anything
+    else POISONS the recording -- the region then simply stays eager (and says so once): a kernel the tape does not know about can
+    never be dropped silently.
+
+Per-step scalars: dropout seeds live in device memory while tapes are in use (``rng.use_device_seed``; one ``osp_store_i64`` per step).
+
+A replay returns fresh aliases of the region's persistent output buffers.  They are overwritten by the next replay of the same
+region: callers are the autograd Functions of this package, which consume them within the step.
+"""
+import os
+import warnings
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from . import _lib
+
+ENABLED = os.environ.get("OSP_TAPES", "1") != "0"
+EAGER = object()                    # cache marker: this key could not be recorded, run the region eagerly
+_STATS = {"recorded": 0, "replayed": 0, "poisoned": 0, "calls_replayed": 0}
+_WARNED = set()
+
+
+def fast():
+    """The ``_ospfast`` module (None when it is not built: tapes are then unavailable and every region runs eagerly)."""
+    return _lib.lib()._fast
+
+
+def available():
+    return ENABLED and fast() is not None and hasattr(fast(), "tape_begin")
+
+
+def recording():
+    f = fast()
+    return f is not None and hasattr(f, "tape_recording") and f.tape_recording()
+
+
+def stats():
+    return dict(_STATS)
+
+
+# ---------------------------------------------------------------------------------------------------- ATen interception
+#: operators that launch nothing: allocation, views, metadata
+_NO_KERNEL = {
+    "aten::empty", "aten::empty_like", "aten::empty_strided", "aten::new_empty", "aten::new_empty_strided", "aten::view",
+    "aten::_unsafe_view", "aten::reshape", "aten::_reshape_alias", "aten::as_strided", "aten::slice", "aten::select", "aten::narrow",
+    "aten::transpose", "aten::permute", "aten::t", "aten::unsqueeze", "aten::squeeze", "aten::expand", "aten::detach", "aten::alias",
+    "aten::unbind", "aten::split", "aten::split_with_sizes", "aten::chunk", "aten::view_as", "aten::record_stream", "aten::lift_fresh",
+    "aten::is_same_size", "aten::sym_size", "aten::sym_stride", "aten::sym_numel", "aten::sym_storage_offset", "aten::size",
+    "aten::stride", "aten::numel", "aten::dim", "aten::is_contiguous", "aten::is_pinned", "aten::expand_as", "aten::unflatten",
+    "aten::flatten", "aten::movedim", "aten::swapaxes", "aten::_unsafe_index", "aten::is_nonzero_placeholder",
+}
+
+
+def _plain(t):
+    return isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+
+
+def _r_zeros(func, args, kwargs):
+    """zeros / zeros_like / new_zeros / zero_ / fill_(0): hipMemsetAsync through the C ABI."""
+    name = func._schema.name
+    if name == "aten::zero_" or (name == "aten::fill_" and not isinstance(args[1], torch.Tensor) and float(args[1]) == 0.0):
+        t = args[0]
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+            return NotImplemented
+        _lib.call("osp_memset", t, 0, t.numel() * t.element_size())
+        return t
+    kw = dict(kwargs or {})
+    if name == "aten::zeros":
+        out = torch.empty(args[0], **kw)
+    elif name == "aten::zeros_like":
+        kw.pop("memory_format", None)
+        out = torch.empty_like(args[0], **kw, memory_format=torch.contiguous_format)
+    elif name == "aten::new_zeros":
+        out = args[0].new_empty(args[1], **kw)
+    else:
+        return NotImplemented
+    if not out.is_cuda:
+        return func(*args, **(kwargs or {}))
+    if out.numel():
+        _lib.call("osp_memset", out, 0, out.numel() * out.element_size())
+    return out
+
+
+def _bcast_mode(x, y):
+    """osp_ew_mul mode of y against x (contiguous f32): 0 same shape, 1 one value per row, 2 one value per column; None otherwise."""
+    if tuple(x.shape) == tuple(y.shape):
+        return 0, 1
+    if y.dim() <= x.dim() and x.dim() >= 1:
+        ys = (1,) * (x.dim() - y.dim()) + tuple(y.shape)
+        inner = x.shape[-1]
+        if ys[-1] == 1 and tuple(ys[:-1]) == tuple(x.shape[:-1]):
+            return 1, inner
+        if ys[-1] == inner and all(v == 1 for v in ys[:-1]):
+            return 2, inner
+    return None, None
+
+
+def _r_addsub(func, args, kwargs):
+    name = func._schema.name
+    a, b = args[0], args[1]
+    alpha = float((kwargs or {}).get("alpha", 1.0))
+    if name.startswith("aten::sub"):
+        alpha = -alpha
+    inplace = name.endswith("_")
+    if isinstance(b, torch.Tensor) and _plain(a) and _plain(b) and tuple(a.shape) == tuple(b.shape):
+        out = a if inplace else torch.empty_like(a)
+        _lib.call("osp_ew_axpby", a, b, out, a.numel(), 1.0, alpha)
+        return out
+    if _plain(a) and not isinstance(b, torch.Tensor):
+        out = a if inplace else torch.empty_like(a)
+        _lib.call("osp_ew_axpby", a, None, out, a.numel(), 1.0, alpha * float(b))
+        return out
+    return NotImplemented
+
+
+def _r_mul(func, args, kwargs):
+    name = func._schema.name
+    a, b = args[0], args[1]
+    inplace = name.endswith("_")
+    if isinstance(a, torch.Tensor) and not isinstance(b, torch.Tensor) and _plain(a):
+        out = a if inplace else torch.empty_like(a)
+        _lib.call("osp_ew_axpby", a, None, out, a.numel(), float(b), 0.0)
+        return out
+    if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)):
+        return NotImplemented
+    if a.numel() < b.numel() and not inplace:
+        a, b = b, a
+    if _plain(a) and b.is_cuda and b.dtype == torch.float32 and b.numel() == 1:           # times a device scalar
+        out = a if inplace else torch.empty_like(a)
+        _lib.call("osp_ew_scale_dev", a, b, out, a.numel(), 1.0)
+        return out
+    if _plain(a) and _plain(b):
+        mode, inner = _bcast_mode(a, b)
+        if mode is not None:
+            out = a if inplace else torch.empty_like(a)
+            _lib.call("osp_ew_mul", a, b, out, a.numel(), inner, mode)
+            return out
+    return NotImplemented
+
+
+def _r_neg(func, args, kwargs):
+    a = args[0]
+    if _plain(a):
+        out = torch.empty_like(a)
+        _lib.call("osp_ew_axpby", a, None, out, a.numel(), -1.0, 0.0)
+        return out
+    return NotImplemented
+
+
+def _r_div(func, args, kwargs):
+    a, b = args[0], args[1]
+    if _plain(a) and not isinstance(b, torch.Tensor):
+        out = torch.empty_like(a)
+        _lib.call("osp_ew_axpby", a, None, out, a.numel(), 1.0 / float(b), 0.0)
+        return out
+    return NotImplemented
+
+
+def _r_clone(func, args, kwargs):
+    a = args[0]
+    if isinstance(a, torch.Tensor) and a.is_cuda and a.is_contiguous():
+        out = torch.empty_like(a)
+        if a.numel():
+            _lib.call("osp_copy", out, a, a.numel() * a.element_size())
+        return out
+    return NotImplemented
+
+
+def _r_copy_(func, args, kwargs):
+    dst, src = args[0], args[1]
+    if (isinstance(src, torch.Tensor) and dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.is_contiguous()
+            and src.is_contiguous() and tuple(dst.shape) == tuple(src.shape)):
+        if dst.numel():
+            _lib.call("osp_copy", dst, src, dst.numel() * dst.element_size())
+        return dst
+    return NotImplemented
+
+
+def _r_cat(func, args, kwargs):
+    ts = list(args[0])
+    dim = args[1] if len(args) > 1 else (kwargs or {}).get("dim", 0)
+    if not ts or dim != 0 or not all(isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == ts[0].dtype
+                                       and tuple(t.shape[1:]) == tuple(ts[0].shape[1:]) for t in ts):
+        return NotImplemented
+    out = torch.empty((sum(t.shape[0] for t in ts),) + tuple(ts[0].shape[1:]), device=ts[0].device, dtype=ts[0].dtype)
+    row = 0
+    for t in ts:
+        if t.numel():
+            _lib.call("osp_copy", out[row:], t, t.numel() * t.element_size())
+        row += t.shape[0]
+    return out
+
+
+def _r_sum_mean(func, args, kwargs):
+    """full reductions of small f32 tensors to a scalar (the per-utterance loss means)."""
+    a = args[0]
+    if len(args) > 1 or (kwargs and any(v is not None for v in kwargs.values())):
+        return NotImplemented
+    if _plain(a) and 0 < a.numel() <= (1 << 20):
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        scale = 1.0 / a.numel() if func._schema.name == "aten::mean" else 1.0
+        _lib.call("osp_sum_scaled", a, a.numel(), scale, out)
+        return out
+    return NotImplemented
+
+
+_REROUTE = {
+    "aten::zeros": _r_zeros, "aten::zeros_like": _r_zeros, "aten::new_zeros": _r_zeros, "aten::zero_": _r_zeros, "aten::fill_": _r_zeros,
+    "aten::add": _r_addsub, "aten::add_": _r_addsub, "aten::sub": _r_addsub, "aten::sub_": _r_addsub,
+    "aten::mul": _r_mul, "aten::mul_": _r_mul, "aten::neg": _r_neg, "aten::div": _r_div,
+    "aten::clone": _r_clone, "aten::copy_": _r_copy_, "aten::cat": _r_cat, "aten::sum": _r_sum_mean, "aten::mean": _r_sum_mean,
+}
+
+
+def _touches_gpu(args, kwargs):
+    for a in list(args) + list((kwargs or {}).values()):
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return True
+        elif isinstance(a, (list, tuple)):
+            if any(isinstance(t, torch.Tensor) and t.is_cuda for t in a):
+                return True
+    return False
+
+
+class _AtenGuard(TorchDispatchMode):
+    """Active while a region is recorded (see the module docstring)."""
+
+    def __init__(self, rec):
+        super().__init__()
+        self.rec = rec
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func._schema.name
+        if name in _NO_KERNEL:
+            return func(*args, **(kwargs or {}))
+        dev = (kwargs or {}).get("device")
+        on_gpu = _touches_gpu(args, kwargs) or (dev is not None and torch.device(dev).type == "cuda")
+        if not on_gpu:
+            return func(*args, **(kwargs or {}))                 # host-side arithmetic launches nothing
+        impl = _REROUTE.get(name)
+        if impl is not None and not self.rec.poisoned:
+            self.rec.rerouted += 1
+            out = impl(func, args, kwargs)
+            if out is not NotImplemented:
+                return out
+            self.rec.rerouted -= 1
+        self.rec.poison(f"ATen operator {func} launched a kernel inside the region")
+        return func(*args, **(kwargs or {}))
+
+
+# ---------------------------------------------------------------------------------------------------- recording / replay
+def _extent(t):
+    return t.numel() * t.element_size()
+
+
+class Region:
+    """A recorded region: replay(inputs) -> the region's outputs (fresh aliases of persistent buffers)."""
+    __slots__ = ("cap", "outs", "n_inputs", "ncalls", "meta", "extra")
+
+    def __init__(self, cap, outs, n_inputs, ncalls, meta):
+        self.cap, self.outs, self.n_inputs, self.ncalls, self.meta = cap, outs, n_inputs, ncalls, meta
+        self.extra = None
+
+    def replay(self, inputs):
+        bases = [0 if t is None else t.data_ptr() for t in inputs]
+        rc = fast().tape_replay(self.cap, bases, _lib._STREAM_OVERRIDE[0] or _lib._raw_stream(_lib._cur_device()))
+        if rc != 0:
+            raise _lib.OspError(f"tape replay: {rc[1]} failed ({rc[0]}): {_lib.lib().cdll.osp_last_error().decode()}")
+        _STATS["replayed"] += 1
+        _STATS["calls_replayed"] += self.ncalls
+        return _alias(self.outs)
+
+
+def _alias(outs):
+    if outs is None:
+        return None
+    if isinstance(outs, torch.Tensor):
+        return outs.detach()
+    return tuple(_alias(o) for o in outs)
+
+
+class Recorder:
+    """``with Recorder(inputs) as rec: outs = fn(*inputs)`` then ``rec.finish(outs)`` -> Region, or None when the recording was
+    poisoned (the execution itself was complete and valid either way: a recording run IS a normal run)."""
+
+    def __init__(self, inputs, label=""):
+        self.inputs = list(inputs)
+        self.label = label
+        self.poisoned = None
+        self.rerouted = 0
+        self.cap = None
+        self._guard = None
+
+    def poison(self, why):
+        if self.poisoned is None:
+            self.poisoned = why
+
+    def __enter__(self):
+        f = fast()
+        for t in self.inputs:
+            if t is not None and not (t.is_cuda and t.is_contiguous()):
+                self.poison("a region input is not a contiguous device tensor")
+        bases = [0 if t is None else t.data_ptr() for t in self.inputs]
+        sizes = [0 if t is None else _extent(t) for t in self.inputs]
+        f.tape_begin(bases, sizes, _lib._STREAM_OVERRIDE[0] or _lib._raw_stream(_lib._cur_device()))
+        for t in self.inputs:                                    # inputs stay alive only through the caller; nothing to keep
+            pass
+        self._guard = _AtenGuard(self)
+        self._guard.__enter__()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        f = fast()
+        self._guard.__exit__(et, ev, tb)
+        if et is not None:
+            f.tape_abort()
+            return False
+        self.cap = f.tape_end()
+        return False
+
+    def finish(self, outs):
+        if self.cap is None:
+            return None
+        if self.poisoned is not None:
+            _STATS["poisoned"] += 1
+            key = (self.label, self.poisoned)
+            if key not in _WARNED:
+                _WARNED.add(key)
+                warnings.warn(f"optispeech_amd.tape: region {self.label!r} stays eager: {self.poisoned}")
+            self.cap = None
+            return None
+        ncalls, npatches, names, streams = fast().tape_info(self.cap)
+        _STATS["recorded"] += 1
+        # aliases taken NOW (inside the caller's Function.forward the outputs carry no autograd history yet): the objects handed to
+        # the caller get a grad_fn later, and holding those would pin the first step's graph
+        return Region(self.cap, _alias(outs), len(self.inputs), ncalls,
+                      {"patches": npatches, "rerouted": self.rerouted, "label": self.label, "names": names})
+
+
+def run(cache, key, inputs, fn, label=""):
+    """Run region ``fn(*inputs)`` through the tape cache ``cache`` (a dict owned by the caller): record on the first call with
+    ``key``, replay afterwards.  ``fn`` returns a tensor, a (nested) tuple of tensors / None, or None."""
+    if not available() or recording() or _lib._RECORD[0] is not None or torch.cuda.is_current_stream_capturing():
+        return fn(*inputs)                                       # (inside a hipGraph capture the graph owns the memory: stay eager)
+    ent = cache.get(key)
+    if ent is None:
+        if len(cache) >= 16:                                     # each region owns its activation buffers: bound the set
+            cache.pop(next(iter(cache)))
+        with Recorder(inputs, label) as rec:
+            outs = fn(*inputs)
+        region = rec.finish(outs)
+        cache[key] = region if region is not None else EAGER
+        return outs
+    if ent is EAGER:
+        return fn(*inputs)
+    return ent.replay(inputs)

@@ -1,0 +1,183 @@
+"""The HIP path at the BENCHMARK'S OWN SIZE against checksums the REFERENCE produced (tools/make_golden_b32.py):
+
+  * configs[1]: B = 32, T_text <= 128, T_mel <= 800, the full GAN step (G phase with frozen discriminators, D phase) in the two
+    modes bench.py times -- "mixed" (north_star's 1e-3 waveform bound) and "bf16" (the headline; bounds stated in
+    tests/test_gpu_bf16.py);
+  * configs[4]: synthesise() of 64 sentences -- int64 durations and wav lengths exact, waveform 1e-3 in f32;
+  * configs[3]: the Transformer module at the full width, B = 32, T = 800.
+
+Integer paths (32 MAS paths -> durations, segment starts, the ground-truth segment gather, 64 x 128 inference durations) are EXACT in
+every mode.  The inputs are regenerated from the seed (tests/_golden_inputs.py) and checked against the fixture's checksums.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+from oracle import schema as S                          # noqa: E402  (weights of the fixtures: checker-side helper)
+from tests import _golden_inputs as GI                  # noqa: E402
+
+
+def _close(got, want, rel):
+    return abs(float(got) - float(want)) <= rel * abs(float(want))
+
+
+# (wav_hat L2 checksum, acoustic losses, MR-STFT loss, adversarial terms, loss_g, AM grad norms, vocoder grad norms, loss_d, D grad norms)
+TOL = {"mixed": dict(wav=1e-4, am=1e-4, stft=2e-4, adv=3e-2, loss_g=2e-2, g_am=2e-3, g_voc=6e-2, loss_d=2e-2, g_d=6e-2),
+       "bf16": dict(wav=2e-3, am=1e-3, stft=3e-2, adv=3e-2, loss_g=2e-2, g_am=3e-2, g_voc=None, loss_d=2e-2, g_d=6e-2)}
+
+
+@pytest.mark.parametrize("mode", ["mixed", "bf16"])
+def test_b32_gan_step_vs_reference_checksums(golden, mode):
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_optispeech
+    from tests.test_gpu_training import _ref_grads
+    g = golden("full_b32_gan")
+    tol = TOL[mode]
+    precision.set_precision(mode)
+    try:
+        m = make_optispeech(ModelConfig().no_dropout(), batch_size=32, pretraining_steps=0).to(DEV).train()
+        W = S.make_weights(S.generator_schema(S.Cfg()), int(g["seed"]))
+        W.update(S.make_weights(S.discriminator_schema(), int(g["disc_seed"])))
+        missing, unexpected = m.load_state_dict(W, strict=False)
+        assert not unexpected and all(("melspec" in k or "window" in k) for k in missing), (missing, unexpected)
+        m.generator.segment_rand01 = torch.from_numpy(g["rand01"])
+        batch = {k: torch.from_numpy(v) for k, v in GI.gan_batch(g).items()}
+        batch.update(sids=None, lids=None)
+        m.discriminator.lambda_mel = 0.0                  # the reference run could not evaluate torchaudio's mel
+        logs = {}
+        for p in m.discriminator.parameters():
+            p.requires_grad_(False)
+        loss_g, (wav, wav_hat) = m.training_step_g(batch, True, logs)
+        out = m._last_gen_outputs
+        aux = out["_aux"]
+        assert np.array_equal(out["start_idx"].cpu().numpy(), g["start_idx"])               # segment starts: exact
+        ndiff = int((aux["durations"].cpu().numpy() != g["durations"]).sum())
+        assert ndiff == 0, f"{ndiff} of {g['durations'].size} durations differ from the reference's MAS paths"
+        assert _close(wav.double().norm().item(), g["wav_cks"][1], 1e-9)                     # ground-truth segment gather: exact
+        assert _close(wav.double().sum().item(), g["wav_cks"][0], 1e-6)
+        for k, kk in (("p_avg", "p_avg"), ("e_avg", "e_avg")):
+            d = (aux[k].cpu().double() - torch.from_numpy(g[kk]).double()).abs().max().item()
+            assert d <= 1e-4 * np.abs(g[kk]).max(), (k, d)
+        for k in ("loss", "align_loss", "duration_loss", "pitch_loss", "energy_loss"):
+            assert _close(out[k].item(), g[k], tol["am"]), (k, out[k].item(), float(g[k]))
+        assert _close(wav_hat.double().norm().item(), g["wav_hat_l2"], tol["wav"]), (wav_hat.double().norm().item(), float(g["wav_hat_l2"]))
+        got, want = logs["gen_adv_loss/train_mr_stft_loss"].item(), float(g["genlog_mr_stft_loss"])
+        assert abs(got - want) <= tol["stft"] * abs(want), (got, want)
+        for k in ("loss_gen_mp", "loss_gen_mrd", "loss_fm_mp", "loss_fm_mrd"):
+            got, want = logs["gen_adv_loss/train_" + k].item(), float(g["genlog_" + k])
+            assert abs(got - want) <= tol["adv"] * abs(want) + 1e-3, (k, got, want)
+        assert _close(loss_g.item(), g["loss_g"], tol["loss_g"])
+        loss_g.backward()
+        gg = _ref_grads(m.generator)
+        n_am = n_voc = 0
+        for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
+            if n < 1e-6:
+                continue
+            e = abs(gg[k].double().norm().item() - n) / n
+            if k.startswith("vocoder."):
+                if tol["g_voc"] is not None:
+                    assert e <= tol["g_voc"], (k, gg[k].double().norm().item(), n)
+                n_voc += 1
+            else:
+                assert e <= tol["g_am"], (k, gg[k].double().norm().item(), n)
+                n_am += 1
+        assert n_am > 60 and n_voc > 30, (n_am, n_voc)
+        for k in g["grad_g_none"].tolist():                                                  # decoder / energy embed: no gradient
+            assert gg[k] is None or float(gg[k].abs().max()) == 0.0, k
+        for p in m.discriminator.parameters():
+            p.requires_grad_(True)
+        m.optimizers()[1].zero_grad()
+        loss_d = m.training_step_d(batch, (wav, wav_hat.detach()), logs)
+        assert _close(loss_d.item(), g["loss_d"], tol["loss_d"]), (loss_d.item(), float(g["loss_d"]))
+        loss_d.backward()
+        gd = _ref_grads(m.discriminator)
+        for k, n in zip(g["grad_d_names"].tolist(), g["grad_d_norms"].tolist()):
+            if n > 1e-4:
+                assert abs(gd[k].double().norm().item() - n) <= tol["g_d"] * n, (k, gd[k].double().norm().item(), n)
+    finally:
+        precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("mode,graph", [("f32", False), ("bf16", False), ("bf16", True)])
+def test_b64_synthesise_vs_reference_checksums(golden, mode, graph):
+    """configs[4] at its own size.  f32: north_star's 1e-3 on the waveform; bf16 (what bench.py measures RTF in, eager and with the
+    hipGraph-captured decode): integers exact, waveform within the bf16 bound of tests/test_gpu_bf16.py."""
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_generator
+    g = golden("full_b64_synth")
+    precision.set_precision(mode)
+    try:
+        gen = make_generator(ModelConfig()).to(DEV).eval()
+        W = S.make_weights(S.generator_schema(S.Cfg()), int(g["seed"]))
+        W["generator.duration_predictor.linear.bias"].fill_(float(g["dur_bias"]))
+        gen.load_state_dict({k[len("generator."):]: v for k, v in W.items()})
+        gen.graph_decode = graph
+        d, p, e = (float(v) for v in g["factors"])
+        out = gen.synthesise(torch.from_numpy(g["in_x"]).to(DEV), torch.from_numpy(g["in_x_lengths"]), d_factor=d, p_factor=p, e_factor=e)
+        if graph:                                             # second call = the replayed graphs
+            out = gen.synthesise(torch.from_numpy(g["in_x"]).to(DEV), torch.from_numpy(g["in_x_lengths"]), d_factor=d, p_factor=p, e_factor=e)
+    finally:
+        precision.set_precision("f32")
+    ndiff = int((out["durations"].numpy() != g["durations"]).sum())
+    assert ndiff == 0, f"{ndiff} of {g['durations'].size} durations differ"                   # int64 exact
+    assert np.array_equal(out["wav_lengths"].numpy(), g["wav_lengths"])
+    wav = out["wav"].double().numpy()
+    assert tuple(wav.shape) == tuple(g["wav_shape"])
+    step = int(g["wav_probe_step"])
+    probe = wav[:, ::step][:, :257]
+    scale = np.abs(g["wav_probe"]).max()
+    err = np.abs(probe - g["wav_probe"]).max() / scale
+    wl = g["wav_lengths"]
+    l2 = np.array([np.sqrt((wav[b, :wl[b]] ** 2).sum()) for b in range(len(wl))])
+    l2err = np.abs(l2 - g["wav_l2"]).max() / g["wav_l2"].max()
+    if mode == "f32":
+        assert err <= 1e-3 and l2err <= 1e-4, (err, l2err)
+    else:
+        assert err <= 4e-2 and l2err <= 1e-2, (err, l2err)
+    assert out["rtf"] > 0
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_b32_transformer_vs_reference_checksums(golden, mode):
+    """configs[3] width and batch (dim 256, 2 heads, 1 024 linear units, 4 blocks; B = 32, T = 800 ragged): output, input gradient and
+    every parameter-gradient norm of the reference's Transformer module.  bf16 runs the fused training attention."""
+    from optispeech_amd import precision
+    from optispeech_amd.model.transformer import Transformer
+    g = golden("full_b32_transformer")
+    sd, lens, x, Gc = GI.transformer_case(g)
+    rel = 1e-3 if mode == "f32" else 3e-2
+    precision.set_precision(mode)
+    try:
+        m = Transformer(dim=256).to(DEV).eval()
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        assert not missing and not unexpected
+        xt = torch.from_numpy(x).to(DEV).requires_grad_(True)
+        T = x.shape[1]
+        pad = (torch.arange(T)[None] >= torch.from_numpy(lens)[:, None]).to(DEV)
+        y = m(xt, pad)
+        valid = (~pad)[:, :, None]
+        yv = (y.detach() * valid)
+        assert _close(yv.double().norm().item(), g["y_cks"][1], rel / 10), (yv.double().norm().item(), g["y_cks"][1])
+        pe = np.abs(yv[:, ::97, ::31].cpu().numpy() - g["y_probe"]).max() / np.abs(g["y_probe"]).max()
+        assert pe <= rel, pe
+        (y * torch.from_numpy(Gc).to(DEV)).sum().backward()
+        dxv = (xt.grad * valid).double()
+        assert _close(dxv.norm().item(), g["dx_cks"][1], rel), (dxv.norm().item(), g["dx_cks"][1])
+        grads = {}
+        for mprefix, mod in m.named_modules():
+            for name, prm in mod._parameters.items():
+                if prm is None:
+                    continue
+                key, _, to_ref = mod._ref(name) if hasattr(mod, "_ref") else (name, None, None)
+                grads[(mprefix + "." if mprefix else "") + key] = to_ref(prm.grad) if to_ref else prm.grad
+        for k, n in zip(g["gnames"].tolist(), g["gnorms"].tolist()):
+            got = grads[k].double().norm().item()
+            if n < 1e-3:
+                assert got < 1e-2, (k, got, n)
+            else:
+                assert abs(got - n) <= max(rel, 2e-3) * n, (k, got, n)
+    finally:
+        precision.set_precision("f32")

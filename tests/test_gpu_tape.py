@@ -1,0 +1,137 @@
+"""Taped regions of the training step (optispeech_amd/tape.py) against their eager execution ("a -m gpu test
+that the replayed step equals the eager step").
+
+The kernels a replay launches are the ones the recording run launched -- same entry points, same arguments up to the patched input
+addresses, same streams -- so everything deterministic must agree BIT FOR BIT: forward activations, scores, input gradients.  The
+weight-gradient kernels accumulate with f32 atomics (split-K): their sums differ in the last bits between ANY two runs, eager or
+not, and are compared at 2e-5 of the tensor's scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _stack_run(make, waves_per_iter, tapes):
+    """Three forward + backward passes of one sub-discriminator (fresh input allocations, weights changed between the passes as an
+    optimizer would) -> per pass (scores, feature maps, d waves, parameter gradients)."""
+    from optispeech_amd import precision, tape, values
+    from optispeech_amd.ops import gsink
+    keep = tape.ENABLED
+    tape.ENABLED = tapes
+    precision.set_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        d = make().to(DEV)
+        out = []
+        for it, wav in enumerate(waves_per_iter):
+            x = wav.clone().to(DEV).requires_grad_(True)
+            junk = torch.empty((it + 1) * 1000 + 17, device=DEV)          # shifts the allocator: inputs live elsewhere each pass
+            for p in d.parameters():
+                p.grad = None
+            for half in (0, x.shape[0] // 2):                             # whole-batch pass and the generator phase's no-grad head
+                for p in d.parameters():
+                    p.requires_grad_(half == 0)
+                res = d(x, nograd_head=half) if half else d(x)
+                (score, fmaps) = res[1] if half else res
+                g = torch.Generator(device="cpu").manual_seed(100 + it)
+                loss = (score * torch.randn(score.shape, generator=g).to(DEV)).sum()
+                for f in fmaps[:-1]:
+                    loss = loss + (f.float() * torch.randn(f.shape, generator=g).to(DEV)).mean()
+                x.grad = None
+                loss.backward()
+                torch.cuda.synchronize()
+                grads = {k: gsink(p).detach().clone() for k, p in d.named_parameters()} if half == 0 else {}
+                out.append((score.detach().clone(), [f.detach().float().clone() for f in fmaps], x.grad.detach().clone(), grads))
+            del junk
+            with torch.no_grad():                                         # "optimizer step": new weights, stale packs
+                for p in d.parameters():
+                    p.add_(torch.randn(p.shape, generator=torch.Generator().manual_seed(7 + it)).to(DEV) * 0.01 * p.abs().mean())
+                    p.requires_grad_(True)
+            values.bump_param_epoch()
+        return out, tape.stats()
+    finally:
+        tape.ENABLED = keep
+        precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("which", ["period3", "period11", "resolution"])
+def test_taped_discriminator_stack_equals_eager(which):
+    from optispeech_amd import tape
+    from optispeech_amd.model.discriminator import DiscriminatorP, DiscriminatorR
+    make = {"period3": lambda: DiscriminatorP(3), "period11": lambda: DiscriminatorP(11),
+            "resolution": lambda: DiscriminatorR((1024, 256, 1024))}[which]
+    g = torch.Generator().manual_seed(5)
+    waves = [torch.rand(4, 16384, generator=g) * 2 - 1 for _ in range(3)]
+    eager, _ = _stack_run(make, waves, tapes=False)
+    s0 = tape.stats()
+    taped, s1 = _stack_run(make, waves, tapes=True)
+    assert tape.available()
+    assert s1["recorded"] - s0["recorded"] >= 4, (s0, s1)               # forward + backward, two phases
+    assert s1["replayed"] - s0["replayed"] >= 8, (s0, s1)               # passes 2 and 3 are replays
+    assert s1["poisoned"] == s0["poisoned"], "a stack region fell back to eager execution"
+    for i, (e, t) in enumerate(zip(eager, taped)):
+        assert torch.equal(e[0], t[0]), f"pass {i}: scores differ"
+        for a, b in zip(e[1], t[1]):
+            assert torch.equal(a, b), f"pass {i}: feature maps differ"
+        assert torch.equal(e[2], t[2]), f"pass {i}: input gradient differs"
+        for k in e[3]:
+            scale = e[3][k].abs().max().item()
+            assert (e[3][k] - t[3][k]).abs().max().item() <= 2e-5 * scale + 1e-12, (i, k)
+
+
+def _train(tapes, steps=4, pipeline=True):
+    from optispeech_amd import precision, rng, tape
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    keep = tape.ENABLED
+    tape.ENABLED = tapes
+    precision.set_precision("bf16")
+    try:
+        cfg = ModelConfig()                                               # BASELINE widths, dropout / drop-path ON
+        batch = synthetic_batch(2, 24, 96, cfg, seed=5, device=DEV)
+        torch.manual_seed(3)
+        torch.cuda.manual_seed(3)
+        rng.manual_seed(3, 0)
+        rng._state["next_stream"] = 1
+        m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
+        m.pipeline_steps = pipeline
+        m.generator.segment_rand01 = torch.rand(2, generator=torch.Generator().manual_seed(1)).to(DEV)
+        m.optimizers()
+        for sch in m.lr_schedulers():
+            sch.warmup = 4
+            sch.opt.lr = sch.base_lr * (1.0 / 4)
+            sch.last_step = 1
+        logs = []
+        for i in range(steps):
+            m.training_step(batch, i)
+            logs.append(m.fetch_logs())
+        m.join()
+        torch.cuda.synchronize()
+        return logs, {k: v.detach().clone() for k, v in m.state_dict().items()}, tape.stats()
+    finally:
+        tape.ENABLED = keep
+        precision.set_precision("f32")
+
+
+def test_taped_training_steps_match_eager_steps():
+    """Four full GAN steps (multi-stream, pipelined, dropout on) with the taped regions replaying from step 2 on, against the same
+    steps run eagerly: same logged losses and the same weights afterwards, to the tolerance of two eager runs against each other
+    (f32 atomics order + the discrete MAS path; see tests/test_gpu_graph.py)."""
+    from optispeech_amd import tape
+    la, sa, _ = _train(False)
+    s0 = tape.stats()
+    lb, sb, s1 = _train(True)
+    assert s1["replayed"] - s0["replayed"] >= 3 * 16, (s0, s1)          # >= the 8 stacks' forward + backward in both phases, 3 steps
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert x.keys() == y.keys()
+        for k in x:
+            assert np.isfinite(y[k])
+            assert abs(x[k] - y[k]) <= (6e-3 if i == 0 else 2e-2) * abs(x[k]) + 1e-4, (i, k, x[k], y[k])
+    moved = 0
+    for k in sa:
+        if sa[k].is_floating_point():
+            assert torch.allclose(sa[k], sb[k], rtol=1e-3, atol=1.5e-3), (k, (sa[k] - sb[k]).abs().max().item())
+            moved += 1
+    assert moved > 100

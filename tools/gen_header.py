@@ -104,6 +104,20 @@ REPLACES = {
     "osp_conv2d_gemm_bf16_multi": "the same layer of the five DiscriminatorP / three DiscriminatorR stacks in one grid "
                                   "(vocoder/wavenext/disc/_discriminators.py:10-38,100-136: the reference loops over the sub-discriminators)",
     "osp_conv2d_dgrad_bf16_multi": "autograd dgrad of the same, grouped over the sub-discriminators",
+    "osp_memset": "no reference counterpart: zero / byte fill of a buffer inside a taped region (torch.zeros / Tensor.zero_ of the host code)",
+    "osp_copy": "no reference counterpart: device-to-device copy inside a taped region (torch.cat / Tensor.copy_ of the host code)",
+    "osp_tape_selftest": "test aid of the call tapes: adds into a HOST counter, no device work (lets the CPU suite record / patch / replay)",
+    "osp_tape_selftest_table": "test aid of the call tapes: sums host int64 values addressed through a host table (copy + patching of descriptor tables)",
+    "osp_store_i64": "no reference counterpart: the per-step dropout seed written to device memory (kernels read it through seed_dev)",
+    "osp_ew_axpby": "autograd's gradient accumulation (a tensor with several consumers), negation and scalar scaling inside taped regions",
+    "osp_ew_mul": "element-wise products with a row / column broadcast: `x * mask` sites of modules/core.py:161-175 and their autograd",
+    "osp_ew_scale_dev": "autograd of the scalar loss assembly: gradient tensor times an incoming device scalar (generator/loss.py, alignments.py:236-238)",
+    "osp_ew_relu_mask": "autograd of nn.ReLU after nn.Conv1d: modules/core.py:66-71",
+    "osp_transpose_last2": "mel.transpose(1, 2) of OptiSpeechGenerator.forward: generator/__init__.py:122",
+    "osp_length_masks": "sequence_mask + padding masks: utils/model.py:12-16, generator/__init__.py:96-103",
+    "osp_sum_scaled": "torch.mean over the per-utterance loss terms: generator/loss.py:190-193, alignments.py:236-238",
+    "osp_dot_multi": "weighted loss sums: generator/__init__.py:175-181, vocoder/wavenext/disc/__init__.py:105-111",
+    "osp_scale_vec": "autograd of the weighted loss sums",
     "osp_source_hash": "content hash of the sources this library was built from (optispeech_amd/build.py checks it; no reference counterpart)",
 }
 
