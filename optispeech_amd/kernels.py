@@ -11,6 +11,30 @@ from ._lib import call
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_SCALE_RES_MASK, EPI_GELU_BWD, EPI_RELU_BWD, EPI_AXMY, EPI_MASK = range(8)
 
 
+def _keep(*objs):
+    """While a call tape is being recorded (optispeech_amd/tape.py): tensors whose addresses travel inside a HOST descriptor table
+    (the *_multi entry points) are invisible to the tape's own bookkeeping -- keep them alive as long as the tape."""
+    from ._lib import lib
+    f = lib()._fast
+    if f is not None and f.tape_recording():
+        for o in objs:
+            if o is not None:
+                f.tape_keep(o)
+
+
+def _persistent(owner, slot, key, shape, dtype):
+    """A buffer that keeps its ADDRESS for the lifetime of ``owner`` (a Parameter): derived weight packs are refreshed in place every
+    optimizer epoch instead of re-allocated, because the call tapes of the regions that read them hold raw addresses."""
+    bufs = getattr(owner, slot, None)
+    if bufs is None:
+        bufs = {}
+        setattr(owner, slot, bufs)
+    t = bufs.get(key)
+    if t is None or tuple(t.shape) != tuple(shape) or t.device != owner.device or t.dtype != dtype:
+        t = bufs[key] = torch.empty(shape, device=owner.device, dtype=dtype)
+    return t
+
+
 def _seed(seed):
     """(host seed, device seed tensor or None): rng.seed() is an int in eager mode and an rng.DeviceSeed while a step is being
     captured into / replayed from a hipGraph (the per-step seed then lives in device memory, csrc: ``seed_dev``)."""
@@ -105,7 +129,7 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
         if cache is None or cache[0] != stamp:
             cache = (stamp, {})
             p._osp_packs = cache
-        wp = torch.empty((n_out, taps, cin), device=w.device, dtype=torch.bfloat16)
+        wp = _persistent(p, "_osp_pack_bufs", key, (n_out, taps, cin), torch.bfloat16)
         call("osp_pack_bf16", w, None, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
         cache[1][key] = wp
         return wp
@@ -130,9 +154,10 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
         if k2 in c2[1]:
             continue
         off, n2, t2, c_in, strd = k2
-        out = torch.empty((n2, t2, c_in), device=q.device, dtype=torch.bfloat16)
+        out = _persistent(q, "_osp_pack_bufs", k2, (n2, t2, c_in), torch.bfloat16)
         rows.append([q.data_ptr() + off, 0, out.data_ptr(), n2, t2, c_in, strd[0], strd[1], strd[2], 0])
         fills.append((c2[1], k2, out))
+        _keep(q, out)
     for rk2 in dead:
         del _PACK_REG[rk2]
     d = np.asarray(rows, dtype=np.int64)
@@ -570,6 +595,7 @@ def l1_sum_multi(targets, ys, out):
     a, b = _host_i64([t.data_ptr() for t in targets]), _host_i64([t.data_ptr() for t in ys])
     n, sc = _host_i64([t.numel() for t in ys]), _host_f32([1.0 / t.numel() for t in ys])
     bf = _host_i64([_isbf(t) for t in ys])
+    _keep(*targets, *ys)
     call("osp_l1_sum_multi", a, b, n, sc, bf, len(ys), out)
 
 
@@ -580,6 +606,7 @@ def l1_sign_multi(targets, ys, gscale):
     o, n = _host_i64([t.data_ptr() for t in gbs]), _host_i64([t.numel() for t in ys])
     sc = _host_f32([1.0 / t.numel() for t in ys])
     bf = _host_i64([_isbf(t) for t in ys])
+    _keep(*targets, *ys, *gbs)
     call("osp_l1_sign_multi", a, b, o, n, sc, bf, len(ys), gscale)
     return gbs
 
@@ -587,6 +614,7 @@ def l1_sign_multi(targets, ys, gscale):
 def hinge_sum_multi(xs, sgns, out):
     x, n = _host_i64([t.data_ptr() for t in xs]), _host_i64([t.numel() for t in xs])
     sg, sc = _host_f32(sgns), _host_f32([1.0 / t.numel() for t in xs])
+    _keep(*xs)
     call("osp_hinge_sum_multi", x, n, sg, sc, len(xs), out)
 
 
@@ -594,6 +622,7 @@ def hinge_grad_multi(xs, sgns, gscale):
     dxs = [torch.empty_like(t) for t in xs]
     x, o = _host_i64([t.data_ptr() for t in xs]), _host_i64([t.data_ptr() for t in dxs])
     n, sg, sc = _host_i64([t.numel() for t in xs]), _host_f32(sgns), _host_f32([1.0 / t.numel() for t in xs])
+    _keep(*xs, *dxs)
     call("osp_hinge_grad_multi", x, o, n, sg, sc, len(xs), gscale)
     return dxs
 
@@ -623,6 +652,7 @@ def wnorm_fwd_multi(items, reuse=None):
         outs.append((wn, wn32, wt, inv))
         rows.append((v, g, wn, wn32, wt, inv, None, None, None, Cout, Cin, P, Q))
     d = _wn_desc(rows)
+    _keep(*[t for r in rows for t in r[:9]])
     call("osp_wnorm_fwd_multi", d, len(rows))
     return outs
 
@@ -634,6 +664,7 @@ def wnorm_bwd_multi(items):
         Cout, Cin, P, Q = v.shape
         rows.append((v, g, None, None, None, inv, dwn, dv, dg, Cout, Cin, P, Q))
     d = _wn_desc(rows)
+    _keep(*[t for r in rows for t in r[:9]])
     call("osp_wnorm_bwd_multi", d, len(rows))
 
 
@@ -647,9 +678,7 @@ def param_bf16(p, transposed=False):
         cache = (stamp, {})
         p._osp_bf16 = cache
     if transposed not in cache[1]:
-        N, Kd = p.shape
-        cache[1][transposed] = (pack_bf16(p.detach(), Kd, 1, N, (1, 0, Kd)) if transposed
-                                else pack_bf16(p.detach(), N, 1, Kd, (Kd, 0, 1))).view(-1, N if transposed else Kd)
+        param_bf16_many([(p, transposed, None)])
     return cache[1][transposed]
 
 
@@ -670,13 +699,15 @@ def param_bf16_many(requests):
         if key in cache[1]:
             continue
         N, Kd = p.shape
+        bkey = key if kscale is None else ("t_scaled", kscale.data_ptr())
         if transposed or kscale is not None:                     # out[k_dim = N index ... ] : (Kd rows, N reduction) = W^T
-            out = torch.empty((Kd, N), device=p.device, dtype=torch.bfloat16)
+            out = _persistent(p, "_osp_bf16_bufs", bkey, (Kd, N), torch.bfloat16)
             rows.append([p.data_ptr(), 0 if kscale is None else kscale.data_ptr(), out.data_ptr(), Kd, 1, N, 1, 0, Kd, 0])
         else:
-            out = torch.empty((N, Kd), device=p.device, dtype=torch.bfloat16)
+            out = _persistent(p, "_osp_bf16_bufs", bkey, (N, Kd), torch.bfloat16)
             rows.append([p.data_ptr(), 0, out.data_ptr(), N, 1, Kd, Kd, 0, 1, 0])
         fills.append((cache[1], key, out))
+        _keep(p, kscale, out)
     if not rows:
         return
     d = np.asarray(rows, dtype=np.int64)
@@ -822,6 +853,94 @@ def l1_sign(a, b, scale, gscale):
     gb = torch.empty_like(b)
     call("osp_l1_sign", a, b, _isbf(a), a.numel(), float(scale), gscale, gb)
     return gb
+
+
+# ------------------------------------------------------------------------------------------------ element-wise plumbing (csrc/ew.hip)
+def ew_axpby(x, y, a=1.0, b=1.0, out=None):
+    """a * x + b * y (y None: a * x + b) on contiguous f32 tensors of one shape."""
+    _f32(x, y)
+    assert x.is_contiguous() and (y is None or (y.is_contiguous() and y.shape == x.shape))
+    out = torch.empty_like(x) if out is None else out
+    call("osp_ew_axpby", x, y, out, x.numel(), float(a), float(b))
+    return out
+
+
+def ew_mul_rows(x, rowvec, out=None):
+    """x (M, C) * rowvec (M,): one factor per row."""
+    _f32(x, rowvec)
+    assert x.is_contiguous() and rowvec.is_contiguous() and rowvec.numel() * x.shape[-1] == x.numel()
+    out = torch.empty_like(x) if out is None else out
+    call("osp_ew_mul", x, rowvec, out, x.numel(), x.shape[-1], 1)
+    return out
+
+
+def ew_scale_dev(x, s, c=1.0, out=None):
+    """c * s[0] * x with ``s`` a one-element f32 device tensor (an incoming loss gradient)."""
+    _f32(x, s)
+    assert x.is_contiguous() and s.numel() == 1
+    out = torch.empty_like(x) if out is None else out
+    call("osp_ew_scale_dev", x, s, out, x.numel(), float(c))
+    return out
+
+
+def relu_mask(g, y):
+    """g where y > 0, else 0 (ReLU backward)."""
+    _f32(g, y)
+    assert g.is_contiguous() and y.is_contiguous() and g.numel() == y.numel()
+    out = torch.empty_like(g)
+    call("osp_ew_relu_mask", g, y, out, g.numel())
+    return out
+
+
+def transpose_last2(x):
+    """(B, R, C) -> (B, C, R) contiguous."""
+    _f32(x)
+    B, R, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, C, R), device=x.device, dtype=torch.float32)
+    call("osp_transpose_last2", x, y, B, R, C)
+    return y
+
+
+def length_masks(lengths, T):
+    """(padding mask (B, T) bool, True = pad; keep mask (B*T,) f32) of int64 lengths in one launch (utils/model.py:12-16)."""
+    _lens(lengths)
+    B = lengths.numel()
+    keep = torch.empty((B * T,), device=lengths.device, dtype=torch.float32)
+    pad = torch.empty((B, T), device=lengths.device, dtype=torch.bool)
+    call("osp_length_masks", lengths, B, T, keep, pad)
+    return pad, keep
+
+
+def sum_scaled(x, scale):
+    """scale * sum(x) as a 0-dim f32 tensor (small vectors: one workgroup, deterministic order)."""
+    _f32(x)
+    assert x.is_contiguous()
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    call("osp_sum_scaled", x, x.numel(), float(scale), out)
+    return out
+
+
+def dot_multi(terms, coeffs):
+    """sum_i coeffs[i] * terms[i][0] over device scalars -> 0-dim tensor."""
+    for t in terms:
+        _f32(t)
+    out = torch.empty((), device=terms[0].device, dtype=torch.float32)
+    _keep(*terms)
+    call("osp_dot_multi", _host_i64([t.data_ptr() for t in terms]), _host_f32(coeffs), len(terms), out, None)
+    return out
+
+
+def scale_vec(g, coeffs):
+    """(g[0] * coeffs[i])_i as a (len(coeffs),) tensor."""
+    _f32(g)
+    out = torch.empty((len(coeffs),), device=g.device, dtype=torch.float32)
+    call("osp_scale_vec", g, _host_f32(coeffs), len(coeffs), out)
+    return out
+
+
+def store_i64(dst, value):
+    call("osp_store_i64", dst, int(value))
 
 
 # ------------------------------------------------------------------------------------------------ attention (A19)

@@ -16,6 +16,19 @@ from .alignments import (AlignmentModule, GaussianUpsampling, average_by_duratio
                          viterbi_decode)
 
 
+def padding_mask(lengths, T):
+    """~sequence_mask(lengths, T) -> (B, T) bool, True = padding; on the GPU one launch yields it together with the f32 keep mask
+    every module of the forward asks for (modules.row_mask finds it on the tensor)."""
+    if not lengths.is_cuda:
+        return ~sequence_mask(lengths, T)
+    pad, keep = K.length_masks(lengths.contiguous(), int(T))
+    try:
+        pad._osp_rowmask = ((-1 if pad.is_inference() else pad._version, torch.cuda.is_current_stream_capturing()), keep)
+    except (AttributeError, RuntimeError):
+        pass
+    return pad
+
+
 def sequence_mask(length, max_length=None):
     """utils/model.py:12-16."""
     if max_length is None:
@@ -74,7 +87,13 @@ class OptiSpeechGenerator(nn.Module):
             return ops.run_on_side_stream("vocoder", lambda: self.vocoder(segment, f0=None), [segment])
         return self.vocoder(segment, f0=None)
 
-    def _forward_am(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids, vocoder_hook=None):
+    def draw_segment_rand(self, B, device):
+        """The uniform draws of get_random_segments (utils/segments.py:29-34) as a contiguous f32 device vector: the test hook
+        ``segment_rand01`` or torch.rand.  Drawn OUTSIDE the taped acoustic-model segment (torch's generator is host state)."""
+        r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=device)
+        return r.to(device=device, dtype=torch.float32).contiguous()
+
+    def _forward_am(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids, vocoder_hook=None, rand01=None):
         """The acoustic-model part of forward(): everything up to the detached decoder segment, plus the acoustic losses (which
         do not depend on the vocoder).  ``vocoder_hook(segment) -> wav_hat`` runs where the reference calls the vocoder (:161);
         None = the caller runs the vocoder itself (graph-segment mode, optispeech_amd/graphs.py)."""
@@ -82,8 +101,8 @@ class OptiSpeechGenerator(nn.Module):
         Tt, Tm = x.shape[1], mel.shape[2]
         x_lengths = x_lengths.contiguous()
         mel_lengths = mel_lengths.contiguous()
-        input_padding_mask = ~sequence_mask(x_lengths, Tt)                  # :96-102
-        target_padding_mask = ~sequence_mask(mel_lengths, Tm)               # :99-103
+        input_padding_mask = padding_mask(x_lengths, Tt)                    # :96-102
+        target_padding_mask = padding_mask(mel_lengths, Tm)                 # :99-103
 
         with precision.index_path():        # exact-f32 forward of everything the (discrete) alignment depends on, in every mode
             h, _ = self.text_embedding(x)                                       # :106
@@ -93,7 +112,7 @@ class OptiSpeechGenerator(nn.Module):
             if lids is not None:
                 h = h + self.lid_embed(lids.view(-1)).unsqueeze(1)              # :115-117
 
-            feats = mel.transpose(1, 2).contiguous()                            # :122
+            feats = K.transpose_last2(mel.contiguous()) if mel.is_cuda else mel.transpose(1, 2).contiguous()   # :122
             log_p_attn = self.alignment_module(text=h, feats=feats, text_lengths=x_lengths, feats_lengths=mel_lengths,
                                                x_masks=input_padding_mask)      # :120-126
             durations, path, bin_item = viterbi_decode(log_p_attn, x_lengths, mel_lengths)      # :127
@@ -110,9 +129,9 @@ class OptiSpeechGenerator(nn.Module):
             y = self.decoder(y.detach(), target_padding_mask)
 
         segment_size = min(self.segment_size, y.shape[1])                                   # :147
-        r = self.segment_rand01 if self.segment_rand01 is not None else torch.rand(B, device=y.device)
+        r = rand01 if rand01 is not None else self.draw_segment_rand(B, y.device)
         # :148 + utils/segments.py:29-34 in one launch: long(r * clamp(float(len - 4) - segment_size, 0))
-        start_idx = K.segment_starts(r.to(device=y.device, dtype=torch.float32), mel_lengths, segment_size)
+        start_idx = K.segment_starts(r, mel_lengths, segment_size)
         segment = K.gather_rows(y.detach(), start_idx, segment_size)                        # :149-153, detach :161
         wav_hat = vocoder_hook(segment) if vocoder_hook is not None else None
 
@@ -186,7 +205,7 @@ class OptiSpeechGenerator(nn.Module):
         am_t0 = perf_counter()
         x_lengths = x_lengths.to(dev).contiguous()
         Tt = x.shape[1]
-        input_padding_mask = ~sequence_mask(x_lengths, Tt)
+        input_padding_mask = padding_mask(x_lengths, Tt)
         with precision.index_path():        # durations are integers: their inputs stay exact-f32 in every mode
             return self._synthesise_body(x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0,
                                          input_padding_mask)

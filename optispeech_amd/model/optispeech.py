@@ -22,6 +22,7 @@ from torch import nn
 from .. import kernels as K
 from .. import ops
 from .. import rng
+from .. import tape as _tape
 from ..dp import GradReducer
 from ..optim import CosineWarmupSchedule, FusedAdamW
 from ..values import InferenceInputs, InferenceOutputs
@@ -102,6 +103,11 @@ class OptiSpeech(nn.Module):
         #: multi-stream step (optispeech_amd/graphs.py: GeneratorSegments): removes ~2/3 of the step's host time
         self.graph_segments = os.environ.get("OSP_GRAPH_SEGMENTS", "0") == "1"
         self._gen_segments = {}
+        #: acoustic model + vocoder as TAPED segments (optispeech_amd/tape.py: one autograd node each, forward and backward
+        #: replayed from recorded C-ABI call lists on the eager multi-stream schedule).  On by default where tapes are available.
+        self.tape_segments = os.environ.get("OSP_TAPE_SEGMENTS", "1") != "0"
+        self._tape_am = self._tape_voc = None
+        self._seed_dev = None
         self._dstream = None
         self._disc_param_list = None
         self._reducers = None
@@ -152,6 +158,9 @@ class OptiSpeech(nn.Module):
         if (self.graph_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
                 and batch.get("lids") is None and self.train_args.gradient_accumulate_batches is None):
             gen_outputs = self._graphed_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
+        elif (self.tape_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
+                and batch.get("lids") is None and rng.device_seed_active() and _tape.available()):
+            gen_outputs = self._taped_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
         else:
             gen_outputs = self.generator(x=t(batch["x"]), x_lengths=t(batch["x_lengths"]), mel=t(batch["mel"]),
                                          mel_lengths=t(batch["mel_lengths"]), pitches=t(batch["pitches"]),
@@ -167,6 +176,46 @@ class OptiSpeech(nn.Module):
         rows = wav.contiguous().view(B, -1, hop)
         gen_outputs["wav"] = K.gather_rows(rows, gen_outputs["start_idx"], seg).view(B, seg * hop)
         return gen_outputs
+
+    def _taped_generator(self, tensors):
+        """generator.forward through two taped segments (optispeech_amd/tape.py): the acoustic model with its losses, and the vocoder
+        on its own stream.  The first step with a batch signature runs and records them; later steps replay."""
+        from .. import precision
+        gen = self.generator
+        if self._tape_am is None:
+            def am(x, x_lengths, mel, mel_lengths, pitches, energies, r01):
+                o = gen._forward_am(x, x_lengths, mel, mel_lengths, pitches, energies, None, None, vocoder_hook=None, rand01=r01)
+                a = o["_aux"]
+                return (o["loss"], o["align_loss"], o["duration_loss"], o["pitch_loss"], o["energy_loss"], a["segment"], o["start_idx"],
+                        a["durations"], a["p_avg"], a["e_avg"])
+            self._tape_am = _tape.Segment(am, "acoustic model")
+            self._tape_voc = _tape.Segment(lambda seg: (gen.vocoder(seg, f0=None),), "vocoder")
+        x, mel = tensors[0], tensors[2]
+        r01 = gen.draw_segment_rand(x.shape[0], x.device)
+        key = (tuple((tuple(v.shape), v.dtype) for v in tensors), precision.get_precision(), id(self.optimizers()[0].arena))
+        loss, align, dur, pit, ene, segment, start_idx, durations, p_avg, e_avg = self._tape_am(key, *tensors, r01)
+        seg_size = int(segment.shape[1])
+        vkey = (tuple(segment.shape), precision.get_precision(), id(self.optimizers()[0].arena))
+        from ..model.generator import _VOC_STREAM
+        if _VOC_STREAM:
+            wav_hat = ops.run_on_side_stream("vocoder", lambda: self._tape_voc(vkey, segment)[0], [segment])
+        else:
+            wav_hat = self._tape_voc(vkey, segment)[0]
+        return {"wav_hat": wav_hat, "start_idx": start_idx, "segment_size": seg_size, "loss": loss,
+                "align_loss": align.detach(), "duration_loss": dur.detach(), "pitch_loss": pit.detach(), "energy_loss": ene.detach(),
+                "_aux": {"durations": durations, "p_avg": p_avg, "e_avg": e_avg, "segment": segment}}
+
+    def _push_seed(self):
+        """The step's dropout seed into device memory (the kernels of a taped region read it through ``seed_dev``: an argument
+        baked into a recorded call would freeze the first step's masks)."""
+        dev = self.device
+        if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return False
+        if self._seed_dev is None or self._seed_dev.device != dev:
+            self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        K.store_i64(self._seed_dev, rng.host_seed())
+        rng.use_device_seed(self._seed_dev)
+        return True
 
     def _graphed_generator(self, tensors):
         """generator.forward through the two graphed segments (captured on the first call with this batch signature)."""
@@ -203,6 +252,15 @@ class OptiSpeech(nn.Module):
         # gradients are exchanged once per optimiser step: on the batches that only accumulate, nothing is all-reduced
         red_g.eager_ranges = red_d.eager_ranges = st.apply
         rng.advance()
+        dev_seed = self.tape_segments and _tape.available() and self._push_seed()
+        try:
+            self._training_step_body(st, batch, red_g, red_d)
+        finally:
+            if dev_seed:
+                rng.use_device_seed(None)
+
+    def _training_step_body(self, st, batch, red_g, red_d):
+        ta = self.train_args
         # ---- generator phase (discriminator weights frozen = toggle_optimizer; training_step_g freezes them after the
         # shared real-wave pass, which needs the parameter graph for the discriminator phase)
         self._stage_g_forward(st, batch)

@@ -88,11 +88,23 @@ def _flush_wgrad():
     _WG["pending"] = []
 
 
+def _wait_for(side_raw, event):
+    """The CURRENT stream waits for everything queued on the stream ``side_raw`` so far: ``event`` is recorded on the side stream and
+    waited for here, in one C-ABI call (osp_stream_handover issued ON the side stream with this stream as its target) -- so that
+    the join lands on a call tape like any other launch (optispeech_amd/tape.py)."""
+    cur_raw = _lib._STREAM_OVERRIDE[0] or _lib._raw_stream(torch.cuda.current_device())
+    keep = _lib._STREAM_OVERRIDE[0]
+    _lib._STREAM_OVERRIDE[0] = side_raw
+    try:
+        _lib.lib().call("osp_stream_handover", event.cuda_event, cur_raw)
+    finally:
+        _lib._STREAM_OVERRIDE[0] = keep
+
+
 def _join_wgrad():
     _flush_wgrad()
-    cur = torch.cuda.current_stream()
     for side in _WG["used"]:
-        cur.wait_stream(side.stream)
+        _wait_for(side.raw, side.next_event())
         side.pos = 0
     _WG["used"], _WG["queued"], _WG["done"] = [], False, []
 
@@ -112,6 +124,18 @@ def begin_backward():
                 cur.wait_stream(side.stream)
                 side.pos = 0
         _WG["used"], _WG["queued"], _WG["done"] = [], False, []
+
+
+def nested_backward_begin():
+    """A backward pass run INSIDE another one (tape.Segment records its inner graph's backward): the inner pass gets a clean
+    hand-over state, so that it queues -- and records -- its own end-of-pass join instead of relying on the outer pass's."""
+    outer = (_WG["queued"], _WG["pending"], _WG["used"], _WG["done"], _WG["regions"])
+    _WG["queued"], _WG["pending"], _WG["used"], _WG["done"], _WG["regions"] = False, [], [], [], 0
+    return outer
+
+
+def nested_backward_end(outer):
+    _WG["queued"], _WG["pending"], _WG["used"], _WG["done"], _WG["regions"] = outer
 
 
 def wgrad_side_streams():
@@ -321,7 +345,7 @@ class ConvLinearFn(torch.autograd.Function):
         B, T, Cin = x.shape
         g = dy.contiguous().view(B * T, Cout)
         if act == "relu":
-            g = g * (y > 0)
+            g = K.relu_mask(g, y) if (g.is_cuda and g.dtype == torch.float32) else g * (y > 0)
         # dgrad: dx[m,c] = sum_{j,n} g[m - j + pad, n] w[n, j, c]  == conv with flipped taps over the (n) axis
         dx = None
         if ctx.needs_input_grad[0]:
@@ -485,7 +509,8 @@ class VarianceEmbedFn(torch.autograd.Function):
         if drop_p > 0.0:
             # x + dropout(emb) in one launch; the backward regenerates the mask from the same Philox counter (element index)
             emb = K.conv_gemm(v, w, C, T=T, taps=taps, pad=pad, bias=b)
-            y = K.dropout_add(emb, drop_p, seed, stream_id, res=x.view(B * T, C)) * rowmask[:, None]
+            y = K.dropout_add(emb, drop_p, seed, stream_id, res=x.view(B * T, C))
+            y = K.ew_mul_rows(y, rowmask, out=y) if y.is_cuda else y * rowmask[:, None]
             dm = None
         else:
             dm = None
@@ -503,7 +528,8 @@ class VarianceEmbedFn(torch.autograd.Function):
         v, rowmask, dm = ctx.saved_tensors
         w, b = ctx.params
         B, T, C, taps, pad = ctx.cfg
-        g = dy.contiguous().view(B * T, C) * rowmask[:, None]
+        g = dy.contiguous().view(B * T, C)
+        g = K.ew_mul_rows(g, rowmask) if g.is_cuda else g * rowmask[:, None]
         dx = g.view(B, T, C) if ctx.needs_input_grad[0] else None
         drop_p, seed, stream_id = ctx.drop
         ge = K.dropout_add(g, drop_p, seed, stream_id) if drop_p > 0.0 else g
@@ -575,7 +601,9 @@ class AlignLogProbFn(torch.autograd.Function):
         wtf = torch.zeros((B, N, C), device=f.device, dtype=torch.float32)
         wcol = torch.zeros((B, N), device=f.device, dtype=torch.float32)
         K.conv_wgrad(w, f, wtf, wcol, batch=B)
-        de = torch.addcmul(-wtf, wcol.unsqueeze(-1), e)
+        # de = colsum(w) * e - w^T f
+        de = K.ew_mul_rows(e.view(B * N, C), wcol.view(-1)).view(B, N, C)
+        K.ew_axpby(de, wtf, 1.0, -1.0, out=de)
         return df, de, None, None, None
 
 
@@ -590,11 +618,26 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+_side_evs = {}
+
+
+def _side_events(device):
+    """Two persistent events of the CTC side stream (fork, join), created with their handles (torch creates them lazily)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ev = _side_evs.get(key)
+    if ev is None:
+        ev = (torch.cuda.Event(), torch.cuda.Event())
+        for e in ev:
+            e.record()
+        _side_evs[key] = ev
+    return ev
+
+
 def join_side_stream():
     """Make the current stream wait for everything queued on the side stream so far (no host sync)."""
-    main = torch.cuda.current_stream()
     while _pending_side:
-        main.wait_event(_pending_side.pop())
+        side, ev = _pending_side.pop()
+        _wait_for(side.cuda_stream, ev)
 
 
 class AlignLossFn(torch.autograd.Function):
@@ -610,26 +653,30 @@ class AlignLossFn(torch.autograd.Function):
         # B=32) and occupies 32 of the 256 CUs: it runs on a side stream next to the decoder / vocoder forward.  The
         # caller joins with ``join_side_stream()`` before it consumes the loss (generator.forward does, right before the
         # loss sum); the gradient saved here is only read in backward, i.e. after that join.
-        main = torch.cuda.current_stream()
         side = _side_stream(lp.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        ev = _side_events(lp.device)
+        # hand-over and launches go through the C ABI on raw stream handles (no torch stream switch): a call tape records them
+        lib = _lib.lib()
+        lib.call("osp_stream_handover", ev[0].cuda_event, side.cuda_stream)
+        keep = _lib._STREAM_OVERRIDE[0]
+        _lib._STREAM_OVERRIDE[0] = side.cuda_stream
+        try:
             loss_item, grad = K.forwardsum_ctc(lp, x_len, y_len, want_grad=need)
-            fs = loss_item.mean()
-        for t in (lp, x_len, y_len):
-            t.record_stream(side)
-        for t in (fs, grad):
+            fs = K.sum_scaled(loss_item, 1.0 / B)
+        finally:
+            _lib._STREAM_OVERRIDE[0] = keep
+        for t in (lp, x_len, y_len, loss_item, fs, grad):
             if t is not None:
-                t.record_stream(main)
-        _pending_side.append(side.record_event())
+                t.record_stream(side)                              # (allocated under the calling stream, used on the side stream)
+        _pending_side.append((side, ev[1]))
         if need:
             ctx.save_for_backward(grad, path, y_len)
-        return fs, bin_item.mean()
+        return fs, K.sum_scaled(bin_item, 1.0 / B)
 
     @staticmethod
     def backward(ctx, g_fs, g_bin):
         grad, path, y_len = ctx.saved_tensors
-        dlp = grad * g_fs
+        dlp = K.ew_scale_dev(grad, g_fs.reshape(1))
         K.bin_loss_bwd(path, y_len, g_bin.reshape(1).contiguous().float(), dlp)
         return dlp, None, None, None, None
 
@@ -646,7 +693,8 @@ class VarianceLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1, g2):
         gd, gp, ge = ctx.saved_tensors
-        return gd * g0, gp * g1, ge * g2, None, None, None, None
+        return (K.ew_scale_dev(gd, g0.reshape(1)), K.ew_scale_dev(gp, g1.reshape(1)), K.ew_scale_dev(ge, g2.reshape(1)),
+                None, None, None, None)
 
 
 class GaussianUpsampleFn(torch.autograd.Function):
@@ -837,30 +885,27 @@ def _named_stream(key, device):
 
 # ------------------------------------------------------------------------------------------------ scalar loss assembly
 class WeightedSumFn(torch.autograd.Function):
-    """sum_i coeff_i * term_i over device scalars in ONE autograd node: forward = a stack and a dot product, backward = one
-    multiply (the gradients of the terms are views of it).  The loss assemblies (generator/__init__.py:175-181,
+    """sum_i coeff_i * term_i over device scalars in ONE autograd node and one launch each way (osp_dot_multi / osp_scale_vec; the
+    gradients of the terms are views of one vector).  The loss assemblies (generator/__init__.py:175-181,
     vocoder/wavenext/disc/__init__.py:105-111) were ~8 tiny launches forward and as many backward each."""
 
     @staticmethod
     def forward(ctx, coeffs, *terms):
-        st = torch.stack([t.reshape(()).float() for t in terms])
-        ctx.save_for_backward(coeffs)
-        return torch.dot(st, coeffs)
+        ctx.coeffs = coeffs
+        ts = [t.reshape(()) if t.dtype == torch.float32 else t.reshape(()).float() for t in terms]
+        if ts[0].is_cuda:
+            return K.dot_multi(ts, coeffs)
+        return torch.dot(torch.stack(ts), torch.tensor(coeffs, dtype=torch.float32))
 
     @staticmethod
     def backward(ctx, g):
-        (coeffs,) = ctx.saved_tensors
-        gs = g * coeffs
+        if g.is_cuda:
+            gs = K.scale_vec(g.reshape(1).float(), ctx.coeffs)
+        else:
+            gs = g * torch.tensor(ctx.coeffs, dtype=torch.float32)
         return (None,) + tuple(gs.unbind(0))
 
 
-_COEFF_CACHE = {}
-
-
 def weighted_sum(terms, coeffs):
-    """terms: device scalars, coeffs: python floats (cached as a device vector)."""
-    key = (tuple(float(c) for c in coeffs), str(terms[0].device))
-    ct = _COEFF_CACHE.get(key)
-    if ct is None:
-        ct = _COEFF_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=terms[0].device)
-    return WeightedSumFn.apply(ct, *terms)
+    """terms: device scalars, coeffs: python floats."""
+    return WeightedSumFn.apply(tuple(float(c) for c in coeffs), *terms)

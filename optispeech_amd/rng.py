@@ -46,6 +46,11 @@ def use_device_seed(tensor):
     _dev["seed"] = DeviceSeed(tensor) if tensor is not None else None
 
 
+def device_seed_active() -> bool:
+    """True while dropout sites hand their kernels the seed as a device tensor (graph capture / replay, taped steps)."""
+    return _dev["seed"] is not None
+
+
 def new_stream() -> int:
     s = _state["next_stream"]
     _state["next_stream"] += 1

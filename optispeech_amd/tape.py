@@ -372,3 +372,90 @@ def run(cache, key, inputs, fn, label=""):
     if ent is EAGER:
         return fn(*inputs)
     return ent.replay(inputs)
+
+
+# ---------------------------------------------------------------------------------------------------- taped autograd segments
+class Segment:
+    """A differentiable sub-graph of the step -- the acoustic model, the vocoder -- as ONE autograd node whose forward and backward
+    are call tapes.
+
+    ``fn(*inputs) -> tuple of tensors`` builds an ordinary autograd graph out of this package's Functions (any number of nodes,
+    side streams through the C ABI, parameter gradients accumulated straight into the gradient arena).  The first call with a given
+    ``key`` RUNS it that way -- forward under a recorder, then, when the step's backward arrives, the inner graph's backward under a
+    second recorder -- so the recording step computes exactly what an eager step computes.  Later calls replay the two tapes: no
+    inner graph, no Python per kernel.  The inputs receive no gradient (the acoustic model's are data, the vocoder's is the
+    detached decoder segment).  A recording that met something it cannot hold leaves the key eager: ``fn`` then simply runs under
+    the caller's autograd, every step."""
+
+    def __init__(self, fn, label):
+        self.fn, self.label = fn, label
+        self.cache = {}
+        self.anchor = None
+
+    def __call__(self, key, *inputs):
+        if (not available() or recording() or not torch.is_grad_enabled() or not inputs[0].is_cuda
+                or torch.cuda.is_current_stream_capturing() or self.cache.get(key) is EAGER):
+            return self.fn(*inputs)
+        if self.anchor is None or self.anchor.device != inputs[0].device:
+            self.anchor = torch.zeros(1, device=inputs[0].device, requires_grad=True)     # gives the node's outputs a grad_fn
+        return _SegmentFn.apply(self, key, self.anchor, *inputs)
+
+
+class _SegmentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, key, anchor, *inputs):
+        ctx.seg, ctx.key = seg, key
+        ctx.set_materialize_grads(False)
+        inputs = [t.contiguous() if isinstance(t, torch.Tensor) else t for t in inputs]
+        ent = seg.cache.get(key)
+        if ent is not None:
+            outs = ent[0].replay(inputs)
+            ctx.inner = None
+            ctx.diff = ent[2]
+        else:
+            if len(seg.cache) >= 8:
+                seg.cache.pop(next(iter(seg.cache)))
+            with Recorder(inputs, seg.label + " forward") as rec:
+                with torch.enable_grad():
+                    inner = tuple(seg.fn(*[t.detach() if isinstance(t, torch.Tensor) else t for t in inputs]))
+            diff = tuple(i for i, o in enumerate(inner) if isinstance(o, torch.Tensor) and o.requires_grad)
+            region = rec.finish(tuple(o.detach() if isinstance(o, torch.Tensor) else o for o in inner))
+            ctx.inner = (inner, region)
+            ctx.diff = diff
+            outs = tuple(o.detach() if isinstance(o, torch.Tensor) else o for o in inner)
+        nd = [o for i, o in enumerate(outs) if isinstance(o, torch.Tensor) and i not in ctx.diff]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        seg, key = ctx.seg, ctx.key
+        gin = [None if grads[i] is None else grads[i].contiguous() for i in ctx.diff]
+        pattern = tuple(None if g is None else (tuple(g.shape), g.dtype) for g in gin)
+        nin = len(ctx.needs_input_grad)
+        if ctx.inner is None:
+            fwd, bwd, diff, pat = seg.cache[key]
+            if pat != pattern:
+                raise RuntimeError(f"taped segment {seg.label!r}: the step asks for gradients of a different set of outputs than the "
+                                   f"recorded backward has ({pattern} vs {pat}); give such a step its own key")
+            bwd.replay(gin)
+            return (None,) * nin
+        inner, fwd = ctx.inner
+        ctx.inner = None
+        outs = [inner[i] for i in ctx.diff]
+        pairs = [(o, g) for o, g in zip(outs, gin) if g is not None]
+        if fwd is None:                                            # the forward recording was poisoned: plain nested backward
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+            seg.cache[key] = EAGER
+            return (None,) * nin
+        from . import ops as _ops
+        outer = _ops.nested_backward_begin()                       # the segment joins its own weight-gradient side streams: on the tape
+        try:
+            with Recorder(gin, seg.label + " backward") as rec:
+                torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        finally:
+            _ops.nested_backward_end(outer)
+        bwd = rec.finish(None)
+        seg.cache[key] = (fwd, bwd, ctx.diff, pattern) if bwd is not None else EAGER
+        return (None,) * nin

@@ -29,8 +29,8 @@ def _stack_run(make, waves_per_iter, tapes):
         for it, wav in enumerate(waves_per_iter):
             x = wav.clone().to(DEV).requires_grad_(True)
             junk = torch.empty((it + 1) * 1000 + 17, device=DEV)          # shifts the allocator: inputs live elsewhere each pass
-            for p in d.parameters():
-                p.grad = None
+            for p in d.parameters():                                      # zeroed IN PLACE: the gradient sinks keep their addresses, as
+                gsink(p).zero_()                                          # the optimizer's flat arena does (a tape holds them)
             for half in (0, x.shape[0] // 2):                             # whole-batch pass and the generator phase's no-grad head
                 for p in d.parameters():
                     p.requires_grad_(half == 0)
