@@ -1,0 +1,74 @@
+"""Placement of the training step's HIP streams on the GPU's hardware queues ("lanes").
+
+Measured in round 4: the ROCm 7.2 runtime multiplexes every HIP stream of a process onto GPU_MAX_HW_QUEUES = 4 hardware
+queues, dealt out round-robin; work of two streams that share a queue executes in enqueue order, one after the other, whenever the
+host enqueues faster than the device drains (which the call tapes make the normal case).  The step uses ~16 streams -- the calling
+stream, the vocoder stream, the CTC side stream, two weight-gradient side streams, eight sub-discriminator streams, the spectral-loss
+stream, the discriminator-phase calling stream -- so WHICH of them share a queue decides how much of the multi-stream schedule is
+real concurrency: shifting the assignment by one stream moved the step between 17.2 and 19.7 ms (profiles/r04_stream_skew.txt).
+
+This module makes the assignment explicit and deterministic: a pool of streams is created up front, in a fixed order, and each is
+bound to its hardware queue right away (one trivial launch); pool entry i sits on lane i mod 4.  A logical stream asks for a lane by
+name; ``OSP_LANES="name:lane,..."`` overrides the table (tools/lane_search.py uses that).  Names: voc, ctc, wg_main, wg_voc, wg_other,
+p0..p4 (period discriminators 2, 3, 5, 7, 11), r0..r2 (resolution discriminators), spec, dphase.
+"""
+import os
+
+import torch
+
+N_LANES = 4
+DEPTH = 7                      # pool entries per lane
+
+#: lane per logical stream (None = an unmanaged stream from torch's pool, as before round 4)
+DEFAULT = {"voc": None, "ctc": None, "wg_main": None, "wg_voc": None, "wg_other": None, "p0": None, "p1": None, "p2": None, "p3": None,
+           "p4": None, "r0": None, "r1": None, "r2": None, "spec": None, "dphase": None}
+
+_pool = {}
+_taken = {}
+_table = None
+
+
+def table():
+    global _table
+    if _table is None:
+        t = dict(DEFAULT)
+        for item in os.environ.get("OSP_LANES", "").split(","):
+            if ":" in item:
+                k, v = item.split(":")
+                t[k.strip()] = None if v.strip() in ("-", "") else int(v)
+        _table = t
+    return _table
+
+
+def managed():
+    return any(v is not None for v in table().values())
+
+
+def _make_pool(device):
+    from . import kernels as K
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _pool:
+        streams = []
+        scratch = torch.zeros(1, dtype=torch.int64, device=device)
+        for i in range(N_LANES * DEPTH):
+            s = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(s):
+                K.store_i64(scratch, i)                      # first use binds the stream to its hardware queue: do it in pool order
+            streams.append(s)
+        torch.cuda.synchronize(device)
+        _pool[idx], _taken[idx] = streams, set()
+    return idx
+
+
+def stream(name, device):
+    """The persistent stream of logical name ``name`` (a fresh one per call: callers cache it)."""
+    lane = table().get(name)
+    if lane is None:
+        return torch.cuda.Stream(device=device)
+    idx = _make_pool(device)
+    for i, s in enumerate(_pool[idx]):
+        if i % N_LANES == lane % N_LANES and i not in _taken[idx]:
+            _taken[idx].add(i)
+            return s
+    return torch.cuda.Stream(device=device)

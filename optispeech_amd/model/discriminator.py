@@ -290,7 +290,8 @@ class _Multi(nn.Module):
         overlap the large GEMMs of another.  autograd replays every node's backward on the stream its forward ran on and
         joins the streams at the end of backward(), so the backward overlaps the same way."""
         main = torch.cuda.current_stream()
-        streams = _disc_streams(id(self), len(self.discriminators), x.device)
+        fam = "p" if isinstance(self.discriminators[0], DiscriminatorP) else "r"
+        streams = _disc_streams(id(self), len(self.discriminators), x.device, names=[fam + str(i) for i in range(len(self.discriminators))])
         assert len(streams) == len(self.discriminators)
         if ready is None:
             ready = main.record_event()
@@ -330,6 +331,8 @@ _PERIOD_FOLD = os.environ.get("OSP_PERIOD_FOLD", "1") != "0"
 #: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
 _FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"
 _STREAMS = {}
+#: HIP priority of the sub-discriminator streams (lower number = higher priority; 0 = default).  See OptiSpeech.__init__.
+_DISC_PRIORITY = int(os.environ.get("OSP_PRIO_DISC", "0"))
 _MAX_STREAMS = int(os.environ.get("OSP_DISC_MAX_STREAMS", "8"))     # streams per discriminator family
 _PENDING = []
 
@@ -348,7 +351,7 @@ def join_streams():
 def on_side_stream(key, fn, inputs):
     """Run ``fn()`` on a persistent side stream (ordered after the current stream's work so far); joined by join_streams()."""
     dev = inputs[0].device
-    st = _disc_streams(key, 1, dev)[0]
+    st = _disc_streams(key, 1, dev, names=["spec"])[0]
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         out = fn()
@@ -358,13 +361,30 @@ def on_side_stream(key, fn, inputs):
     return out
 
 
-def _disc_streams(key, n, device):
+_SKEWED = set()
+
+
+def _skew(device, var):
+    """Experiment knob: burn ``$var`` streams of torch's pool before the next one is taken (shifts which hardware queue the streams
+    created afterwards land on: the runtime deals its hardware queues out round-robin)."""
+    n = int(os.environ.get(var, "0"))
+    if n and var not in _SKEWED:
+        _SKEWED.add(var)
+        _SKEWED.update(torch.cuda.Stream(device=device) for _ in range(n))
+
+
+def _disc_streams(key, n, device, names=None):
     """n persistent side streams for ``key``.  The COUNT is part of the cache key: callers key by id(module), CPython re-uses the id
     of a collected object, and a five-stack family that inherited a dead three-stack family's entry was zipped against three
     streams -- two sub-discriminators silently dropped (found in round 3 by a test that builds both families in one process)."""
     k = (key, n, torch.device(device).index)
     if k not in _STREAMS:
-        pool = [torch.cuda.Stream(device=device) for _ in range(min(n, _MAX_STREAMS))]
+        _skew(device, "OSP_SKEW_DISC")
+        from .. import lanes
+        if names is not None and lanes.managed():
+            pool = [lanes.stream(nm, device) for nm in names[:min(n, _MAX_STREAMS)]]
+        else:
+            pool = [torch.cuda.Stream(device=device, priority=_DISC_PRIORITY) for _ in range(min(n, _MAX_STREAMS))]
         _STREAMS[k] = [pool[i % len(pool)] for i in range(n)]
     return _STREAMS[k]
 

@@ -62,6 +62,7 @@ _SYNC_AFTER_G = __import__("os").environ.get("OSP_SYNC_AFTER_G", "0") == "1"
 #: backward() runs on the calling thread instead of the engine's per-device worker thread: one device per process, so the worker
 #: only adds a thread hand-over and GIL traffic per pass (host enqueue 20.2 -> 17.9 ms per step at B = 32; OSP_AUTOGRAD_MT=1 restores it)
 _AUTOGRAD_MT = __import__("os").environ.get("OSP_AUTOGRAD_MT", "0") == "1"
+_D_AFTER_G = __import__("os").environ.get("OSP_D_AFTER_G", "0") == "1"
 
 
 class OptiSpeech(nn.Module):
@@ -104,10 +105,22 @@ class OptiSpeech(nn.Module):
         self.graph_segments = os.environ.get("OSP_GRAPH_SEGMENTS", "0") == "1"
         self._gen_segments = {}
         #: acoustic model + vocoder as TAPED segments (optispeech_amd/tape.py: one autograd node each, forward and backward
-        #: replayed from recorded C-ABI call lists on the eager multi-stream schedule).  On by default where tapes are available.
-        self.tape_segments = os.environ.get("OSP_TAPE_SEGMENTS", "1") != "0"
+        #: replayed from recorded C-ABI call lists on the eager multi-stream schedule).  OPT-IN: host enqueue 13.4 -> 9.3 ms per step, but
+        #: the step is GPU-bound (17.2 ms) and with the vocoder taped the device needs 20.1 ms for the same kernels in the overlapped
+        #: schedule (17.6 with only the acoustic model taped; serialised stage by stage the three variants are within 1 ms of each
+        #: other; no stream -> hardware-queue assignment of 36 tried recovers it: profiles/r04_tape_segments_ab.txt).  The
+        #: sub-discriminator stacks, whose tapes are a measured win (18.9 -> 17.2 ms), are taped regardless of this switch.
+        self.tape_segments = os.environ.get("OSP_TAPE_SEGMENTS", "0") == "1"
         self._tape_am = self._tape_voc = None
         self._seed_dev = None
+        #: how many steps the HOST may run ahead of the device (0 = unbounded).  With the taped regions a step is enqueued in about
+        #: half the time the device needs for it; unbounded, the host piles several steps of launches into the four hardware queues
+        #: the ~14 streams share and blocks inside the runtime at unpredictable points (measured: 20.5 ms / step against 17.5 with
+        #: the slower eager host, same GPU-only time).  Waiting for the END OF THE GENERATOR PHASE of an earlier step (one event per
+        #: step, no device idle: the device still has >= one step queued) keeps the queues short.
+        self.max_steps_ahead = int(os.environ.get("OSP_MAX_STEPS_AHEAD", "2"))
+        self._pace = []
+        self._g_done_event = None
         self._dstream = None
         self._disc_param_list = None
         self._reducers = None
@@ -193,14 +206,16 @@ class OptiSpeech(nn.Module):
         x, mel = tensors[0], tensors[2]
         r01 = gen.draw_segment_rand(x.shape[0], x.device)
         key = (tuple((tuple(v.shape), v.dtype) for v in tensors), precision.get_precision(), id(self.optimizers()[0].arena))
-        loss, align, dur, pit, ene, segment, start_idx, durations, p_avg, e_avg = self._tape_am(key, *tensors, r01)
+        am = self._tape_am if os.environ.get("OSP_TAPE_AM", "1") != "0" else (lambda k, *a: self._tape_am.fn(*a))
+        vo = self._tape_voc if os.environ.get("OSP_TAPE_VOC", "1") != "0" else (lambda k, *a: self._tape_voc.fn(*a))
+        loss, align, dur, pit, ene, segment, start_idx, durations, p_avg, e_avg = am(key, *tensors, r01)
         seg_size = int(segment.shape[1])
         vkey = (tuple(segment.shape), precision.get_precision(), id(self.optimizers()[0].arena))
         from ..model.generator import _VOC_STREAM
         if _VOC_STREAM:
-            wav_hat = ops.run_on_side_stream("vocoder", lambda: self._tape_voc(vkey, segment)[0], [segment])
+            wav_hat = ops.run_on_side_stream("vocoder", lambda: vo(vkey, segment)[0], [segment])
         else:
-            wav_hat = self._tape_voc(vkey, segment)[0]
+            wav_hat = vo(vkey, segment)[0]
         return {"wav_hat": wav_hat, "start_idx": start_idx, "segment_size": seg_size, "loss": loss,
                 "align_loss": align.detach(), "duration_loss": dur.detach(), "pitch_loss": pit.detach(), "energy_loss": ene.detach(),
                 "_aux": {"durations": durations, "p_avg": p_avg, "e_avg": e_avg, "segment": segment}}
@@ -252,12 +267,19 @@ class OptiSpeech(nn.Module):
         # gradients are exchanged once per optimiser step: on the batches that only accumulate, nothing is all-reduced
         red_g.eager_ranges = red_d.eager_ranges = st.apply
         rng.advance()
+        pace = self.max_steps_ahead > 0 and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+        if pace and len(self._pace) >= self.max_steps_ahead:
+            self._pace.pop(0).synchronize()
         dev_seed = self.tape_segments and _tape.available() and self._push_seed()
         try:
             self._training_step_body(st, batch, red_g, red_d)
         finally:
             if dev_seed:
                 rng.use_device_seed(None)
+        if pace:
+            ev = torch.cuda.Event()
+            ev.record()                                            # end of this step's work on the calling stream
+            self._pace.append(ev)
 
     def _training_step_body(self, st, batch, red_g, red_d):
         ta = self.train_args
@@ -323,6 +345,7 @@ class OptiSpeech(nn.Module):
         with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):
             (st.loss_g / st.scale).backward()
         st.loss_g = None
+        self._g_done_event = torch.cuda.current_stream().record_event() if _D_AFTER_G else None
         if _SYNC_AFTER_G:                                  # diagnostic (tools/race2.sh): drain the device between the phases
             torch.cuda.synchronize()
 
@@ -343,6 +366,10 @@ class OptiSpeech(nn.Module):
         keep_ranges = getattr(red_d, "eager_ranges", True)
         if shared and red_d is not None:
             red_d.eager_ranges = False
+        if _D_AFTER_G and st.pre is not None:
+            # experiment knob: the discriminator phase's forward starts only after the generator's backward has drained from the
+            # calling stream (instead of as soon as the waves exist)
+            st.pre = (st.pre[0], self._g_done_event if self._g_done_event is not None else torch.cuda.current_stream().record_event())
         try:
             loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre,
                                           replay=self.replay_disc_forward and self.train_args.cache_generator_outputs)
@@ -377,7 +404,8 @@ class OptiSpeech(nn.Module):
     def _disc_phase_stream(self):
         """Context manager: make the discriminator-phase stream current, ordered after the calling stream's work so far."""
         if self._dstream is None:
-            self._dstream = torch.cuda.Stream(device=self.device)
+            from .. import lanes
+            self._dstream = lanes.stream("dphase", self.device) if lanes.managed() else torch.cuda.Stream(device=self.device)
         self._dstream.wait_stream(torch.cuda.current_stream())
         return torch.cuda.stream(self._dstream)
 

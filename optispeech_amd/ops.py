@@ -33,6 +33,8 @@ def _want(p):
 # otherwise hand their memory to the next kernel of the calling stream while the side stream still reads it).
 import os as _os
 
+#: HIP priority of the generator-side helper streams (vocoder, weight-gradient side streams, CTC side stream)
+_CHAIN_PRIORITY = int(_os.environ.get("OSP_PRIO_CHAIN", "0"))
 _WG = {"on": _os.environ.get("OSP_WGRAD_STREAM", "1") != "0", "sides": {}, "used": [], "queued": False, "pending": [], "done": [],
        "regions": 0, "every": int(_os.environ.get("OSP_WGRAD_FLUSH", "1"))}
 
@@ -44,8 +46,9 @@ class _Side:
     calling streams and relied on hipStreamWaitEvent capturing the record at call time)."""
     __slots__ = ("stream", "raw", "events", "pos")
 
-    def __init__(self, dev):
-        self.stream = torch.cuda.Stream(device=dev)
+    def __init__(self, dev, name="wg_other"):
+        from . import lanes
+        self.stream = lanes.stream(name, torch.device("cuda", dev)) if lanes.managed() else torch.cuda.Stream(device=dev, priority=_CHAIN_PRIORITY)
         self.raw = self.stream.cuda_stream
         self.events, self.pos = [], 0
 
@@ -69,7 +72,10 @@ def _flush_wgrad():
     raw = _lib._raw_stream(dev)
     side = _WG["sides"].get((dev, raw))
     if side is None:
-        side = _WG["sides"][(dev, raw)] = _Side(dev)
+        # (which calling stream this is decides the side stream's lane: the default stream = the acoustic model's, the vocoder's)
+        vs = _named.get(("vocoder", dev))
+        name = "wg_main" if raw == 0 else ("wg_voc" if (vs is not None and vs.cuda_stream == raw) else "wg_other")
+        side = _WG["sides"][(dev, raw)] = _Side(dev, name)
     if side not in _WG["used"]:
         _WG["used"].append(side)
     ev = side.next_event()
@@ -614,7 +620,8 @@ _pending_side = []
 def _side_stream(device):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=key)
+        from . import lanes
+        _side_streams[key] = lanes.stream("ctc", torch.device("cuda", key)) if lanes.managed() else torch.cuda.Stream(device=key, priority=_CHAIN_PRIORITY)
     return _side_streams[key]
 
 
@@ -655,19 +662,20 @@ class AlignLossFn(torch.autograd.Function):
         # loss sum); the gradient saved here is only read in backward, i.e. after that join.
         side = _side_stream(lp.device)
         ev = _side_events(lp.device)
-        # hand-over and launches go through the C ABI on raw stream handles (no torch stream switch): a call tape records them
-        lib = _lib.lib()
-        lib.call("osp_stream_handover", ev[0].cuda_event, side.cuda_stream)
-        keep = _lib._STREAM_OVERRIDE[0]
-        _lib._STREAM_OVERRIDE[0] = side.cuda_stream
-        try:
+        # fork through the C ABI on raw handles (a call tape records it); the launches run with the side stream CURRENT, so that
+        # everything they allocate -- including the recursion's workspace, which dies inside K.forwardsum_ctc -- belongs to the
+        # side stream's pool: allocated under the calling stream it would be handed to the calling stream's next allocation while
+        # the recursion is still writing it (found as non-finite duration-predictor gradients in round 4)
+        _lib.lib().call("osp_stream_handover", ev[0].cuda_event, side.cuda_stream)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
             loss_item, grad = K.forwardsum_ctc(lp, x_len, y_len, want_grad=need)
             fs = K.sum_scaled(loss_item, 1.0 / B)
-        finally:
-            _lib._STREAM_OVERRIDE[0] = keep
-        for t in (lp, x_len, y_len, loss_item, fs, grad):
+        for t in (lp, x_len, y_len):
+            t.record_stream(side)
+        for t in (fs, grad):
             if t is not None:
-                t.record_stream(side)                              # (allocated under the calling stream, used on the side stream)
+                t.record_stream(main)
         _pending_side.append((side, ev[1]))
         if need:
             ctx.save_for_backward(grad, path, y_len)
@@ -879,7 +887,11 @@ _named = {}
 def _named_stream(key, device):
     k = (key, torch.device(device).index)
     if k not in _named:
-        _named[k] = torch.cuda.Stream(device=device)
+        from . import lanes
+        from .model.discriminator import _skew
+        _skew(device, "OSP_SKEW_" + str(key).upper())
+        _named[k] = (lanes.stream("voc", device) if (lanes.managed() and key == "vocoder")
+                     else torch.cuda.Stream(device=device, priority=_CHAIN_PRIORITY))
     return _named[k]
 
 

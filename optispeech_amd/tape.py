@@ -37,9 +37,18 @@ _STATS = {"recorded": 0, "replayed": 0, "poisoned": 0, "calls_replayed": 0}
 _WARNED = set()
 
 
+_PACE = [False]
+
+
 def fast():
     """The ``_ospfast`` module (None when it is not built: tapes are then unavailable and every region runs eagerly)."""
-    return _lib.lib()._fast
+    f = _lib.lib()._fast
+    if f is not None and not _PACE[0]:
+        _PACE[0] = True
+        ns = int(os.environ.get("OSP_TAPE_PACE_NS", "0"))
+        if ns and hasattr(f, "tape_set_pace"):
+            f.tape_set_pace(ns)
+    return f
 
 
 def available():
@@ -349,6 +358,13 @@ class Recorder:
             return None
         ncalls, npatches, names, streams = fast().tape_info(self.cap)
         _STATS["recorded"] += 1
+        if os.environ.get("OSP_TAPE_DUMP", "0") == "1":
+            import collections
+            per = collections.Counter("current" if st is None else hex(st) for st in streams)
+            print(f"[tape] {self.label}: {ncalls} calls, {npatches} patches, {self.rerouted} re-routed ATen ops, streams {dict(per)}", flush=True)
+            if os.environ.get("OSP_TAPE_DUMP_CALLS", "0") == "1":
+                for n, st in zip(names, streams):
+                    print(f"[tape]    {'current' if st is None else hex(st):>14s} {n}", flush=True)
         # aliases taken NOW (inside the caller's Function.forward the outputs carry no autograd history yet): the objects handed to
         # the caller get a grad_fn later, and holding those would pin the first step's graph
         return Region(self.cap, _alias(outs), len(self.inputs), ncalls,

@@ -14,7 +14,13 @@ batch = synthetic_batch(32, 128, 800, cfg, seed=1234, device="cuda")
 m.optimizers()
 m.graph_steps = os.environ.get("GRAPH", "0") == "1"
 n = int(os.environ.get("STEPS", "20"))
-for i in range(3 + n):
+import time
+m.pipeline_steps = os.environ.get("OSP_PIPELINE_STEPS", "0") == "1" or m.pipeline_steps
+for i in range(3):
     m.training_step(batch, i)
 torch.cuda.synchronize()
-print("done", 3 + n, "steps")
+t0 = time.perf_counter()
+for i in range(3, 3 + n):
+    m.training_step(batch, i)
+torch.cuda.synchronize()
+print("done", 3 + n, "steps;", round((time.perf_counter() - t0) / n * 1e3, 2), "ms per step over the last", n)
