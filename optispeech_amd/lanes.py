@@ -19,9 +19,12 @@ import torch
 N_LANES = 4
 DEPTH = 7                      # pool entries per lane
 
-#: lane per logical stream (None = an unmanaged stream from torch's pool, as before round 4)
-DEFAULT = {"voc": None, "ctc": None, "wg_main": None, "wg_voc": None, "wg_other": None, "p0": None, "p1": None, "p2": None, "p3": None,
-           "p4": None, "r0": None, "r1": None, "r2": None, "spec": None, "dphase": None}
+#: lane per logical stream (None = an unmanaged stream from torch's pool, as before round 4).  The table is the best of a random search
+#: (36 balanced deals) plus a local search around the winner (30 one / two-stream mutations), each candidate = one `bench.py` run:
+#: 16.65-16.81 ms / step in five repeats against 17.5-17.7 for the unmanaged assignment on the same boxes; the 70 candidates span
+#: 16.7 ... 20.3 ms (profiles/r04_lane_search.txt).  OSP_LANES="" with OSP_LANES_OFF=1 gives the unmanaged streams back.
+DEFAULT = {"voc": 1, "ctc": 1, "wg_main": 3, "wg_voc": 0, "wg_other": None, "p0": 3, "p1": 1, "p2": 2, "p3": 0,
+           "p4": 3, "r0": 1, "r1": 0, "r2": 2, "spec": 0, "dphase": 1}
 
 _pool = {}
 _taken = {}
@@ -32,6 +35,8 @@ def table():
     global _table
     if _table is None:
         t = dict(DEFAULT)
+        if os.environ.get("OSP_LANES_OFF", "0") == "1":
+            t = {k: None for k in t}
         for item in os.environ.get("OSP_LANES", "").split(","):
             if ":" in item:
                 k, v = item.split(":")

@@ -11,6 +11,16 @@ fixed = os.environ.get("CANDS")
 if fixed:
     for i, c in enumerate(fixed.split(";")):
         cands.append((f"given{i}", c))
+base = os.environ.get("BASE")
+if base:
+    b = dict(kv.split(":") for kv in base.split(","))
+    cands.append(("base", base)); cands.append(("base_again", base))
+    for i in range(n):
+        a = dict(b)
+        for nm in rnd.sample(names, rnd.choice([1, 1, 2])):
+            a[nm] = str(rnd.randrange(4))
+        cands.append((f"mut{i}", ",".join(f"{k}:{v}" for k, v in a.items())))
+    n = 0
 for i in range(n):
     # the eight stacks: a random balanced deal (two per lane); everything else uniformly random
     deal = [0, 0, 1, 1, 2, 2, 3, 3]
@@ -23,6 +33,8 @@ os.makedirs(out, exist_ok=True)
 res = []
 for tag, lanes in cands:
     env = dict(os.environ, OSP_LANES=lanes, **extra)
+    if tag == "unmanaged":
+        env["OSP_LANES_OFF"] = "1"
     r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-infer", "--no-am-only"], env=env, capture_output=True, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
