@@ -26,7 +26,8 @@ B, T_TEXT, T_MEL = 32, 128, 800
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r03_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/)
+PMC_SUMMARY = "r04_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/): TCC traffic / L2 hit
+PMC_MFMA = "r04_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM pass (tools/pmc_mfma.sh): matrix-pipe busy share per symbol
 
 
 def parse():
@@ -40,9 +41,10 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="utterances per CPU-baseline step (32 = the configuration the GPU number is quoted on, SURVEY 8(d))")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps (SURVEY 8(d): 3 warm + 5 timed)")
     ap.add_argument("--cpu-warm", type=int, default=3, help="untimed CPU-baseline steps")
-    ap.add_argument("--cpu-threads", type=str, default="8",
-                    help="thread counts tried for the CPU baseline, comma separated (SURVEY 8(d): 8; the port does not scale past ~8 threads)")
-    ap.add_argument("--cpu-budget", type=float, default=150.0,
+    ap.add_argument("--cpu-threads", type=str, default="8,16,32",
+                    help="thread counts tried for the CPU baseline, comma separated; every figure is kept in `sample` (VERDICT r03: the sweep "
+                         "8, 16, 32 -- the port does not scale past ~8 threads, 'all' 256 hardware threads measured 5 frames/s)")
+    ap.add_argument("--cpu-budget", type=float, default=180.0,
                     help="wall-clock budget in seconds for the CPU baseline: the 3 + 5 protocol is cut short (and says so) when the host is slow")
     ap.add_argument("--cpu-full", action="store_true", help="no wall-clock budget: the full protocol whatever it takes")
     ap.add_argument("--graph", action="store_true",
@@ -56,6 +58,10 @@ def parse():
                          "the device runs the graph-launched chains ~1 ms slower than the eagerly launched ones on ROCm 7.2 "
                          "(23.6 vs 22.5 ms), so it is off by default")
     ap.add_argument("--ragged", action="store_true", help="ragged lengths (BASELINE.md section 3 variant)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the GLOBAL batch stays 32 utterances, rank r takes rows [32 r / N, 32 (r + 1) / N) "
+                         "(north_star's '>= 6x strong scaling at 8 GPUs'); default is weak scaling, 32 utterances per GPU")
+    ap.add_argument("--no-transformer", action="store_true", help="skip the configs[3] (Transformer backbone) secondary step figure")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial schedule: do not issue the discriminator phase from its own stream (OptiSpeech.pipeline_steps)")
     ap.add_argument("--backbone", choices=["convnext", "transformer"], default="convnext",
@@ -109,26 +115,6 @@ class KernelTimer:
                 e1.record()
                 timer.events.append((hit[0], hit[1], e0, e1))
         lib.call = call
-        # grouped launches (opt-in, OSP_DISC_GROUPED=1) go through _lib.call_rows: same bracket
-        orig_rows = _lib.call_rows
-
-        def call_rows(name, rows):
-            if not timer.enabled:
-                return orig_rows(name, rows)
-            note(buf, 128, ctypes.byref(fl))
-            note_bytes(ctypes.byref(by))
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig_rows(name, rows)
-            note(buf, 128, ctypes.byref(fl))
-            note_bytes(ctypes.byref(by))
-            sym = buf.value.decode()
-            if sym and fl.value > 0:
-                timer.bytes["mfma:" + sym] = timer.bytes.get("mfma:" + sym, 0.0) + by.value
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record()
-                timer.events.append(("mfma:" + sym, fl.value, e0, e1))
-        _lib.call_rows = call_rows
 
     def summary(self):
         """{key: (work, ms, launches)}"""
@@ -219,7 +205,7 @@ def cpu_baseline_sweep(nb, timed_steps, thread_list, warm=1, budget_s=None):
             "host_cpus": have}
 
 
-def synthesise_rtf(model, dev, n_sent=64, seed=7):
+def synthesise_rtf(model, dev, n_sent=64, seed=7, timer=None, cpu=True, cpu_sentences=8, cpu_threads=8):
     """BASELINE config[4]: synthesise() on 64 batched sentences; durations overridden to U{4..8} frames/phoneme because
     random-init weights predict degenerate durations.  RTF as the reference defines it
     (generator/__init__.py:285-288): (t_acoustic + t_vocoder) / (padded wav length / sample_rate)."""
@@ -236,6 +222,54 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7):
         model.generator.graph_decode = graph
         res[graph] = [model.synthesise(inputs, durations_override=dur) for _ in range(4)][-1]
     model.generator.graph_decode = False
+    # roofline of the decode: one more eager call with every entry-point call bracketed by HIP events (KernelTimer); the dominant
+    # matrix-core symbol by total time, its algorithmic flops / bytes as the library's dispatcher reports them
+    roof = None
+    if timer is not None:
+        from optispeech_amd import tape as _tape
+        keep_tape, _tape.ENABLED = _tape.ENABLED, False
+        timer.events.clear()
+        timer.bytes = {}
+        timer.enabled = True
+        model.synthesise(inputs, durations_override=dur)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        _tape.ENABLED = keep_tape
+        mf = {k[5:]: v for k, v in timer.summary().items() if k.startswith("mfma:") and v[1] > 0}
+        if mf:
+            tot_ms = sum(v[1] for v in mf.values())
+            dom = max(mf, key=lambda k: mf[k][1])
+            fl, ms, n = mf[dom]
+            nbytes = timer.bytes.get("mfma:" + dom, 0.0)
+            ach = fl / (ms * 1e-3) / 1e12
+            hbm_tf = (fl / nbytes) * PEAK_HBM_GBS * 1e9 / 1e12 if nbytes else None
+            roof = {"bound": "mfma", "symbol": dom, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_BF16_MFMA_TFLOPS, "launches": n, "avg_launch_us": ms / n * 1e3, "ms_per_call": ms,
+                    "algorithmic_flop_per_launch": fl / n, "algorithmic_bytes_per_launch": nbytes / n if nbytes else None,
+                    "hbm_gbs": nbytes / (ms * 1e-3) / 1e9 if nbytes else None, "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS if nbytes else None,
+                    "hbm_bound_tflops": hbm_tf, "matrix_core_ms_per_call_all_symbols": tot_ms,
+                    "how": "HIP events around every entry-point call of one eager synthesise() of the same 64 sentences; symbol, flops and "
+                           "algorithmic bytes from the library's dispatcher (osp_kernel_note_host)"}
+        timer.events.clear()
+    # BASELINE configs[4] reads "RTF vs CPU": the oracle's synthesise (the CPU port of generator/__init__.py:194-301) on a bounded sample
+    # of the SAME sentences (the first `cpu_sentences`, same duration override, same weights), RTF by the same definition
+    cpu_fig = None
+    if cpu:
+        from oracle import generator as OG
+        keep_thr = torch.get_num_threads()
+        torch.set_num_threads(cpu_threads)
+        P = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("generator.")}
+        xs, xl, ds = x[:cpu_sentences], x_len[:cpu_sentences], dur[:cpu_sentences]
+        tmax = int(xl.max())
+        t0 = time.perf_counter()
+        oc = OG.synthesise(P, xs[:, :tmax], xl, 1.0, 1.0, 1.0, durations_override=ds[:, :tmax])
+        t_cpu = time.perf_counter() - t0
+        torch.set_num_threads(keep_thr)
+        pad_s = oc["wav"].shape[-1] / model.sample_rate
+        cpu_fig = {"rtf": t_cpu / pad_s, "seconds": t_cpu, "sentences": cpu_sentences, "threads": cpu_threads, "kind": "port",
+                   "padded_audio_s": pad_s, "total_audio_s": float(oc["wav_lengths"].sum()) / model.sample_rate,
+                   "sample": f"oracle.generator.synthesise on the first {cpu_sentences} of the 64 sentences (same weights, same duration "
+                             f"override), {cpu_threads} threads, one call; RTF = wall time / padded audio length of that sub-batch"}
     model.train()
     o, oe = res[True], res[False]
     same = bool(torch.equal(torch.as_tensor(o.wav), torch.as_tensor(oe.wav)))
@@ -244,7 +278,8 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7):
             "eager": {"rtf": oe.rtf, "latency_ms": oe.latency}, "graph_output_equals_eager": same,
             "rtf": o.rtf, "am_rtf": o.am_rtf, "v_rtf": o.v_rtf, "latency_ms": o.latency, "sentences": n_sent,
             "padded_audio_s": o.wav.shape[-1] / model.sample_rate, "total_audio_s": audio_s,
-            "aggregate_audio_s_per_s": audio_s / (o.latency * 1e-3)}
+            "aggregate_audio_s_per_s": audio_s / (o.latency * 1e-3), "roofline": roof, "cpu_rtf": cpu_fig,
+            "rtf_vs_cpu": (cpu_fig["rtf"] / o.rtf) if cpu_fig else None}
 
 
 def _selectors(precision):
@@ -359,9 +394,19 @@ def main():
     torch.manual_seed(1234)                                   # configs/train.yaml:53; same init on every rank
     rng.manual_seed(1234, rank)
     cfg = ModelConfig(backbone=a.backbone)
-    model = make_optispeech(cfg, batch_size=B, pretraining_steps=0).to(dev).train()
-    batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
+    if a.strong:
+        assert B % world == 0, f"--strong splits {B} utterances over {world} ranks"
+    Bl = B // world if a.strong else B                       # utterances per rank
+    model = make_optispeech(cfg, batch_size=Bl, pretraining_steps=0).to(dev).train()
+    if a.strong:                                              # the SAME 32 utterances whatever N is: rank r owns rows [r Bl, (r + 1) Bl)
+        full = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234, ragged=a.ragged, device=dev)
+        batch = {k: (v[rank * Bl:(rank + 1) * Bl] if (torch.is_tensor(v) or isinstance(v, list)) else v) for k, v in full.items()}
+        batch = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    else:
+        batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
     model.optimizers()
+    for r_ in model._reducers:
+        r_.measure = world > 1
     # production schedule: the eager multi-stream step (eight sub-discriminator streams, vocoder stream, CTC side stream), its
     # discriminator phase issued from a second calling stream (pipeline_steps) so that step n+1's generator forward overlaps step
     # n's discriminator backward.  --graph times the hipGraph replay of the same step instead (optispeech_amd/graphs.py)
@@ -383,12 +428,23 @@ def main():
     for i in range(a.warmup):
         model.training_step(batch, 2 + i)
     sync()
+    for r_ in model._reducers:
+        r_.exposed_ms()                                       # drop the warm-up's brackets
     t0 = time.perf_counter()
     for i in range(a.steps):
         model.training_step(batch, a.warmup + i)
     t_enq = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    comm_exposed = None
+    if world > 1:
+        # per rank: how long the step's streams stood still in GradReducer.wait() (generator gradients before AdamW(G), discriminator
+        # gradients before AdamW(D)) -- 0 when the all-reduces finished under the compute they overlap
+        mine = torch.tensor([r_.exposed_ms() / a.steps for r_ in model._reducers], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        comm_exposed = {"generator_ms_per_step": [float(t[0]) for t in allr], "discriminator_ms_per_step": [float(t[1]) for t in allr],
+                        "how": "HIP events around GradReducer.wait() on the waiting stream, per rank, averaged over the timed steps"}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -433,7 +489,7 @@ def main():
         sync()
         am_dt = (time.perf_counter() - t1) / 10
         model.train_args.pretraining_steps = keep
-        am_only = {"ms_per_step": am_dt * 1e3, "mel_frames_per_s": world * B * T_MEL / am_dt, "steps": 10,
+        am_only = {"ms_per_step": am_dt * 1e3, "mel_frames_per_s": world * Bl * T_MEL / am_dt, "steps": 10,
                    "note": "pre-training regime (global_step < pretraining_steps): acoustic-model losses only, per-rank wall time of rank 0"}
     # secondary figure: the discriminator phase re-using the forward that the generator phase of the same step ran on the same
     # waves with the same (not yet updated) discriminator weights (OptiSpeech.replay_disc_forward; bit-identical values, the
@@ -497,14 +553,44 @@ def main():
                               "(wav_hat / mel <= 1e-3 vs the reference goldens, tests/test_gpu_mixed.py), only the MPD / MRD "
                               "discriminator stacks on the bf16 kernels"}
     ms_per_step = dt / a.steps * 1e3
-    value = world * B * T_MEL / (dt / a.steps)
+    value = world * Bl * T_MEL / (dt / a.steps)
+    # what the host needs to ENQUEUE a step when the device never pushes back: the same step on a 2-utterance batch (GPU work
+    # negligible).  `host_enqueue_ms_per_step` of the timed region includes the time the host is blocked behind a full device queue.
+    host_free = None
+    if secondary and not a.no_am_only:
+        small = synthetic_batch(2, 16, 72, cfg, seed=1, device=dev)
+        for i in range(6):
+            model.training_step(small, 900 + i)
+        sync()
+        t5 = time.perf_counter()
+        for i in range(20):
+            model.training_step(small, 910 + i)
+        host_free = (time.perf_counter() - t5) / 20 * 1e3
+        sync()
+    # secondary figure: BASELINE configs[3], the Transformer backbone at the same batch (eager multi-stream step, same schedule)
+    tf_fig = None
+    if secondary and not a.no_am_only and not a.no_transformer and a.backbone == "convnext" and a.precision == "bf16":
+        tcfg = ModelConfig(backbone="transformer")
+        tm = make_optispeech(tcfg, batch_size=B, pretraining_steps=0).to(dev).train()
+        tm.pipeline_steps = model.pipeline_steps
+        tb = synthetic_batch(B, T_TEXT, T_MEL, tcfg, seed=1234, ragged=a.ragged, device=dev)
+        for i in range(5):
+            tm.training_step(tb, i)
+        sync()
+        t6 = time.perf_counter()
+        for i in range(10):
+            tm.training_step(tb, 5 + i)
+        sync()
+        t_dt = (time.perf_counter() - t6) / 10
+        tf_fig = {"ms_per_step": t_dt * 1e3, "mel_frames_per_s": B * T_MEL / t_dt, "steps": 10,
+                  "workload": "configs[3]: Transformer backbone (2 heads, 1 024 linear units, 4 blocks, fused training attention), batch=32, "
+                              "T_text=128, T_mel=800, full GAN step"}
+        del tm, tb
 
     if rank == 0:
         # Every matrix-core symbol of the step, timed in the 3 serialised steps above and classified by the library's own
         # dispatcher (KernelTimer); the roofline object is the symbol with the LARGEST TOTAL TIME, the others are listed beside it.
-        DESCR = {"conv_gemm_bf16_glds8e_grp_kernel": "8 waves, 256x256 tiles, direct-to-LDS, GROUPED over the five DiscriminatorP stacks: 512->1024 / 1024->1024 forward + fused-phase dgrad (1 020 tiles per launch)",
-                 "conv_gemm_bf16_glds_grp_kernel": "4 waves, 128x128 tiles, direct-to-LDS, grouped over the stacks of a family: the remaining MPD conv-GEMM forward + dgrad launches (N >= 128)",
-                 "conv_gemm_bf16_glds_n64_grp_kernel": "4 waves, 128x64 tiles, direct-to-LDS, grouped over the three DiscriminatorR stacks (64-channel layers)",
+        DESCR = {
                  "conv_gemm_bf16_glds8e_kernel": "8 waves, 256x256 tiles, direct-to-LDS: DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
                  "conv_gemm_bf16_glds_kernel": "4 waves, 128x128 tiles, direct-to-LDS: the remaining MPD / MRD conv-GEMM forward + dgrad launches (N >= 128)",
                  "conv_gemm_bf16_glds_n64_kernel": "4 waves, 128x64 tiles, direct-to-LDS: the 64-channel DiscriminatorR layers",
@@ -560,6 +646,21 @@ def main():
             roof["traffic"] = pj.get("traffic_bytes_per_launch")
             roof["l2_hit_rate"] = pj.get("l2_hit_rate")
             roof["traffic_unit"] = "bytes/launch, read from profiles/" + PMC_SUMMARY + " (separate --pmc pass: TCC_EA0 read x 128 B + write x 64 B)"
+        busy = os.path.join(ROOT, "profiles", PMC_MFMA)
+        if a.precision != "f32" and os.path.exists(busy) and dom:
+            with open(busy) as fh:
+                bj = json.load(fh).get("kernels", {})
+            for sym, row in roof["mfma_kernels"].items():
+                hit = bj.get(sym) or bj.get(sym.split("<")[0])
+                if hit and "mfma_busy" in hit:
+                    row["mfma_busy"] = hit["mfma_busy"]
+                    for kk in ("waves_parked", "waves_issue_stalled", "waves_issuing"):
+                        if kk in hit:
+                            row[kk] = hit[kk]
+            hit = bj.get(dom) or bj.get(dom.split("<")[0]) or {}
+            roof["mfma_busy"] = hit.get("mfma_busy")
+            roof["mfma_busy_unit"] = ("share of SIMD time the matrix pipe is busy: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x kernel clocks), read "
+                                      "from profiles/" + PMC_MFMA + " (separate rocprofv3 --pmc passes, tools/pmc_mfma.sh)")
         # HBM-bound kernels north_star names (A1a class): algorithmic bytes / measured time vs the 8 TB/s peak
         roof["hbm_kernels"] = hbm_kernel_rooflines(model, dev) if a.precision == "bf16" else {}
         cpu = None
@@ -571,21 +672,22 @@ def main():
                                         + (", acoustic model + vocoder forward / backward replayed from hipGraph segments" if model.graph_segments else "")))
         out = {"metric": "mel-frames/sec/GPU (train step) + RTF (synthesize), ConvNeXt@22.05kHz, 1/2/4/8 MI355X",
                "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": a.precision, "data": "synthetic",
-               "config": {"workload": ("configs[3]: Transformer backbone" if a.backbone == "transformer" else "configs[1]: ConvNeXt backbone") + ", synthetic LJSpeech-shaped batch=32 per GPU "
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
+               "dtype": a.precision, "data": "synthetic", "comm_ms_exposed": comm_exposed,
+               "config": {"workload": ("configs[3]: Transformer backbone" if a.backbone == "transformer" else "configs[1]: ConvNeXt backbone") + ", synthetic LJSpeech-shaped batch=" + (f"32 GLOBAL ({Bl} per GPU, --strong) " if a.strong else "32 per GPU ") +
                                       "(T_text=128, T_mel=800, 22.05 kHz), full GAN training step "
                                       "(G phase + D phase + 2x AdamW), train mode",
-                          "global_batch": B * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}", "schedule": sched,
+                          "global_batch": Bl * world, "T_text": T_TEXT, "T_mel": T_MEL, "parallelism": f"dp{world}", "schedule": sched,
                           "lengths": "ragged" if a.ragged else "fixed"},
                "per_gpu": value / world, "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
+               "host_enqueue_ms_per_step_unblocked": host_free, "transformer_step": tf_fig,
                "call_tapes": {"enabled": bool(keep_tape and _tape.available()), **tape_stats,
                               "note": "regions of the step recorded once as C-ABI call lists and replayed from C (optispeech_amd/tape.py); "
                                       "counts cover set-up + warm-up + timed steps"},
                "roofline": roof, "cpu_baseline": cpu,
                "am_only_step": am_only, "replay_disc_forward_step": replay, "graph_replay_step": graph_fig,
                "parity_mode_step": parity_fig,
-               "synthesise": None if (a.no_infer or not secondary) else synthesise_rtf(model, dev),
+               "synthesise": None if (a.no_infer or not secondary) else synthesise_rtf(model, dev, timer=timer, cpu=not a.no_cpu_baseline),
                "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")}}
         print(json.dumps(out))
     if world > 1:

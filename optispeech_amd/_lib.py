@@ -57,7 +57,7 @@ class _Lib:
         self._fn = {}
         self._sigs = _header_signatures()
         # native argument marshalling (optispeech_amd/fastcall.py): same library, ~5x less interpreter time per call
-        self._fcall, self._fidx, self._fcall_rows, self._fast = None, {}, None, None
+        self._fcall, self._fidx, self._fast = None, {}, None
         if os.environ.get("OSP_CTYPES_CALL", "0") != "1":
             fast = _load_fast()
             if fast is not None and fast.HEADER_SHA1 != _header_sha1():
@@ -69,7 +69,6 @@ class _Lib:
                 fast.set_guard(os.environ.get("OSP_FAST_CALL", "0") != "1")
                 self._fast = fast
                 self._fcall = fast.call
-                self._fcall_rows = getattr(fast, "call_rows", None)
                 self._fidx = {n: fast.index(n) for n in self._sigs if fast.index(n) is not None}
 
     def fn(self, name):
@@ -124,30 +123,6 @@ class _Lib:
             if any(isinstance(a, T) and not a.is_cuda for a in args):
                 raise OspError(f"{name}: tensor argument is not on the GPU")
             raise OspError(f"{name} failed ({rc}): {self.cdll.osp_last_error().decode()}")
-
-
-def call_rows(name, rows):
-    """Grouped entry points ``name(rows_host, count, stream)``: rows = list of argument tuples (tensors / None / int / float)."""
-    L = lib()
-    if _RECORD[0] is not None:
-        raise OspError(f"{name}: grouped launches cannot be deferred (ops.side_wgrad region)")
-    idx = L._fidx.get(name)
-    dev = _cur_device()
-    stream = _STREAM_OVERRIDE[0] or _raw_stream(dev)
-    if idx is not None and hasattr(L, "_fcall_rows") and L._fcall_rows is not None:
-        rc = L._fcall_rows(idx, stream, rows)
-    else:                                                   # ctypes: build the int64 table with numpy
-        import struct
-        import numpy as np
-        tab = np.empty((len(rows), len(rows[0])), dtype=np.int64)
-        for r, row in enumerate(rows):
-            for c, v in enumerate(row):
-                tab[r, c] = (0 if v is None else v.data_ptr() if isinstance(v, torch.Tensor)
-                             else struct.unpack("<I", struct.pack("<f", v))[0] if isinstance(v, float) else int(v))
-        f = L._fn.get(name) or L.fn(name)
-        rc = f(tab.ctypes.data, len(rows), stream)
-    if rc != 0:
-        raise OspError(f"{name} failed ({rc}): {L.cdll.osp_last_error().decode()}")
 
 
 #: reject host tensors before launching (a host pointer would fault on the device); OSP_FAST_CALL=1 drops the check

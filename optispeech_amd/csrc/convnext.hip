@@ -150,7 +150,7 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
     auto pick_runs = [&](int fr) -> int {
         const int64_t rmin = cdiv(T, fr);
         static int balance = -1;
-        if (balance < 0) { const char* e = getenv("OSP_DWCONV_BALANCE"); balance = (e && atoi(e) == 0) ? 0 : 1; }
+        if (balance < 0) { balance = 1; }
         if (!balance || nch != 1) return (int)rmin;
         const int64_t resident = 4096, total = B * rmin;
         const int64_t rounds = cdiv(total, resident);
@@ -159,7 +159,7 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
     };
 #define L(N, F) do { const int R_ = pick_runs(F); hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * (int64_t)R_, 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, (int)C, R_); } while (0)
     static int fr1 = -1;
-    if (fr1 < 0) { const char* e = getenv("OSP_DWCONV_FR"); fr1 = e ? atoi(e) : 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
+    if (fr1 < 0) { fr1 = 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
     if (nch == 1) { if (fr1 == 8) L(1, 8); else if (fr1 == 4) L(1, 4); else L(1, 16); } else if (nch == 2) L(2, 8); else if (nch == 3) L(3, 4); else L(4, 4);
 #undef L
     OSP_LAUNCH_CHECK();
@@ -406,7 +406,7 @@ extern "C" int osp_layernorm_bwd(const float* dy, const float* xin, const float*
     OSP_CHECK_ARG(!ws || ws_blocks > 0, "ws needs ws_blocks > 0");
     const int64_t blocks = cdiv(rows, 4 * FRAMES);   // FRAMES rows per wave
     static int64_t lnb_cap = 0;
-    if (!lnb_cap) { const char* e = getenv("OSP_LNBWD_WG"); lnb_cap = e ? atoll(e) : 256; }      // atomics path: tools/lndw_probe.py at 32 x 800 x 256, caps 256 / 512 / 1024 = 25.0 / 26.8 / 31.3 us
+    if (!lnb_cap) { lnb_cap = 256; }      // atomics path: tools/lndw_probe.py at 32 x 800 x 256, caps 256 / 512 / 1024 = 25.0 / 26.8 / 31.3 us
     const bool two_stage = ws && dlnw;
     const int64_t cap = two_stage ? ws_blocks : (dlnw ? lnb_cap : 4096);
     dim3 grid((unsigned)(blocks < cap ? blocks : cap));
@@ -652,134 +652,6 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void ln_dwconv7_bwd_kernel(const
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Round 3: the same fused backward as a TILE kernel.  The run kernel above re-reads 2.5 rows per frame of dh / xhat / x (a run of
-// FR = 4 frames needs FR + 6 rows of each), keeps three 10-row windows in registers (248 VGPRs = 8 waves per CU) and walks its
-// three load bursts one after the other: 52-55 % of the HBM roofline even without parameter gradients.  Here a workgroup of 8
-// waves owns a tile of up to LT_ROWS - 6 consecutive frames of one utterance and shares the halo through LDS:
-//   phase 1  the tile's nrows + 6 window rows are dealt round-robin to the waves; a wave requests all its dh / xhat / x rows at
-//            once, rebuilds dc (two wave reductions per row) and parks dc and x in LDS -- every input row is fetched ONCE per tile
-//            ((26 + 6) / 26 = 1.23 rows per frame instead of 2.5);
-//   phase 2  the owned frames are dealt round-robin again: dx[t] = dres[t] + sum_j w[j] dc[t - j + 3] and the tap gradients
-//            ddw[j] += dc[t] x[t + j - 3] read dc / x rows out of LDS (14 ds_read_b128 per frame and lane).
-// No windows in registers: <= 128 VGPRs, two workgroups = 16 waves per CU; while one workgroup computes out of LDS the other
-// one's loads are in flight.  Persistent workgroups (at most 2 per CU), parameter-gradient rows -> per-workgroup partials ->
-// reduce_partials_kernel (no atomics here).  Algorithmic bytes per frame as before: 5 * C * 4.
-#define LT_ROWS 32
-#define LT_NWV 8
-__global__ __launch_bounds__(64 * LT_NWV, 4) void ln_dwconv7_bwd_tile_kernel(const float* __restrict__ dh, const float* __restrict__ xhat,
-                                                             const float* __restrict__ rstd, const float* __restrict__ lnw,
-                                                             const float* __restrict__ x, const float* __restrict__ dw,
-                                                             const float* __restrict__ dres, const float* __restrict__ dres_rowmask,
-                                                             float* __restrict__ dx, float* __restrict__ dlnw, float* __restrict__ dlnb,
-                                                             float* __restrict__ ddw, float* __restrict__ ddb, float* __restrict__ ws,
-                                                             int B, int T, int C, int TR, int tiles_per_utt) {
-    __shared__ __attribute__((aligned(16))) float dcs[LT_ROWS][256];
-    __shared__ __attribute__((aligned(16))) float xs[LT_ROWS][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ch = lane * 4;
-    const bool chan = ch < C;
-    const int chs = chan ? ch : 0;
-    const float invC = 1.0f / (float)C;
-    const float4 gw = chan ? *reinterpret_cast<const float4*>(lnw + chs) : f4zero();
-    // the 7 taps live in LDS (28 VGPRs otherwise: with them the kernel spills at the 128-VGPR budget of 16 waves per CU)
-    __shared__ __attribute__((aligned(16))) float wsm[7][256];
-    if (wave < 7) *reinterpret_cast<float4*>(&wsm[wave][lane * 4]) = chan ? *reinterpret_cast<const float4*>(dw + (int64_t)wave * C + chs) : f4zero();
-    float4 gwt[7], gb = f4zero(), aw = f4zero(), ab = f4zero();
-#pragma unroll
-    for (int j = 0; j < 7; ++j) gwt[j] = f4zero();
-    const bool want_taps = ddw != nullptr;                              // kernel-uniform
-    const int ntiles = B * tiles_per_utt;
-    constexpr int RPW = LT_ROWS / LT_NWV;                               // window rows per wave (4)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_utt, t0 = (tile - b * tiles_per_utt) * TR;
-        const int nrows = min(TR, T - t0);
-        const int64_t base = (int64_t)b * T * C;
-        // ---- phase 1: window row r <-> frame t0 + r - 3, r = wave + LT_NWV * i
-        float4 d[RPW], v[RPW], xr[RPW];
-        float rs[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = wave + LT_NWV * i, t = t0 + r - 3;
-            const bool in = r < nrows + 6 && t >= 0 && t < T;
-            const int64_t off = base + (int64_t)(in ? t : t0) * C + chs;
-            d[i] = *reinterpret_cast<const float4*>(dh + off);
-            v[i] = *reinterpret_cast<const float4*>(xhat + off);
-            xr[i] = *reinterpret_cast<const float4*>(x + off);
-            rs[i] = in ? rstd[(int64_t)b * T + t] : 0.f;              // rows outside the utterance are the conv's zero padding
-            if (!(in && chan)) { d[i] = f4zero(); v[i] = f4zero(); xr[i] = f4zero(); }
-        }
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = wave + LT_NWV * i;
-            if (r >= nrows + 6) continue;                               // wave-uniform
-            const float4 dd = d[i], vv = v[i];
-            if (r >= 3 && r < nrows + 3) {                              // owned frame: LayerNorm parameter gradients
-                aw = f4fma(dd, vv, aw);
-                ab.x += dd.x; ab.y += dd.y; ab.z += dd.z; ab.w += dd.w;
-            }
-            const float4 g = make_float4(dd.x * gw.x, dd.y * gw.y, dd.z * gw.z, dd.w * gw.w);
-            const float m1 = wave_sum(f4sum(g)) * invC;
-            const float m2 = wave_sum(g.x * vv.x + g.y * vv.y + g.z * vv.z + g.w * vv.w) * invC;
-            const float sc = rs[i];
-            const float4 c = chan ? make_float4(sc * (g.x - m1 - vv.x * m2), sc * (g.y - m1 - vv.y * m2), sc * (g.z - m1 - vv.z * m2),
-                                                sc * (g.w - m1 - vv.w * m2)) : f4zero();
-            *reinterpret_cast<float4*>(&dcs[r][lane * 4]) = c;
-            *reinterpret_cast<float4*>(&xs[r][lane * 4]) = xr[i];
-        }
-        __syncthreads();
-        // ---- phase 2: owned frame f <-> window row f + 3.  The residual rows are requested first (all of them, then consumed: the
-        // registers of phase 1 are free again; requesting them before the barrier spilled at the 128-VGPR budget)
-        float4 dr[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int f = wave + LT_NWV * i;
-            const bool in = f < nrows;
-            dr[i] = f4zero();
-            if (dres && in && chan) {
-                const float4 q = *reinterpret_cast<const float4*>(dres + base + (int64_t)(t0 + f) * C + ch);
-                const float rm = dres_rowmask ? dres_rowmask[(int64_t)b * T + t0 + f] : 1.f;
-                dr[i] = make_float4(q.x * rm, q.y * rm, q.z * rm, q.w * rm);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int f = wave + LT_NWV * i;
-            if (f >= nrows) continue;                                   // wave-uniform
-            float4 a = dr[i];
-#pragma unroll
-            for (int j = 0; j < 7; ++j)
-                a = f4fma(*reinterpret_cast<const float4*>(&wsm[j][lane * 4]), *reinterpret_cast<const float4*>(&dcs[f + 6 - j][lane * 4]), a);   // w[j] dc[t - j + 3]
-            if (chan) st_stream(reinterpret_cast<float4*>(dx + base + (int64_t)(t0 + f) * C + ch), a);
-            if (want_taps) {
-                const float4 d0 = *reinterpret_cast<const float4*>(&dcs[f + 3][lane * 4]);                             // dc[t]
-#pragma unroll
-                for (int j = 0; j < 7; ++j) gwt[j] = f4fma(d0, *reinterpret_cast<const float4*>(&xs[f + j][lane * 4]), gwt[j]);   // x[t + j - 3]
-                gb.x += d0.x; gb.y += d0.y; gb.z += d0.z; gb.w += d0.w;
-            }
-        }
-        __syncthreads();                                                // the next tile overwrites dcs / xs
-    }
-    if (!ddw && !dlnw) return;                                          // kernel-uniform
-    // parameter-gradient rows [7 taps | ddb | dlnw | dlnb]: per-wave partials -> LDS (dcs re-used: 8 waves x 256 floats per row),
-    // one row at a time, -> the workgroup's partial row in ws (two-stage reduction) or atomics
-    float* part = ws ? ws + (int64_t)blockIdx.x * 10 * C : nullptr;
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const float4 val = j < 7 ? gwt[j] : j == 7 ? gb : j == 8 ? aw : ab;
-        *reinterpret_cast<float4*>(&dcs[wave][lane * 4]) = val;
-        __syncthreads();
-        float* dst = j < 7 ? (ddw ? ddw + (int64_t)j * C : nullptr) : j == 7 ? ddb : j == 8 ? dlnw : dlnb;
-        if (threadIdx.x < 256 && (int)threadIdx.x < C && (dst || part)) {
-            float sum = 0.f;
-#pragma unroll
-            for (int q = 0; q < LT_NWV; ++q) sum += dcs[q][threadIdx.x];
-            if (part) part[(int64_t)j * C + threadIdx.x] = sum;
-            else atomicAdd(dst + threadIdx.x, sum);
-        }
-        __syncthreads();
-    }
-}
 
 extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const float* rstd, const float* lnw, const float* x,
                                   const float* dw, const float* dres, const float* dres_rowmask, float* dx, float* dlnw, float* dlnb,
@@ -789,32 +661,13 @@ extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const floa
     OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256, "C must be a multiple of 4, <= 256 (wider blocks: osp_layernorm_bwd + osp_dwconv7_bwd)");
     OSP_CHECK_ARG(!ws || ws_blocks > 0, "ws needs ws_blocks > 0");
     static int fr = -1;
-    if (fr < 0) { const char* e = getenv("OSP_LNDW_FR"); fr = e ? atoi(e) : 4; }      // tools/lndw_probe.py at 32 x 800 x 256: FR 4 / 6 / 8 = 41.9 / 49.7 / 50.6 us (8 spills: 256-VGPR cap for two workgroups / CU)
+    if (fr < 0) { fr = 4; }      // tools/lndw_probe.py at 32 x 800 x 256: FR 4 / 6 / 8 = 41.9 / 49.7 / 50.6 us (8 spills: 256-VGPR cap for two workgroups / CU)
     // 256 VGPRs per thread: 8 waves per CU are resident, as one workgroup of 8 waves (256 workgroups: half the atomics per address)
-    // or two of 4 (OSP_LNDW_NWV=4)
+    // (two of 4 measured the same within noise)
     static int nwv = -1, maxwg = -1;
-    if (nwv < 0) { const char* e = getenv("OSP_LNDW_NWV"); nwv = (e && atoi(e) == 4) ? 4 : 8; }
-    if (maxwg < 0) { const char* e = getenv("OSP_LNDW_WG"); maxwg = e ? atoi(e) : 2048 / nwv; }
+    if (nwv < 0) { nwv = 8; }
+    if (maxwg < 0) { maxwg = 2048 / nwv; }
     const bool two_stage = ws && (dlnw || ddw);
-    static int tile_v = -1;
-    // opt-in (OSP_LNDW_TILE=1): measured at 32 x 800 x 256 (profiles/r03_lndw_variants.txt) the tile kernel and the run kernel
-    // are the same speed -- 41.1 vs 41.2 us with atomics, 42.9 vs 42.1 us with the two-stage reduction, 34-35 vs 32 us without
-    // parameter gradients -- although the tile kernel fetches half the rows from L2: neither is bound by L2 / HBM bytes
-    if (tile_v < 0) { const char* e = getenv("OSP_LNDW_TILE"); tile_v = (e && atoi(e) == 1) ? 1 : 0; }
-    if (tile_v) {
-        // tile kernel (round 3): tiles of TR <= LT_ROWS - 6 frames, equal within an utterance; persistent workgroups, 2 per CU
-        const int64_t tpu = cdiv(T, LT_ROWS - 6), TR = cdiv(T, tpu), ntiles = B * tpu;
-        int64_t nb = ntiles < 512 ? ntiles : 512;
-        if (two_stage && nb > ws_blocks) nb = ws_blocks;
-        hipLaunchKernelGGL(ln_dwconv7_bwd_tile_kernel, dim3((unsigned)nb), dim3(64 * LT_NWV), 0, stream, dh, xhat, rstd, lnw, x, dw, dres,
-                           dres_rowmask, dx, dlnw, dlnb, ddw, ddb, two_stage ? ws : nullptr, (int)B, (int)T, (int)C, (int)TR, (int)tpu);
-        if (two_stage) {
-            PartialDst d = {{ddw, ddb, dlnw, dlnb}, {7 * (int)C, (int)C, (int)C, (int)C}};
-            launch_reduce_partials(ws, (int)nb, 10 * (int)C, d, stream);
-        }
-        OSP_LAUNCH_CHECK();
-        return OSP_OK;
-    }
     const int64_t cap = two_stage ? (ws_blocks < maxwg ? ws_blocks : maxwg) : maxwg;
     unsigned nblk = 0;
 #define L(F, W) do { nblk = (unsigned)(cdiv(B * cdiv(T, F), W) < cap ? cdiv(B * cdiv(T, F), W) : cap); \

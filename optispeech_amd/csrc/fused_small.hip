@@ -388,7 +388,7 @@ extern "C" int osp_colsum_prod(const float* a, const float* b, const float* rowf
     // (round 3: ~64 workgroups, not 1024 -- 1024 / 256 / 128 / 64 / 32 workgroups: 35.4 / 27.6 / 15.7 / 11.3 / 11.7 us per launch averaged over a step's 12 launches: every workgroup adds into the SAME C addresses, and same-address atomics serialise at the
     // memory side -- the kernel's tail was proportional to the number of workgroups, see smallcin.hip's two-stage note)
     static int64_t wg_target = 0;
-    if (!wg_target) { const char* e = getenv("OSP_COLSUM_WG"); wg_target = e ? atoll(e) : 64; }
+    if (!wg_target) { wg_target = 64; }
     int64_t rpb = cdiv(M, wg_target);
     rpb = rpb < 8 ? 8 : rpb;
     hipLaunchKernelGGL(colsum_prod_kernel, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream, a, b, rowf, out, M, (int)C, (int)rpb);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_kernel(const GemmB pp
 __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const GemmB pp) {
     conv_gemm_bf16_glds_body<128, 2, 64>(pp, glds_smem, grid_tile_ctx());
 }
-// (the 8-wave 256x256 kernels: gemm_bf16_w8.hip; the grouped launches of a discriminator family: gemm_bf16_grp.hip / _w8.hip)
+// (the 8-wave 256x256 kernels: gemm_bf16_w8.hip)
 
 // C[u, t*c_step + c_off, n] = epi( sum_{j<taps} sum_{c<Cin} A[u, t*a_step + j*a_tapstep + a_off, c] * Bw(n, j, c) )
 // for t < Trows (rows M = utterances * Trows); a tap that leaves [0, Tin) contributes zero.
@@ -247,14 +247,9 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
 
 // Kernel selection + launch for a filled parameter block.  With p.nphase > 0 (fused dgrad phases) the grid's z dimension
 // enumerates the phases and p.M is the largest phase (see GemmB::Phase); batch must then be 1.
-// kind_out (grouped launches): when the dispatcher picks one of the direct-to-LDS kernels for a single problem (batch 1), it
-// does NOT launch but reports the class (1 = 128x128, 2 = 128x64, 3 = 8-wave 256x256) so that the caller can put the problem
-// into a group; every other class is launched as usual and reported as 0.
-enum { GK_LAUNCHED = 0, GK_GLDS = 1, GK_N64 = 2, GK_W8E = 3 };
-static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind_out = nullptr) {
-    if (kind_out) *kind_out = GK_LAUNCHED;
+static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
     static int nt_env = -1;
-    if (nt_env < 0) { const char* e = getenv("OSP_GEMM_NT"); nt_env = e ? atoi(e) : 0; }
+    if (nt_env < 0) { nt_env = 0; }
     p.nt_out = nt_env;
     const int64_t M = p.M, N = p.N, Cin = p.Cin, taps = p.taps, lda = p.lda, sBn = p.sBn, sBtap = p.sBtap, sBk = p.sBk,
                   sAb = p.sAb, sBb = p.sBb, a_bf16 = p.a_bf16, b_bf16 = p.b_bf16;
@@ -317,8 +312,6 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
     static int64_t small_max = 160, small_max32 = 260;
     if (use_small < 0) {
         const char* e = getenv("OSP_GEMM_SMALL"); use_small = (e && atoi(e) == 0) ? 0 : 1;
-        const char* t = getenv("OSP_GEMM_SMALL_MAX"); if (t) small_max = atoll(t);
-        const char* u = getenv("OSP_GEMM_SMALL_MAX32"); if (u) small_max32 = atoll(u);
     }
     if (use_small && p.nphase == 0 && fast && sBk == 1 && b_bf16 && (Cin % TBK == 0) && N > 64 &&
         cdiv(M, 128) * cdiv(N, 128) * batch < (a_bf16 ? small_max : small_max32))
@@ -337,7 +330,6 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * TBK * 2);
             attr64 = 1;
         }
-        if (kind_out && batch_in == 1) { *kind_out = GK_N64; return OSP_OK; }
         osp_note_symbol("conv_gemm_bf16_glds_n64_kernel");
         hipLaunchKernelGGL(conv_gemm_bf16_glds_n64_kernel, grid, dim3(256), 2 * (128 + 64) * TBK * 2, stream, p);
         OSP_LAUNCH_CHECK();
@@ -350,7 +342,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
         static int64_t w8_min = 0;
         if (w8 == -2) {
             const char* e = getenv("OSP_GEMM_W8"); w8 = e ? atoi(e) : -1;
-            const char* t = getenv("OSP_GEMM_W8_MIN"); w8_min = t ? atoll(t) : 160;
+            w8_min = 160;
         }
         const int64_t t256 = cdiv(M, 256) * cdiv(N, 256) * batch;
         // measured (tools/gemm_w8_probe.py, profiles/r02_gemm_w8_probe.txt): +23..30 % where the reduction is long (K >= 2560: the
@@ -359,11 +351,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
         if (w8 != 0 && N >= 256 && t256 >= (w8 == 1 ? 128 : w8_min) && (w8 == 1 || taps * Cin >= 2304)) {
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
             static int early = -1;
-            if (kind_out && batch_in == 1) {
-                const char* e = getenv("OSP_GEMM_W8_EARLY");
-                if (!(e && atoi(e) == 0)) { *kind_out = GK_W8E; return OSP_OK; }
-            }
-            if (early < 0) { const char* e = getenv("OSP_GEMM_W8_EARLY"); early = (e && atoi(e) == 0) ? 0 : 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py)
+            if (early < 0) { early = 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py)
             return osp_launch_glds8(p, g8, early != 0, stream);
         }
         static int attr_done = 0;
@@ -374,7 +362,6 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
         }
         // (a 256x128 three-stage variant at one wave per SIMD was measured in round 1 and did not beat this kernel at
         // 2 workgroups / CU -- 218 vs 209 us at M = 13056, N = 1024, K = 5120 -- and was removed in round 3)
-        if (kind_out && batch_in == 1) { *kind_out = GK_GLDS; return OSP_OK; }
         osp_note_symbol("conv_gemm_bf16_glds_kernel");
         hipLaunchKernelGGL(conv_gemm_bf16_glds_kernel, grid, dim3(256), GLDS_LDS, stream, p);
         OSP_LAUNCH_CHECK();
@@ -383,40 +370,9 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream, int* kind
     // narrow outputs (N <= 64, the DiscriminatorR stacks): short K loops are latency-bound at 2 workgroups / CU; the
     // BK = 32 instantiation halves the LDS footprint (5 workgroups / CU) -- pays off once there are many row tiles
     static int bk32_env = -2;
-    if (bk32_env == -2) { const char* e = getenv("OSP_GEMM_BK32"); bk32_env = e ? atoi(e) : -1; }
+    if (bk32_env == -2) { bk32_env = -1; }
     const bool bk32 = bk32_env >= 0 ? bk32_env != 0 : (M >= 65536);
     return osp_launch_gemm_reg(p, grid, bm, bn, sBk == 1, fast, bk32, stream);
-}
-
-// Launch up to GEMM_GROUP_MAX filled problems: each goes through the dispatcher; those it assigns to a direct-to-LDS class are
-// collected per class and leave as ONE grouped grid per class, the rest are launched on the spot.
-static int gemm_launch_group(GemmB* ps, int n, hipStream_t stream) {
-    int kind[GEMM_GROUP_MAX];
-    for (int i = 0; i < n; ++i) {
-        const int rc = gemm_launch(ps[i], 1, stream, &kind[i]);
-        if (rc != OSP_OK) return rc;
-    }
-    for (int k = GK_GLDS; k <= GK_W8E; ++k) {
-        GemmGroup g;
-        g.n = 0;
-        const int bm = k == GK_W8E ? 256 : 128, bn = k == GK_W8E ? 256 : (k == GK_N64 ? 64 : 128);
-        int tiles = 0;
-        for (int i = 0; i < n; ++i) {
-            if (kind[i] != k) continue;
-            const GemmB& p = ps[i];
-            g.p[g.n] = p;
-            g.nb[g.n] = (int)cdiv(p.N, bn); g.mb[g.n] = (int)cdiv(p.M, bm);
-            tiles += g.nb[g.n] * g.mb[g.n] * (p.nphase > 0 ? p.nphase : 1);
-            g.tile_end[g.n] = tiles;
-            ++g.n;
-        }
-        if (!g.n) continue;
-        for (int i = g.n; i < GEMM_GROUP_MAX; ++i) { g.tile_end[i] = tiles; g.nb[i] = g.mb[i] = 1; }
-        const int rc = k == GK_W8E ? osp_launch_glds8e_grp(g, tiles, stream) : osp_launch_glds_grp(g, tiles, k == GK_N64, stream);
-        if (rc != OSP_OK) return rc;
-    }
-    OSP_LAUNCH_CHECK();
-    return OSP_OK;
 }
 
 static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16, int64_t lda, int64_t M, int64_t Trows, int64_t Tin,
@@ -427,7 +383,7 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
                                   const void* res, int64_t res_bf16, int64_t ldr, const float* rowmask, const float* rowscale,
                                   void* aux_out, const void* aux_in, int64_t aux_bf16, int64_t ld_aux, float slope,
                                   int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate,
-                                  hipStream_t stream, GemmB* fill_only = nullptr) {
+                                  hipStream_t stream) {
     OSP_CHECK_ARG(A && B && C, "null operand");
     OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && Tin > 0 && batch > 0, "bad shape");
     OSP_CHECK_ARG(d2[0] > 0 && d2[1] > 0 && d2[2] > 0 && taps % d2[2] == 0 && Trows % d2[0] == 0, "bad 2-D geometry");
@@ -450,7 +406,6 @@ static int conv_gemm_bf16_impl(const int64_t* d2, const void* A, int64_t a_bf16,
     p.fd_trows = make_fastdiv((unsigned)Trows); p.fd_wrows = make_fastdiv((unsigned)d2[0]);
     p.Wrows = (int)d2[0]; p.Hin = (int)d2[1]; p.KW = (int)d2[2]; p.a_step_h = (int)d2[3]; p.a_tapstep_h = (int)d2[4];
     p.a_off_h = (int)d2[5]; p.Wc = (int)d2[6]; p.c_step_h = (int)d2[7]; p.c_off_h = (int)d2[8]; p.sBtap_h = d2[9];
-    if (fill_only) { *fill_only = p; return OSP_OK; }                  // grouped launch: the caller collects the blocks
     return gemm_launch(p, batch, stream);
 }
 
@@ -489,27 +444,6 @@ extern "C" int osp_conv2d_gemm_bf16(const void* A, int64_t a_bf16, int64_t lda, 
                                nullptr, nullptr, aux_in, aux_bf16, ld_aux, slope, 1, 0, 0, 0, 0, 0, stream);
 }
 
-static inline float f_of_bits(int64_t v) { float f; const unsigned u = (unsigned)v; memcpy(&f, &u, 4); return f; }
-static inline const void* ptr_of(int64_t v) { return reinterpret_cast<const void*>(static_cast<uintptr_t>(v)); }
-
-// GROUPED form of osp_conv2d_gemm_bf16: `count` (<= 5) problems, row r of rows_host = the 42 arguments of that entry point in
-// order, as int64 (pointers as addresses, `slope` as the bit pattern of the float in the low 32 bits).  Problems the dispatcher
-// sends to the same direct-to-LDS kernel class leave as one grid (GemmGroup above); the others are launched one by one.
-extern "C" int osp_conv2d_gemm_bf16_multi(const int64_t* rows_host, int64_t count, hipStream_t stream) {
-    OSP_CHECK_ARG(rows_host && count > 0 && count <= GEMM_GROUP_MAX, "1..5 problems");
-    GemmB ps[GEMM_GROUP_MAX];
-    for (int64_t r = 0; r < count; ++r) {
-        const int64_t* a = rows_host + r * 42;
-        const int64_t d2[10] = {a[5], a[6], a[10], a[11], a[12], a[13], a[28], a[29], a[30], a[20]};
-        const int rc = conv_gemm_bf16_impl(d2, ptr_of(a[0]), a[1], a[2], a[3], a[4], a[7], a[8], a[9], a[14], a[15], a[16], nullptr,
-                                           ptr_of(a[17]), a[18], a[19], a[21], a[22], a[23], const_cast<void*>(ptr_of(a[24])), a[25], a[26],
-                                           a[27], a[31], a[32], a[33], reinterpret_cast<const float*>(ptr_of(a[34])), nullptr, ptr_of(a[35]),
-                                           a[36], a[37], nullptr, nullptr, nullptr, ptr_of(a[38]), a[39], a[40], f_of_bits(a[41]), 1, 0, 0, 0,
-                                           0, 0, stream, &ps[r]);
-        if (rc != OSP_OK) return rc;
-    }
-    return gemm_launch_group(ps, (int)count, stream);
-}
 
 // dgrad of a strided channels-last conv2d, all output phases in ONE launch.
 //   dx[u, h, w, c] = epi( sum_{kh, kw, n} dy[u, (h + ph - kh) / sh, (w + pw - kw) / sw, n] * Wt[c, kh, kw, n] )   (exact divisions only)
@@ -521,8 +455,7 @@ extern "C" int osp_conv2d_gemm_bf16_multi(const int64_t* rows_host, int64_t coun
 static int conv2d_dgrad_impl(const void* dy, int64_t dy_bf16, const void* wt, int64_t w_bf16, void* dx, int64_t dx_bf16,
                              int64_t U, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, int64_t KH,
                              int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t epi, const void* aux_in,
-                             int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream, GemmB* fill_only,
-                             int* filled) {
+                             int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream) {
     OSP_CHECK_ARG(dy && wt && dx, "null operand");
     OSP_CHECK_ARG(U > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && sh > 0 && sw > 0, "bad shape");
     OSP_CHECK_ARG(sh * sw <= 4 && KH >= sh && KW >= sw, "unsupported stride (at most 4 phases, kernel >= stride)");
@@ -567,7 +500,6 @@ static int conv2d_dgrad_impl(const void* dy, int64_t dy_bf16, const void* wt, in
             for (int k = 0; k < np; ++k) { mmax = p.ph[k].M > mmax ? p.ph[k].M : mmax; tmax = p.ph[k].taps > tmax ? p.ph[k].taps : tmax; }
             r.M = mmax; r.Trows = p.ph[0].Trows; r.Wrows = p.ph[0].Wrows; r.taps = tmax; r.KW = p.ph[0].KW;
             r.a_off_h = r.a_off = r.c_off_h = r.c_off = 0; r.fd_trows = p.ph[0].fd_trows; r.fd_wrows = p.ph[0].fd_wrows;
-            if (fill_only) { *fill_only = r; *filled = 1; return OSP_OK; }     // grouped launch: the caller collects the blocks
         }
         rc = gemm_launch(r, 1, stream);
     }
@@ -579,24 +511,7 @@ extern "C" int osp_conv2d_dgrad_bf16(const void* dy, int64_t dy_bf16, const void
                                      int64_t KW, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t epi, const void* aux_in,
                                      int64_t aux_bf16, const void* res, int64_t res_bf16, float slope, hipStream_t stream) {
     return conv2d_dgrad_impl(dy, dy_bf16, wt, w_bf16, dx, dx_bf16, U, H, W, Ho, Wo, Cin, Cout, KH, KW, sh, sw, ph, pw, epi, aux_in, aux_bf16,
-                             res, res_bf16, slope, stream, nullptr, nullptr);
+                             res, res_bf16, slope, stream);
 }
 
-// GROUPED form of osp_conv2d_dgrad_bf16 (rows of its 25 arguments as int64, `slope` as float bits): the fused-phase dgrads of the
-// same layer of several stacks in one grid; degenerate channel counts (first / last layers) are launched one by one as before.
-extern "C" int osp_conv2d_dgrad_bf16_multi(const int64_t* rows_host, int64_t count, hipStream_t stream) {
-    OSP_CHECK_ARG(rows_host && count > 0 && count <= GEMM_GROUP_MAX, "1..5 problems");
-    GemmB ps[GEMM_GROUP_MAX];
-    int n = 0;
-    for (int64_t r = 0; r < count; ++r) {
-        const int64_t* a = rows_host + r * 25;
-        int filled = 0;
-        const int rc = conv2d_dgrad_impl(ptr_of(a[0]), a[1], ptr_of(a[2]), a[3], const_cast<void*>(ptr_of(a[4])), a[5], a[6], a[7], a[8], a[9],
-                                         a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19], ptr_of(a[20]), a[21],
-                                         ptr_of(a[22]), a[23], f_of_bits(a[24]), stream, &ps[n], &filled);
-        if (rc != OSP_OK) return rc;
-        n += filled;
-    }
-    return n ? gemm_launch_group(ps, n, stream) : OSP_OK;
-}
 

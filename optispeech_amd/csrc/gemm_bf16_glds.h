@@ -1,5 +1,5 @@
 // Direct-to-LDS body of the bf16 conv-GEMM family, shared by the translation units that instantiate it (gemm_bf16.hip: the 4-wave
-// 128x128 / 128x64 / 256x128 kernels; gemm_bf16_w8.hip: the 8-wave 256x256 kernels; gemm_bf16_grp.hip: the grouped 4-wave kernels).
+// 128x128 / 128x64 / 256x128 kernels; gemm_bf16_w8.hip: the 8-wave 256x256 kernels).
 // One instantiation of the body with its ten epilogues takes about a minute of compile time; one file per kernel class keeps
 // the build parallel.  Each translation unit launches its own kernels through the host launchers declared at the end.
 #pragma once
@@ -172,12 +172,8 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         if constexpr (!EARLY) { if (ld >= 0) issue_end(); }
     };
     const int nk = K / TBK;
-    // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, "two waves per SIMD", item 4): the
-    // younger wave of every SIMD loses the VALU / issue arbitration on every segment.  Compile-time switch OSP_GLDS_PRIO, OFF:
-#ifndef OSP_GLDS_PRIO
-#define OSP_GLDS_PRIO 0                // measured: no gain on this loop (DiscriminatorP 1024->1024 forward 136-141 us either way)
-#endif
-    if constexpr (NW == 8 && OSP_GLDS_PRIO) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+    // (s_setprio(1) for the second-dispatched half of an 8-wave workgroup -- MI355X_MICROARCH.md, 'two waves per SIMD' -- measured: no
+    // gain on this loop, 136-141 us either way; not kept)
     if constexpr (NST == 2) {
         issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,24 +216,5 @@ extern __shared__ __attribute__((aligned(1024))) unsigned short glds_smem[];
 // 4 waves, 128x128 tiles: two 32 KB stages; the row-domain epilogues stage one 32-row f32 block per wave (4 x 9 KB)
 #define GLDS_LDS (2 * (128 + TBN) * TBK * 2)
 
-// ---- GROUPED launch (round 3): up to GEMM_GROUP_MAX problems of the same kernel class in ONE grid -- the same layer of the five
-// DiscriminatorP (three DiscriminatorR) stacks, which differ in operand pointers and row counts only.  One period's 1024 -> 1024
-// layer is 51 x 4 = 204 tiles of 256 x 256 on 256 CUs (80 % of one round, and every number measured on it carried that 80 %);
-// the five together are 1 020 tiles = 3.98 rounds.  It also turns 5 (3) launches into one.  A workgroup finds its problem in the
-// prefix table (wave-uniform scalar work), takes that problem's parameter block out of the kernel-argument segment and runs the
-// unchanged body with a TileCtx of its own.
-#define GEMM_GROUP_MAX 5
-struct GemmGroup { int n; int tile_end[GEMM_GROUP_MAX]; int nb[GEMM_GROUP_MAX]; int mb[GEMM_GROUP_MAX]; GemmB p[GEMM_GROUP_MAX]; };
-__device__ __forceinline__ int group_pick(const GemmGroup& g, TileCtx& tc) {
-    const int bid = blockIdx.x;
-    int k = 0;
-    while (k < g.n - 1 && bid >= g.tile_end[k]) ++k;
-    const int local = bid - (k ? g.tile_end[k - 1] : 0), per = g.nb[k] * g.mb[k];
-    tc.NB = g.nb[k]; tc.MB = g.mb[k]; tc.z = local / per; tc.lin = local - tc.z * per;
-    return k;
-}
-
 // host launchers of the kernels that live in other translation units
 int osp_launch_glds8(const GemmB& p, dim3 grid, bool early, hipStream_t stream);              // gemm_bf16_w8.hip
-int osp_launch_glds8e_grp(const GemmGroup& g, int tiles, hipStream_t stream);                 // gemm_bf16_w8.hip
-int osp_launch_glds_grp(const GemmGroup& g, int tiles, bool n64, hipStream_t stream);         // gemm_bf16_grp.hip

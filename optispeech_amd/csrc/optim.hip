@@ -33,7 +33,7 @@ extern "C" int osp_sumsq(const float* g, int64_t n, double* out, hipStream_t str
     OSP_CHECK_ARG((reinterpret_cast<uintptr_t>(g) & 15) == 0, "gradient arena must be 16-byte aligned");
     const int64_t blocks = cdiv(n, 256 * 16);
     static int64_t cap = 0;
-    if (!cap) { const char* e = getenv("OSP_SUMSQ_WG"); cap = e ? atoll(e) : 256; }         // every workgroup ends with one f64 atomic into `out`: 128 / 256 / 512 / 1024 workgroups = 38 / 28 / 29 / 35 us
+    if (!cap) { cap = 256; }         // every workgroup ends with one f64 atomic into `out`: 128 / 256 / 512 / 1024 workgroups = 38 / 28 / 29 / 35 us
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap)), dim3(256), 0, stream, g, n, out);
     OSP_LAUNCH_CHECK();
     return OSP_OK;

@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libosp_hip is written for gfx950 (CDNA4) only: DPP row_bcast / wave_shr controls, ds_read_b64_tr_b16, 32x32x16 bf16 MFMA, LDS-DMA"
+#endif
+
 #define OSP_OK 0
 #define OSP_ERR_ARG -1
 #define OSP_ERR_HIP -2

@@ -383,7 +383,7 @@ extern "C" int osp_smallcin_conv_fwd(const float* x, const float* w, const float
     if (y_bf16 && (Cout == 32 || Cout == 64) && taps <= 48 && !getenv("OSP_SMALLCIN_VALU")) {
         const int64_t tiles = cdiv(M, 32), nb = cdiv(tiles, 4);
         static int64_t fcap = 0;
-        if (!fcap) { const char* e = getenv("OSP_SMALLCIN_FWD_WG"); fcap = e ? atoll(e) : 512; }
+        if (!fcap) { fcap = 512; }
         const dim3 grid((unsigned)(nb < fcap ? nb : fcap)), block(256);     // 2 blocks / CU: the per-wave weight prologue is amortised
         const int ks = (int)cdiv(taps, 16);
 #define SC_FWD(KS, NT_) hipLaunchKernelGGL((smallcin_fwd_mfma_kernel<KS, NT_>), grid, block, 0, stream, p)
@@ -414,7 +414,7 @@ extern "C" int osp_smallcin_conv_wgrad(const float* x, const void* dy, int64_t y
     if (y_bf16 && (Cout == 32 || Cout == 64) && taps < 64 && !getenv("OSP_SMALLCIN_VALU")) {
         const int64_t steps = cdiv(M, 16), nb = cdiv(steps, 4 * 8);
         static int64_t wg_cap = 0;
-        if (!wg_cap) { const char* e = getenv("OSP_SMALLCIN_WG"); wg_cap = e ? atoll(e) : 256; }
+        if (!wg_cap) { wg_cap = 256; }
         const dim3 grid((unsigned)(nb < wg_cap ? nb : wg_cap)), block(256);  // one atomic epilogue per block
         const int tt_ = taps < 32 ? 1 : 2, nt_ = Cout == 32 ? 1 : 2, E = tt_ * nt_ * 1024;
         if (ws && ws_floats >= (int64_t)grid.x * E) p.ws = ws;

@@ -629,7 +629,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
                                    dW, db, stream);
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     static int64_t tgt_gen = 0;
-    if (!tgt_gen) { const char* e = getenv("OSP_WGRAD_TARGET_GEN"); tgt_gen = e ? atoll(e) : 512; }
+    if (!tgt_gen) { tgt_gen = 512; }
     int64_t splits = tiles >= 192 ? 1 : cdiv(tgt_gen, tiles);
     int64_t chunk = cdiv(cdiv(M, splits), TBK) * TBK;
     if (chunk < 2 * TBK) chunk = 2 * TBK;
@@ -645,8 +645,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     // buffer descriptor -- half the MFMA work is padding, but the generic tile kernel below (no DMA, no double buffering) took
     // 84 us for the same layer
     const bool cin32 = Cin == 32 && N % 64 == 0 && ((int64_t)(M / Trows) * d2[1] * Tin * ldx) * 2 < (int64_t)0x7fffff00 &&
-                       (M * ldy) * 2 < (int64_t)0x7fffff00 && !getenv("OSP_WGRAD_NO_CIN32") &&
-                       !(getenv("OSP_WGRAD_BUF") && atoi(getenv("OSP_WGRAD_BUF")) == 0);      // needs the descriptor's bounds check
+                       (M * ldy) * 2 < (int64_t)0x7fffff00;      // needs the descriptor's bounds check
     if (use_tr && fast && N % 64 == 0 && (Cin % 64 == 0 || cin32)) {
         // 128-tiles when both channel counts allow it, 64-tiles otherwise (DiscriminatorR).  The frames are split until the grid
         // has about `target` workgroups; partial sums meet in f32 atomics, and every split adds a tile's worth of them: round 3
@@ -656,8 +655,8 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         const int64_t T_ = (N % 128 == 0 && Cin % 128 == 0) ? 128 : 64;
         static int64_t tgt_env = -1;
         static int64_t tgt64_env = -1;
-        if (tgt_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET"); tgt_env = e ? atoll(e) : 0; }
-        if (tgt64_env < 0) { const char* e = getenv("OSP_WGRAD_TARGET64"); tgt64_env = e ? atoll(e) : 0; }
+        if (tgt_env < 0) { tgt_env = 0; }
+        if (tgt64_env < 0) { tgt64_env = 0; }
         const int64_t tl = (N / T_) * taps * cdiv(Cin, T_) * batch, target = T_ == 128 ? (tgt_env > 0 ? tgt_env : 256) : (tgt64_env > 0 ? tgt64_env : (tgt_env > 0 ? 2 * tgt_env : 512));
         int64_t sp = tl >= target / 2 - 64 ? 1 : (target + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
@@ -669,7 +668,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         const int64_t rows_x = (M / Trows) * (int64_t)p.Hin * Tin;
         const int64_t yb = ((M - 1) * ldy + N) * 2, xb = ((rows_x - 1) * ldx + Cin) * 2;
         static int use_buf = -1;
-        if (use_buf < 0) { const char* e = getenv("OSP_WGRAD_BUF"); use_buf = (e && atoi(e) == 0) ? 0 : 1; }
+        if (use_buf < 0) { use_buf = 1; }
         const bool buf = use_buf && yb > 0 && xb > 0 && yb < (int64_t)0x7fffff00 && xb < (int64_t)0x7fffff00;
         p.y_bytes = buf ? (unsigned)yb : 0; p.x_bytes = buf ? (unsigned)xb : 0;
         // 8-wave 256 x 256 tiles for the wide layers (DiscriminatorP 512->1024 and 1024->1024): OSP_WGRAD_W8 = 0 switches them off
@@ -682,7 +681,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         if (w8 && N % 256 == 0 && Cin % 256 == 0 && M >= 4096) {
             const int64_t tl8 = (N / 256) * taps * (Cin / 256) * batch;
             static int64_t tgt8 = -1;
-            if (tgt8 < 0) { const char* e = getenv("OSP_WGRAD_W8_TARGET"); tgt8 = e ? atoll(e) : 256; }
+            if (tgt8 < 0) { tgt8 = 256; }
             int64_t sp8 = tl8 >= tgt8 / 2 ? 1 : tgt8 / tl8;                              // workgroups over the launch (1 resident per CU)
             if (sp8 < 1) sp8 = 1;
             int64_t ch8 = cdiv(cdiv(M, sp8), TBK) * TBK;
@@ -708,7 +707,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         // f32 operands (generator): 64-channel tiles through registers; small problems -> many splits
         const int64_t tl = (N / 64) * taps * (Cin / 64) * batch;
         static int64_t tgt32 = 0;
-        if (!tgt32) { const char* e = getenv("OSP_WGRAD_TARGET_F32"); tgt32 = e ? atoll(e) : 512; }    // 256 / 512 / 1024 / 2048 workgroups: 78 / 34 / 39 / 52 us per launch (16 per step; 2048 was the round-2 value)
+        if (!tgt32) { tgt32 = 512; }    // 256 / 512 / 1024 / 2048 workgroups: 78 / 34 / 39 / 52 us per launch (16 per step; 2048 was the round-2 value)
         int64_t sp = tl >= tgt32 / 2 - 64 ? 1 : (tgt32 + tl / 2) / tl;
         int64_t ch = cdiv(cdiv(M, sp), TBK) * TBK;
         if (ch < 2 * TBK) ch = 2 * TBK;

@@ -8,6 +8,9 @@
 // A workgroup owns a SLICE of 64 channels and a contiguous share of the rows: 8 lanes x 16 bytes cover the slice (one 128-byte
 // line per row and tap), 32 row groups walk the share, 4 rows per trip with all their loads requested before the first FMA.
 // The 32 row groups meet in LDS; one atomic per (tap, channel) and workgroup (49 k atomics for the 1024-channel layer).
+// NOT bit-reproducible run to run: the row shares of a channel slice meet in f32 atomics, whose order the hardware decides (as in
+// every split-K weight-gradient kernel of the library except smallcin_wgrad, which reduces owner-writes); the sums agree to f32
+// round-off (1e-7 relative), which is what the determinism tests of the data-parallel path allow for.
 #include "osp_common.h"
 
 #define WN1_MAXT 9

@@ -95,29 +95,6 @@ def conv2d_fwd(x, w, bias, KH, KW, sh, sw, ph, pw, slope, out_bf16):
     return out
 
 
-def conv2d_fwd_args(x, w, bias, KH, KW, sh, sw, ph, pw, slope, out_bf16):
-    """(output tensor, osp_conv2d_gemm_bf16 argument tuple) of conv2d_fwd: one member of a grouped launch."""
-    U, H, W, C = x.shape
-    Cout = w.shape[0]
-    Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
-    out = torch.empty((U, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    args = K.conv2d_gemm_bf16_args(x.view(U * H * W, C), w, Cout, M=U * Ho * Wo, Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, cin=C,
-                                   taps=KH * KW, KW=KW, a_step_h=sh, a_tapstep_h=1, a_off_h=-ph, a_step=sw, a_tapstep=1, a_off=-pw,
-                                   w_strides=(KH * KW * C, KW * C, C, 1), out=out.view(U * Ho * Wo, Cout), ldc=Cout, Tc=Ho * Wo, Wc=Wo,
-                                   epi=K.EPI_LRELU if slope is not None else K.EPI_NONE, bias=bias, slope=slope or 0.0)
-    return out, args
-
-
-def conv2d_dgrad_args(dy, wt, H, W, KH, KW, sh, sw, ph, pw, *, lrelu_y=None, extra=None, slope=0.1, out_bf16=False):
-    """(dx tensor, osp_conv2d_dgrad_bf16 argument tuple) of conv2d_dgrad: one member of a grouped launch."""
-    U, Ho, Wo, Cout = dy.shape
-    Cin = wt.shape[0]
-    dx = torch.empty((U, H, W, Cin), device=dy.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    isbf = lambda t: int(t is not None and t.dtype == torch.bfloat16)                 # noqa: E731
-    return dx, (dy, isbf(dy), wt, isbf(wt), dx, isbf(dx), U, H, W, Ho, Wo, Cin, Cout, KH, KW, sh, sw, ph, pw,
-                K.EPI_LRELU_BWD if lrelu_y is not None else K.EPI_NONE, lrelu_y, isbf(lrelu_y), extra, isbf(extra), float(slope))
-
-
 def transpose_weight2d(w):
     """native (Cout, KH, KW, Cin) -> dgrad layout (Cin, KH, KW, Cout), bf16."""
     t = w.permute(3, 1, 2, 0).contiguous()
@@ -394,174 +371,6 @@ class ConvStackReplayFn(torch.autograd.Function):
         _, x, acts, packs, spec, slope = ctx.rec
         _stack_backward(x, acts[:5], packs, ctx.params, spec, slope, False, ctx.need_w, (None,) * 5, ds)
         return (None,) + (None,) * len(ctx.params)
-
-
-class MultiConvStackFn(torch.autograd.Function):
-    """ConvStackFn for ALL stacks of a family (the five DiscriminatorP / the three DiscriminatorR) in LOCKSTEP: layer i of every
-    stack is issued together, and the layers that go to the direct-to-LDS conv-GEMM leave as ONE grouped launch
-    (K.conv2d_gemm_bf16_multi / conv2d_dgrad_bf16_multi; csrc/gemm_bf16.hip: GemmGroup).  Why: one period's 1024 -> 1024 layer
-    is 204 tiles of 256 x 256 on 256 CUs (80 % of a round); the five periods together are 1 020 tiles = 3.98 rounds, in one
-    launch instead of five -- on ONE stream, where round 2 needed a stream per stack to fill the chip.
-
-    forward(spec, cfg, n, x_0 .. x_{n-1}, (v, g, b) x 6 of stack 0, ..., of stack n-1); cfg = (slope, u0 per stack or None).
-    Returns, per stack, y1..y5, s (with a no-grad head u0: 6 head tensors, then the 6 differentiable ones -- as ConvStackFn)."""
-
-    @staticmethod
-    def forward(ctx, spec, cfg, n, *flat):
-        slope, u0s = cfg
-        u0s = u0s or (0,) * n
-        ctx.set_materialize_grads(False)
-        xs = [t.contiguous() for t in flat[:n]]
-        params = [flat[n + 18 * k: n + 18 * (k + 1)] for k in range(n)]
-        need_w = [[bool(ctx.needs_input_grad[3 + n + 18 * k + 3 * i]) for i in range(6)] for k in range(n)]
-        need_x = [bool(ctx.needs_input_grad[3 + k]) for k in range(n)]
-        packs = [[] for _ in range(n)]
-        acts = [[] for _ in range(n)]
-        h = list(xs)
-        for i in range(6):
-            KH, KW, sh, sw, ph, pw = spec[i]
-            lr = slope if i < 5 else None
-            rows, outs = [], []
-            for k in range(n):
-                vs, gs, bs = params[k][0::3], params[k][1::3], params[k][2::3]
-                cout, cin = vs[i].shape[0], vs[i].shape[1]
-                small = (cin == 1 and cout in (16, 32, 64) and KH * KW <= cout)
-                wn, wn32, wt, inv = wnorm_packed(vs[i], gs[i], small, True)
-                packs[k].append((wn, wn32, wt, inv))
-                if small:
-                    U, H, W = h[k].shape[0], h[k].shape[1], h[k].shape[2]
-                    Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
-                    outs.append(K.smallcin_fwd(h[k], wn32.view(cout, -1), bs[i].detach(), U=U, Hin=H, Win=W, Ho=Ho, Wo=Wo, cout=cout,
-                                               KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw, slope=lr, out_bf16=i < 5).view(U, Ho, Wo, cout))
-                else:
-                    out, args = conv2d_fwd_args(h[k], wn, bs[i].detach(), KH, KW, sh, sw, ph, pw, lr, i < 5)
-                    rows.append(args)
-                    outs.append(out)
-            if rows:
-                K.conv2d_gemm_bf16_multi(rows)
-            for k in range(n):
-                h[k] = outs[k]
-                acts[k].append(outs[k])
-        any_grad = any(need_x) or any(any(w) for w in need_w)
-        if any_grad:
-            saved = []
-            for k in range(n):
-                saved += [xs[k][u0s[k]:]] + [a[u0s[k]:] for a in acts[k][:5]]
-                saved += [t for pk in packs[k] for t in (pk[0], pk[2], pk[3]) if t is not None]
-            ctx.save_for_backward(*saved)
-            ctx.layout = [[(pk[0] is not None, pk[2] is not None, pk[3] is not None) for pk in packs[k]] for k in range(n)]
-            ctx.params, ctx.n = params, n
-            ctx.cfg = (spec, slope, need_x, need_w, u0s, [x.shape[0] for x in xs])
-        ret, nondiff = [], []
-        for k in range(n):
-            if u0s[k]:
-                head = [a[:u0s[k]] for a in acts[k]]
-                nondiff += head
-                ret += head + [a[u0s[k]:] for a in acts[k]]
-            else:
-                ret += acts[k]
-        if nondiff:
-            ctx.mark_non_differentiable(*nondiff)
-        return tuple(ret)
-
-    @staticmethod
-    def backward(ctx, *douts):
-        spec, slope, need_x, need_w, u0s, Us = ctx.cfg
-        n = ctx.n
-        saved = list(ctx.saved_tensors)
-        stacks, pos = [], 0
-        for k in range(n):
-            per = 12 if u0s[k] else 6
-            d = douts[pos + per - 6: pos + per]                      # (with a no-grad head the first 6 gradients are None)
-            pos += per
-            x, acts = saved[0], saved[1:6]
-            saved = saved[6:]
-            pk = []
-            for has in ctx.layout[k]:
-                item = []
-                for flag in has:
-                    item.append(saved.pop(0) if flag else None)
-                pk.append(item)                                       # (wn, wt, inv)
-            stacks.append(dict(x=x, acts=acts, packs=pk, params=ctx.params[k], need_x=need_x[k], need_w=need_w[k], dfm=d[:5], ds=d[5]))
-        gs = _multi_stack_backward(stacks, spec, slope)
-        outs = []
-        for k in range(n):
-            g = gs[k]
-            if need_x[k] and u0s[k] and g is not None:
-                full = torch.zeros((Us[k],) + tuple(g.shape[1:]), device=g.device, dtype=g.dtype)
-                full[u0s[k]:] = g
-                g = full
-            outs.append(g if need_x[k] else None)
-        return (None, None, None) + tuple(outs) + (None,) * (18 * n)
-
-
-def _multi_stack_backward(stacks, spec, slope):
-    """_stack_backward for several stacks in lockstep: per layer the weight gradients of every stack, then ONE grouped launch
-    for the input gradients of the layer below; the weight-norm backward of all stacks in one launch at the end."""
-    from .ops import gsink
-    n = len(stacks)
-    g, flats, offs, sizes, extras = [], [], [], [], []
-    for st in stacks:
-        x, acts = st["x"], st["acts"]
-        vs = st["params"][0::3]
-        extras.append([d.contiguous() if d is not None else None for d in st["dfm"]])
-        ds = st["ds"]
-        if ds is None:
-            ds = torch.zeros((x.shape[0],) + tuple(acts[4].shape[1:3]) + (1,), device=x.device, dtype=torch.float32)
-        g.append(ds.contiguous())
-        sz = [vs[i].numel() if st["need_w"][i] else 0 for i in range(6)]
-        sizes.append(sz)
-        flats.append(torch.zeros((sum(sz),), device=x.device, dtype=torch.float32) if sum(sz) else None)
-        offs.append([sum(sz[:i]) for i in range(6)])
-    wn_items = []
-    alive = [True] * n
-    for i in range(5, -1, -1):
-        KH, KW, sh, sw, ph, pw = spec[i]
-        rows, dxs, who = [], [], []
-        for k, st in enumerate(stacks):
-            if not alive[k]:
-                continue
-            vs, gs_, bs = st["params"][0::3], st["params"][1::3], st["params"][2::3]
-            inp = st["acts"][i - 1] if i > 0 else st["x"]
-            wn, wt, inv = st["packs"][i]
-            cout, cin = vs[i].shape[0], vs[i].shape[1]
-            gk = g[k]
-            if st["need_w"][i]:
-                dw = flats[k][offs[k][i]:offs[k][i] + sizes[k][i]].view(cout, KH, KW, cin)
-                db = gsink(bs[i])
-                if cin == 1 and cout in (16, 32, 64) and KH * KW <= cout:
-                    K.smallcin_wgrad(inp, gk, dw, db, U=inp.shape[0], Hin=inp.shape[1], Win=inp.shape[2], Ho=gk.shape[1],
-                                     Wo=gk.shape[2], cout=cout, KH=KH, KW=KW, sh=sh, sw=sw, ph=ph, pw=pw)
-                else:
-                    U, Ho, Wo = gk.shape[0], gk.shape[1], gk.shape[2]
-                    H, W = inp.shape[1], inp.shape[2]
-                    K.conv2d_wgrad_bf16(gk.view(U * Ho * Wo, cout), inp.view(U * H * W, cin), dw, db, M=U * Ho * Wo,
-                                        Trows=Ho * Wo, Wrows=Wo, Hin=H, Win=W, n=cout, cin=cin, taps=KH * KW, KW=KW, pad_h=ph,
-                                        pad_w=pw, step_h=sh, step_w=sw)
-                wn_items.append((dw, vs[i].detach(), gs_[i].detach(), inv, gsink(vs[i]), gsink(gs_[i])))
-            if i > 0 and (st["need_x"] or any(st["need_w"][:i])):
-                dx, args = conv2d_dgrad_args(gk, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, lrelu_y=inp,
-                                             extra=extras[k][i - 1], slope=slope, out_bf16=True)
-            elif i == 0 and st["need_x"]:
-                dx, args = conv2d_dgrad_args(gk, wt, inp.shape[1], inp.shape[2], KH, KW, sh, sw, ph, pw, out_bf16=False)
-            else:
-                g[k], alive[k] = None, False
-                continue
-            rows.append(args); dxs.append(dx); who.append(k)
-        if rows:
-            K.conv2d_dgrad_bf16_multi(rows)
-        for k, dx in zip(who, dxs):
-            g[k] = dx
-    if wn_items:
-        K.wnorm_bwd_multi(wn_items)
-        from .dp import reduce_ready
-        for st in stacks:
-            if all(st["need_w"]):
-                reduce_ready(list(st["params"]))                     # data parallel: this stack's gradient slice is complete
-    if any(any(st["need_w"]) for st in stacks) and g_stream_is_side():
-        side = torch.cuda.current_stream()
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream().wait_stream(side))
-    return g
 
 
 # =================================================================================================== f32 parity mode

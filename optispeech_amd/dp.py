@@ -7,6 +7,7 @@ Overlap schedule (exactly equivalent to the reference's order of optimiser steps
   -> [D-grad all-reduce in flight] -> wait G -> clip + AdamW(G) -> wait D -> clip + AdamW(D).
 Gradient averaging (1/world) is folded into the optimiser kernel's ``grad_scale``.
 """
+import contextlib
 import os
 
 import torch
@@ -68,29 +69,10 @@ def destroy_native_comm():
         _native["ready"], _native["stream"] = False, None
 
 
-# ---------------------------------------------------------------------------------------------- shared-GPU test aid
-#: Test aid only (tests/test_gpu_dp.py: two ranks on ONE GPU over gloo).  Two PROCESSES computing on one MI355X of this pool at
-#: the same time give occasionally different FFT results -- rocFFT behind torch.stft as well as this package's STFT kernel, never
-#: a process that has the GPU to itself (tools/probes/shared_gpu_all.sh, profiles/r03_shared_gpu_probe.txt).  So the ranks of
-#: that test take TURNS on the GPU: a rank computes while it holds this lock, and hands it over -- device drained -- whenever it
-#: blocks in a (host-side, gloo) collective.  None in every real run: one process per GPU.
-SHARED_GPU_TURN = None
-
-
-class _yield_turn:
-    """``with _yield_turn():`` around a blocking gloo collective: drain the device, let the other rank compute, take the GPU back."""
-
-    def __enter__(self):
-        self.lock = SHARED_GPU_TURN
-        if self.lock is not None:
-            torch.cuda.synchronize()
-            self.lock.release()
-        return self
-
-    def __exit__(self, *exc):
-        if self.lock is not None:
-            self.lock.acquire()
-        return False
+#: Context-manager factory entered around every BLOCKING host-side collective of the gloo path (the single-GPU test aid stages
+#: device buffers through the host).  Nothing in a real run (one process per GPU, RCCL ordered on-stream); tests/test_gpu_dp.py, whose
+#: two ranks share one GPU, installs a turn-taking lock here.
+around_host_collective = contextlib.nullcontext
 
 
 class _NativeWork:
@@ -124,6 +106,16 @@ class GradReducer:
         self._drain_first = gloo and not self.native
         self._ctrl_drain = gloo                      # small control-plane collectives (broadcast, log scalars) on device tensors
         self._force_active = False
+        #: measurement aid (bench.py): bracket every wait() with two events on the waiting stream; exposed_ms() = how long that
+        #: stream stood still for the collectives (0 when they finished under the compute they overlap)
+        self.measure = False
+        self._brackets = []
+
+    def exposed_ms(self):
+        """Sum over the bracketed wait() calls of the time the waiting stream stalled (call after a device synchronise)."""
+        tot = sum(a.elapsed_time(b) for a, b in self._brackets)
+        self._brackets.clear()
+        return tot
 
     @property
     def active(self):
@@ -140,7 +132,7 @@ class GradReducer:
             # reproducible to 1e-7 run to run in one process (tools/determinism_probe.py, also under contention).
             torch.cuda.synchronize()
             host = flat_grad.detach().to("cpu")
-            with _yield_turn():
+            with around_host_collective():
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.copy_(host)
             torch.cuda.synchronize()
@@ -190,8 +182,16 @@ class GradReducer:
         self._covered.clear()
 
     def wait(self):
+        bracket = self.measure and self._pending and torch.cuda.is_available()
+        if bracket:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._pending:
             w.wait()
+        if bracket:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._brackets.append((e0, e1))
         self._pending.clear()
         self._covered.clear()
 
@@ -204,7 +204,7 @@ class GradReducer:
             torch.cuda.synchronize()
             for t in tensors:
                 host = t.detach().to("cpu")
-                with _yield_turn():
+                with around_host_collective():
                     dist.broadcast(host, src=0, group=self.group)
                 t.copy_(host)
             torch.cuda.synchronize()
@@ -218,7 +218,7 @@ class GradReducer:
             if self._ctrl_drain and t.is_cuda:
                 torch.cuda.synchronize()
                 host = t.detach().to("cpu")
-                with _yield_turn():
+                with around_host_collective():
                     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 t.copy_(host)
                 t /= self.world

@@ -184,6 +184,7 @@ class StepGraphs:
         keep_pipe, m.pipeline_steps = m.pipeline_steps, False
         m.join()
         rng.use_device_seed(self.si[0:1])
+        keep_ranges = (getattr(self.red_g, "eager_ranges", True), getattr(self.red_d, "eager_ranges", True))
         self.red_g.eager_ranges = self.red_d.eager_ranges = False      # collectives stay between the graphs, never inside a capture
         opt_g.dev_scalars = (self.sf[0:1], self.si[1:2])
         opt_d.dev_scalars = (self.sf[1:2], self.si[2:3])
@@ -224,7 +225,7 @@ class StepGraphs:
                 self._restore_host_state(saved)
             cur.wait_stream(s)
         finally:
-            self.red_g.eager_ranges = self.red_d.eager_ranges = True
+            self.red_g.eager_ranges, self.red_d.eager_ranges = keep_ranges
             rng.use_device_seed(None)
             opt_g.dev_scalars = opt_d.dev_scalars = None
             m.pipeline_steps = keep_pipe

@@ -780,34 +780,6 @@ def conv2d_gemm_bf16(a, w, n_out, *, M, Trows, Wrows, Hin, Win, cin, taps, KW, a
     return out
 
 
-def conv2d_gemm_bf16_args(a, w, n_out, *, M, Trows, Wrows, Hin, Win, cin, taps, KW, a_step_h, a_tapstep_h, a_off_h, a_step,
-                          a_tapstep, a_off, w_strides, out, ldc, Tc, Wc, c_step_h=1, c_off_h=0, c_step=1, c_off=0,
-                          epi=EPI_NONE, bias=None, res=None, aux_in=None, slope=0.1, lda=None):
-    """The argument tuple of osp_conv2d_gemm_bf16 for one problem (see conv2d_gemm_bf16): rows of a grouped launch."""
-    lda = a.stride(-2) if lda is None else lda
-    ld_aux = aux_in.stride(-2) if aux_in is not None else 0
-    ldr = res.stride(-2) if res is not None else 0
-    return (a, _isbf(a), lda, M, Trows, Wrows, Hin, Win, cin, taps, KW, a_step_h, a_tapstep_h, a_off_h,
-            a_step, a_tapstep, a_off, w, _isbf(w), w_strides[0], w_strides[1], w_strides[2], w_strides[3], n_out, out,
-            _isbf(out), ldc, Tc, Wc, c_step_h, c_off_h, c_step, c_off, epi, bias, res, _isbf(res), ldr, aux_in, _isbf(aux_in),
-            ld_aux, float(slope))
-
-
-def conv2d_gemm_bf16_multi(rows):
-    """Up to 5 conv2d_gemm_bf16 problems (rows from conv2d_gemm_bf16_args) in one call: the problems the dispatcher sends to the
-    same direct-to-LDS kernel class run as ONE grid (csrc/gemm_bf16.hip: GemmGroup)."""
-    from ._lib import call_rows
-    for lo in range(0, len(rows), 5):
-        call_rows("osp_conv2d_gemm_bf16_multi", rows[lo:lo + 5])
-
-
-def conv2d_dgrad_bf16_multi(rows):
-    """Grouped osp_conv2d_dgrad_bf16 (rows = its argument tuples)."""
-    from ._lib import call_rows
-    for lo in range(0, len(rows), 5):
-        call_rows("osp_conv2d_dgrad_bf16_multi", rows[lo:lo + 5])
-
-
 def conv2d_wgrad_bf16(dy, x, dw, db, *, M, Trows, Wrows, Hin, Win, n, cin, taps, KW, pad_h, pad_w, step_h, step_w):
     call("osp_conv2d_wgrad_bf16", dy, _isbf(dy), dy.stride(-2), x, _isbf(x), x.stride(-2), M, Trows, Wrows, Hin, Win, n, cin,
          taps, KW, pad_h, pad_w, step_h, step_w, dw, db)

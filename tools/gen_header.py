@@ -101,9 +101,6 @@ REPLACES = {
     "osp_clip": "torch.clip(audio, -1, 1) of WaveNeXtHead.forward and its backward: vocoder/wavenext/__init__.py:47",
     "osp_stream_handover": "torch.cuda.Event.record + Stream.wait_event of the multi-stream schedule in one call (no reference counterpart: "
                            "the reference runs on one stream)",
-    "osp_conv2d_gemm_bf16_multi": "the same layer of the five DiscriminatorP / three DiscriminatorR stacks in one grid "
-                                  "(vocoder/wavenext/disc/_discriminators.py:10-38,100-136: the reference loops over the sub-discriminators)",
-    "osp_conv2d_dgrad_bf16_multi": "autograd dgrad of the same, grouped over the sub-discriminators",
     "osp_memset": "no reference counterpart: zero / byte fill of a buffer inside a taped region (torch.zeros / Tensor.zero_ of the host code)",
     "osp_copy": "no reference counterpart: device-to-device copy inside a taped region (torch.cat / Tensor.copy_ of the host code)",
     "osp_tape_selftest": "test aid of the call tapes: adds into a HOST counter, no device work (lets the CPU suite record / patch / replay)",

@@ -6,6 +6,7 @@ out, n, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) 
 extra = dict(kv.split("=", 1) for kv in sys.argv[4:])
 names = ["voc", "ctc", "wg_main", "wg_voc", "p0", "p1", "p2", "p3", "p4", "r0", "r1", "r2", "spec", "dphase"]
 rnd = random.Random(seed)
+NL = int(extra.get("OSP_N_LANES", "4"))
 cands = [("unmanaged", "")]
 fixed = os.environ.get("CANDS")
 if fixed:
@@ -18,14 +19,14 @@ if base:
     for i in range(n):
         a = dict(b)
         for nm in rnd.sample(names, rnd.choice([1, 1, 2])):
-            a[nm] = str(rnd.randrange(4))
+            a[nm] = str(rnd.randrange(NL))
         cands.append((f"mut{i}", ",".join(f"{k}:{v}" for k, v in a.items())))
     n = 0
 for i in range(n):
     # the eight stacks: a random balanced deal (two per lane); everything else uniformly random
-    deal = [0, 0, 1, 1, 2, 2, 3, 3]
+    deal = [k % NL for k in range(8)]
     rnd.shuffle(deal)
-    a = {nm: rnd.randrange(4) for nm in names}
+    a = {nm: rnd.randrange(NL) for nm in names}
     for nm, l in zip(["p0", "p1", "p2", "p3", "p4", "r0", "r1", "r2"], deal):
         a[nm] = l
     cands.append((f"rand{i}", ",".join(f"{k}:{v}" for k, v in a.items())))
