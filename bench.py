@@ -268,6 +268,7 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7, timer=None, cpu=True, cpu_sent
         pad_s = oc["wav"].shape[-1] / model.sample_rate
         cpu_fig = {"rtf": t_cpu / pad_s, "seconds": t_cpu, "sentences": cpu_sentences, "threads": cpu_threads, "kind": "port",
                    "padded_audio_s": pad_s, "total_audio_s": float(oc["wav_lengths"].sum()) / model.sample_rate,
+                   "aggregate_audio_s_per_s": float(oc["wav_lengths"].sum()) / model.sample_rate / t_cpu,
                    "sample": f"oracle.generator.synthesise on the first {cpu_sentences} of the 64 sentences (same weights, same duration "
                              f"override), {cpu_threads} threads, one call; RTF = wall time / padded audio length of that sub-batch"}
     model.train()
@@ -279,7 +280,8 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7, timer=None, cpu=True, cpu_sent
             "rtf": o.rtf, "am_rtf": o.am_rtf, "v_rtf": o.v_rtf, "latency_ms": o.latency, "sentences": n_sent,
             "padded_audio_s": o.wav.shape[-1] / model.sample_rate, "total_audio_s": audio_s,
             "aggregate_audio_s_per_s": audio_s / (o.latency * 1e-3), "roofline": roof, "cpu_rtf": cpu_fig,
-            "rtf_vs_cpu": (cpu_fig["rtf"] / o.rtf) if cpu_fig else None}
+            "rtf_vs_cpu": (cpu_fig["rtf"] / o.rtf) if cpu_fig else None,
+            "throughput_vs_cpu": (audio_s / (o.latency * 1e-3)) / cpu_fig["aggregate_audio_s_per_s"] if cpu_fig else None}
 
 
 def _selectors(precision):

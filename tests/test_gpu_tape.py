@@ -76,7 +76,12 @@ def test_taped_discriminator_stack_equals_eager(which):
         assert torch.equal(e[0], t[0]), f"pass {i}: scores differ"
         for a, b in zip(e[1], t[1]):
             assert torch.equal(a, b), f"pass {i}: feature maps differ"
-        assert torch.equal(e[2], t[2]), f"pass {i}: input gradient differs"
+        if which == "resolution":
+            # the wave gradient of a resolution stack passes through the STFT backward, whose overlap-add accumulates with f32
+            # atomics: not bit-reproducible between ANY two runs
+            assert (e[2] - t[2]).abs().max().item() <= 1e-5 * e[2].abs().max().item(), f"pass {i}: input gradient differs"
+        else:
+            assert torch.equal(e[2], t[2]), f"pass {i}: input gradient differs"
         for k in e[3]:
             scale = e[3][k].abs().max().item()
             assert (e[3][k] - t[3][k]).abs().max().item() <= 2e-5 * scale + 1e-12, (i, k)
