@@ -924,6 +924,38 @@ def attn_softmax_fwd(S, klen, B, H, T1, T2, scale, drop_p=0.0, seed=0, stream_id
     return S, (Pd if Pd is not None else S)
 
 
+def param_bf16_kperm16(p):
+    """bf16 copy of a 2-D f32 parameter (N, K) whose K axis is permuted inside every group of 16 to [0-3, 8-11, 4-7, 12-15]: the order
+    in which an MFMA 32x32 accumulator tile hands its rows to the next MFMA as an A operand (csrc/mlp_fused.hip, phase 2).  Cached on
+    the Parameter for the current optimizer epoch like param_bf16."""
+    from . import values
+    stamp = (values.param_epoch(), p._version, p.data_ptr())
+    cache = getattr(p, "_osp_bf16_kperm16", None)
+    if cache is None or cache[0] != stamp:
+        N, Kd = p.shape
+        assert Kd % 16 == 0
+        w = p.detach().view(N, Kd // 16, 2, 2, 4).transpose(2, 3).contiguous().view(N, Kd).to(torch.bfloat16)
+        cache = (stamp, w)
+        p._osp_bf16_kperm16 = cache
+    return cache[1]
+
+
+def convnext_mlp_fused(h, W1, b1, W2, b2, gamma, x, rowmask=None):
+    """ConvNeXt block MLP without gradients in one launch (csrc/mlp_fused.hip): y = (x + gamma * (W2 gelu(W1 h + b1) + b2)) * rowmask.
+    h (M, C) bf16 (dwconv7_ln_fwd(..., h_bf16=True)), x (M, C) f32, W1 (I, C) / W2 (C, I) f32 Parameters; C in {256, 384}, I % 128 == 0."""
+    M, C = x.shape
+    I = W1.shape[0]
+    assert h.dtype == torch.bfloat16 and h.shape == (M, C) and h.is_contiguous() and x.is_contiguous()
+    _f32(x, b1, b2, gamma)
+    y = torch.empty_like(x)
+    call("osp_convnext_mlp_fused", h, param_bf16(W1), b1, param_bf16_kperm16(W2), b2, gamma, x, rowmask, y, M, C, I)
+    return y
+
+
+def mlp_fused_supported(C, I):
+    return C in (256, 384) and I % 128 == 0 and 128 <= I <= 4096
+
+
 def attn_fused_fwd(q, k, v, klen, H):
     """softmax(q k^T / sqrt(dk) over the valid keys) v per head, scores never written: q, k, v (B, T, H*dk) f32 -> (B, T, H*dk).
     bf16 MFMA operands (performance mode only), no dropout, no gradient."""

@@ -195,6 +195,36 @@ _FUSED_ATTN = _os.environ.get("OSP_FUSED_ATTN", "1") != "0"
 _FUSED_ATTN_TRAIN = _os.environ.get("OSP_FUSED_ATTN_TRAIN", "1") != "0"
 
 
+#: grad mode of the CALLER of the autograd Function being applied.  Inside Function.forward autograd is always off, and
+#: ctx.needs_input_grad only repeats the inputs' requires_grad flags: a parameter fed to a Function under torch.no_grad() still says
+#: "needs grad", so the synthesise path used to write every saved activation (LayerNorm statistics, pre-activations, z) it could
+#: never use.  _grad_aware() wraps a Function's apply to record the outer mode; _saving(ctx) is what forwards ask.
+_OUTER_GRAD = [True]
+
+
+def _saving(ctx):
+    return _OUTER_GRAD[0] and any(ctx.needs_input_grad) and not torch.is_inference_mode_enabled()
+
+
+def _grad_aware(cls):
+    inner = cls.apply
+
+    def apply(*args):
+        prev = _OUTER_GRAD[0]
+        _OUTER_GRAD[0] = torch.is_grad_enabled()
+        try:
+            return inner(*args)
+        finally:
+            _OUTER_GRAD[0] = prev
+    cls.apply = staticmethod(apply)
+    return cls
+
+
+#: the one-kernel MLP of a ConvNeXt block on the no-grad path (OSP_FUSED_MLP=0: the two conv-GEMM launches, for A/B measurements)
+_FUSED_MLP = _os.environ.get("OSP_FUSED_MLP", "1") != "0"
+
+
+@_grad_aware
 class ConvNeXtBlockFn(torch.autograd.Function):
     """ConvNeXtBlock.forward + the backbone's per-block mask (generator/modules/convnext.py:34-47, :99-101).
 
@@ -207,13 +237,17 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         B, T, C = x.shape
         I = W1.shape[0]
         M = B * T
-        save = any(ctx.needs_input_grad)
+        save = _saving(ctx)
         x = x.contiguous()
         ctx.lowp = _precision.is_bf16() and I % 64 == 0 and C % 64 == 0
         # lowp: h goes straight out as bf16 (its only consumers are the bf16 pointwise GEMM and its weight-gradient GEMM)
         h, xhat, rstd = K.dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, 1e-6, save, h_bf16=ctx.lowp)
         h2 = h.view(M, C)
         z = torch.empty((M, C), device=x.device, dtype=torch.float32) if save else None
+        if ctx.lowp and not save and rowscale is None and _FUSED_MLP and K.mlp_fused_supported(C, I):
+            # no gradient wanted (synthesise): pwconv1 -> GELU -> pwconv2 -> gamma / residual / mask in ONE kernel, the (M, I)
+            # hidden activations stay in registers (csrc/mlp_fused.hip)
+            return K.convnext_mlp_fused(h2, W1, b1, W2, b2, gamma, x.view(M, C), rowmask).view(B, T, C)
         if ctx.lowp:
             # performance mode: the I-wide intermediates (pre-activation u, gelu(u)) live in bf16 -- what autocast does
             # to these matmul outputs in the reference's default `16-mixed` precision; the block's input / output /
@@ -290,13 +324,14 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         return (dx,) + (None,) * 12
 
 
+@_grad_aware
 class LayerNormFn(torch.autograd.Function):
     """y = (LN_C(x) * w + b) * dropout * rowmask  (nn.LayerNorm call sites convnext.py:102, wavenext:84)."""
 
     @staticmethod
     def forward(ctx, x, w, b, eps, rowmask, drop_p, seed, stream_id):
         x = x.contiguous()
-        save = any(ctx.needs_input_grad)
+        save = _saving(ctx)
         y, mean, rstd = K.layernorm_fwd(x, w, b, eps, save=save, rowmask=rowmask, drop_p=drop_p, seed=seed,
                                         stream_id=stream_id)
         if save:
@@ -321,6 +356,7 @@ def layer_norm(x, w, b, eps, rowmask=None, drop_p=0.0, seed=0, stream_id=0):
 
 
 # ------------------------------------------------------------------------------------------------ dense conv / linear
+@_grad_aware
 class ConvLinearFn(torch.autograd.Function):
     """y = act(conv1d_k(x) + b) on channels-last frames (nn.Conv1d / nn.Linear call sites of the path).
 
@@ -337,7 +373,7 @@ class ConvLinearFn(torch.autograd.Function):
         epi = K.EPI_RELU if act == "relu" else (K.EPI_MASK if rowmask is not None else K.EPI_NONE)
         assert not (act == "relu" and rowmask is not None)
         y = K.conv_gemm(x.view(B * T, Cin), w, cout, T=T, taps=taps, pad=pad, bias=b, epi=epi, rowmask=rowmask, w_param=w)
-        if any(ctx.needs_input_grad):
+        if _saving(ctx):
             ctx.save_for_backward(x, y if act == "relu" else None, rowmask)
             ctx.params = (w, b)
             ctx.cfg = (cout, taps, pad, act)
@@ -365,6 +401,7 @@ class ConvLinearFn(torch.autograd.Function):
         return (dx,) + (None,) * 7
 
 
+@_grad_aware
 class LSTMFn(torch.autograd.Function):
     """hs = nn.LSTM(H, H, num_layers=1, batch_first=True)(x)[0] with zero initial state (leanspeech.py:49-60).
 
@@ -375,7 +412,7 @@ class LSTMFn(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
         B, T, H = x.shape
         x = x.contiguous()
-        save = any(ctx.needs_input_grad)
+        save = _saving(ctx)
         gx = K.conv_gemm(x.view(B * T, H), w_ih, 4 * H, bias=b_ih + b_hh).view(B, T, 4 * H)
         hs, gates, cs = K.lstm_fwd(gx, w_hh.detach().contiguous(), save=save)
         if save:
@@ -406,6 +443,7 @@ def lstm(x, w_ih, w_hh, b_ih, b_hh):
     return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh)
 
 
+@_grad_aware
 class DepthwiseConvFn(torch.autograd.Function):
     """y = depthwise_conv_K(x) (+ bias) on channels-last frames (nn.Conv1d(C, C, K, padding=K//2, groups=C) call sites:
     ConvSeparable modules/layers.py:455-477).  x (B,T,C); w (K,C) tap-major parameter; bias (C,) or None."""
@@ -414,7 +452,7 @@ class DepthwiseConvFn(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         x = x.contiguous()
         y = K.dwconv_fwd(x, w, bias)
-        if any(ctx.needs_input_grad):
+        if _saving(ctx):
             ctx.save_for_backward(x)
             ctx.params = (w, bias)
         return y
@@ -463,6 +501,7 @@ def conv_linear(x, w, b, cout, taps=1, pad=0, act=None, rowmask=None):
     return ConvLinearFn.apply(x, w, b, cout, taps, pad, act, rowmask)
 
 
+@_grad_aware
 class PredictorLayerFn(torch.autograd.Function):
     """One VariancePredictor layer: Conv1d(k) -> ReLU -> LayerNorm(C, eps 1e-12) -> Dropout (core.py:62-76)."""
 
@@ -473,7 +512,7 @@ class PredictorLayerFn(torch.autograd.Function):
         pad = (taps - 1) // 2
         x = x.contiguous()
         r = K.conv_gemm(x.view(B * T, Cin), w, Cout, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_RELU, w_param=w)
-        save = any(ctx.needs_input_grad)
+        save = _saving(ctx)
         y, mean, rstd = K.layernorm_fwd(r, lnw, lnb, 1e-12, save=save, drop_p=drop_p, seed=seed, stream_id=stream_id)
         if save:
             ctx.save_for_backward(x, r, mean, rstd)
@@ -502,6 +541,7 @@ class PredictorLayerFn(torch.autograd.Function):
         return (dx,) + (None,) * 8
 
 
+@_grad_aware
 class VarianceEmbedFn(torch.autograd.Function):
     """x_out = (x + dropout(Conv1d(1 -> C, k)(values))) * keep_mask   (core.py:161-165 / :170-175)."""
 
@@ -522,7 +562,7 @@ class VarianceEmbedFn(torch.autograd.Function):
             dm = None
             y = K.conv_gemm(v, w, C, T=T, taps=taps, pad=pad, bias=b, epi=K.EPI_SCALE_RES_MASK, res=x.view(B * T, C),
                             rowmask=rowmask)
-        if any(ctx.needs_input_grad):
+        if _saving(ctx):
             ctx.save_for_backward(v, rowmask, dm)
             ctx.params = (w, b)
             ctx.cfg = (B, T, C, taps, pad)
@@ -560,11 +600,12 @@ def dropout_mask(shape, p, seed, stream_id, device):
 
 
 # ------------------------------------------------------------------------------------------------ text embedding
+@_grad_aware
 class TextEmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tok, E, scale, pos, drop_p, seed, stream_id):
         out = K.text_embed_fwd(tok, E, pos, scale, drop_p, seed, stream_id)
-        if any(ctx.needs_input_grad):
+        if _saving(ctx):
             ctx.save_for_backward(tok, pos)
             ctx.params = (E, scale)
             ctx.cfg = (drop_p, seed, stream_id)
@@ -581,6 +622,7 @@ class TextEmbedFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ alignment
+@_grad_aware
 class AlignLogProbFn(torch.autograd.Function):
     """log_p_attn = log_softmax_n(-||f_t - e_n||_2 masked) + prior   (alignments.py:66-81)."""
 
@@ -589,7 +631,7 @@ class AlignLogProbFn(torch.autograd.Function):
         f, e = f.contiguous(), e.contiguous()
         score = K.pairwise_score(f, e, x_len)
         lp, lse = K.logsoftmax_prior_fwd(score, prior)
-        if any(ctx.needs_input_grad):
+        if _saving(ctx):
             ctx.save_for_backward(f, e, score, lse, x_len, y_len)
         return lp
 
@@ -729,6 +771,7 @@ class GaussianUpsampleFn(torch.autograd.Function):
         return dhs, None, None, None, None, None
 
 
+@_grad_aware
 class AttentionFn(torch.autograd.Function):
     """softmax(Q K^T / sqrt(d_k) over the valid keys) V per head: MultiHeadedAttention.forward without the four linear layers
     (generator/modules/_transformer/attention.py:50-125).  q, k, v: (B, T, H * d_k) f32; klen (B,) int64 valid key counts.
@@ -743,7 +786,7 @@ class AttentionFn(torch.autograd.Function):
         B, T, C = q.shape
         dk = C // H
         Z = B * H
-        if (_FUSED_ATTN and sbias is None and drop_p == 0.0 and not any(ctx.needs_input_grad) and q.is_cuda
+        if (_FUSED_ATTN and sbias is None and drop_p == 0.0 and not _saving(ctx) and q.is_cuda
                 and _precision.is_bf16() and dk in (32, 64, 128)):
             # no-grad / inference: one flash-style kernel, the (B*H, T, T) scores never exist (csrc/attention.hip)
             return K.attn_fused_fwd(q.contiguous(), k.contiguous(), v.contiguous(), klen, H)

@@ -1,0 +1,95 @@
+"""One-kernel ConvNeXt block MLP of the no-grad path (csrc/mlp_fused.hip, osp_convnext_mlp_fused) against
+
+  * a float64 restatement of generator/modules/convnext.py:39-46 on the operands the kernel sees (h, W1, W2 rounded to bf16, the
+    GELU output rounded to bf16 as in the performance mode's two-launch path), and
+  * the two-launch path itself (conv_gemm_bf16 GELU epilogue -> conv_gemm_bf16 scale/residual/mask epilogue), which is what the
+    golden synthesise fixtures were accepted on.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _case(M, C, I, seed, mask):
+    g = torch.Generator().manual_seed(seed)
+    h = torch.randn(M, C, generator=g)
+    x = torch.randn(M, C, generator=g)
+    W1 = torch.randn(I, C, generator=g) / C ** 0.5
+    W2 = torch.randn(C, I, generator=g) / I ** 0.5
+    b1 = torch.randn(I, generator=g) * 0.2
+    b2 = torch.randn(C, generator=g) * 0.2
+    gamma = torch.randn(C, generator=g) * 0.5
+    rowmask = (torch.rand(M, generator=g) > 0.25).float() if mask else None
+    return h, x, W1, W2, b1, b2, gamma, rowmask
+
+
+def _reference(h, x, W1, W2, b1, b2, gamma, rowmask):
+    u = _bf16(h) @ _bf16(W1).T + b1.double()
+    gl = _bf16(0.5 * u * (1.0 + torch.erf(u / 2.0 ** 0.5)))
+    y = x.double() + gamma.double() * (gl @ _bf16(W2).T + b2.double())
+    return y * rowmask.double()[:, None] if rowmask is not None else y
+
+
+@pytest.mark.parametrize("C,I", [(384, 1152), (256, 1024), (384, 128), (256, 256)])
+@pytest.mark.parametrize("M,mask", [(1, False), (31, True), (128, False), (129, True), (1000, True), (4133, False)])
+def test_fused_mlp_matches_restatement_and_two_launch_path(C, I, M, mask):
+    from optispeech_amd import kernels as K, precision
+    h, x, W1, W2, b1, b2, gamma, rowmask = _case(M, C, I, 1000 * C + I + M, mask)
+    ref = _reference(h, x, W1, W2, b1, b2, gamma, rowmask)
+    d = lambda t: None if t is None else t.to(DEV)
+    hb = h.to(DEV).to(torch.bfloat16)
+    W1p, W2p = torch.nn.Parameter(W1.to(DEV)), torch.nn.Parameter(W2.to(DEV))
+    precision.set_precision("bf16")
+    try:
+        y = K.convnext_mlp_fused(hb, W1p, d(b1), W2p, d(b2), d(gamma), d(x), d(rowmask))
+        gg = K.conv_gemm_bf16(hb, K.param_bf16(W1p), I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU, bias=d(b1), out_bf16=True)
+        y2 = K.conv_gemm_bf16(gg, K.param_bf16(W2p), C, M=M, Trows=M, Tin=M, cin=I, epi=K.EPI_SCALE_RES_MASK, bias=d(b2),
+                              gamma=d(gamma), res=d(x), rowmask=d(rowmask))
+        torch.cuda.synchronize()
+    finally:
+        precision.set_precision("f32")
+    y, y2 = y.cpu().double(), y2.cpu().double()
+    assert torch.isfinite(y).all()
+    scale = ref.abs().max().item()
+    # the restatement rounds gelu(u) to bf16 from float64 u; the kernels from f32 accumulations of bf16 products: a different
+    # rounding of a few hidden units per row moves an output by <= |gamma W2| * 2^-9 * |g|
+    assert (y - ref).abs().max().item() <= 4e-3 * scale, ((y - ref).abs().max().item(), scale)
+    assert (y - y2).abs().max().item() <= 4e-3 * scale, ((y - y2).abs().max().item(), scale)
+    # aggregate agreement is much tighter than the worst element
+    assert ((y - ref) ** 2).mean().sqrt().item() <= 3e-4 * scale
+    if rowmask is not None:
+        assert (y[rowmask == 0] == 0).all()
+
+
+def test_fused_mlp_is_what_the_no_grad_block_runs(monkeypatch):
+    """ConvNeXtBlockFn under no_grad in performance mode = dwconv7+LN kernel + ONE MLP launch, equal to the autograd-capable path."""
+    from optispeech_amd import kernels as K, ops, precision
+    from optispeech_amd.model.modules import ConvNeXtBlock
+    torch.manual_seed(0)
+    blk = ConvNeXtBlock(384, 1152, layer_scale_init_value=0.3).to(DEV)
+    with torch.no_grad():
+        for w in (blk.dwconv_weight, blk.pwconv1_weight, blk.pwconv2_weight):
+            w.normal_(0, 0.08)
+    x = torch.randn(3, 217, 384, device=DEV)
+    calls = []
+    real = K.convnext_mlp_fused
+    monkeypatch.setattr(K, "convnext_mlp_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    precision.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            y = blk(x)
+        assert calls == [1] and ops._FUSED_MLP
+        y2 = blk(x.clone().requires_grad_(True))
+        assert calls == [1]                                   # the gradient-capable forward keeps the two launches (saves u, g, z)
+        torch.cuda.synchronize()
+    finally:
+        precision.set_precision("f32")
+    scale = y2.abs().max().item()
+    assert (y - y2.detach()).abs().max().item() <= 4e-3 * scale

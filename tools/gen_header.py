@@ -85,6 +85,9 @@ REPLACES = {
     "osp_pack_bf16_multi": "no reference counterpart: osp_pack_bf16 for a list of weights in one launch",
     "osp_lstm_fwd": "recurrence of nn.LSTM(dim, dim, 1, batch_first=True) after the input-projection GEMM: generator/modules/leanspeech.py:49-60 (hx / flags: workspace, flags zeroed)",
     "osp_lstm_bwd": "autograd of the same recurrence: gradient w.r.t. the gate pre-activations for every step (dW / db / dx are GEMMs over it)",
+    "osp_convnext_mlp_fused": "ConvNeXtBlock.forward pwconv1 -> GELU -> pwconv2 -> gamma, residual (+ backbone mask) without gradients, hidden "
+                              "activations never in HBM: generator/modules/convnext.py:39-46,99-101 (callers: OptiSpeechGenerator.synthesise "
+                              "generator/__init__.py:170-228, WaveNeXt.forward vocoder/wavenext/__init__.py:77-88)",
     "osp_attn_fused_fwd": "MultiHeadedAttention.forward_attention without the (T x T) scores in HBM (no-grad / inference path): _transformer/attention.py:75-101",
     "osp_dwconv_fwd": "depthwise nn.Conv1d(groups = C, odd k) and its input gradient (flip = 1): ConvSeparable modules/layers.py:455-477, _conformer/convolution.py",
     "osp_dwconv_wgrad": "autograd weight / bias gradient of the same depthwise Conv1d",
