@@ -8,7 +8,7 @@
 //   * its rows of h (bf16, 32 x C) live in registers as MFMA B-operand fragments for the whole kernel (C / 16 x 4 VGPRs);
 //   * the hidden dimension is walked in chunks of 128 units.  Per chunk
 //       phase 1   S^T (128 units x 32 rows) = W1[chunk] h^T          A = W1 rows from LDS, B = the h fragments; 4 accumulator tiles
-//       GELU      on the accumulators (bias b1 was their initial value), rounded to bf16
+//       GELU      on the accumulators (they start from b1: one extra MFMA per tile against a (hi, lo) bf16 table), rounded to bf16
 //       phase 2   out (32 rows x C) += gelu(S) W2[:, chunk]^T        S^T's accumulator layout IS the A-operand layout of S when
 //                 the 16 units of a k-step are taken in accumulator order (units 4h..4h+3 and 8+4h..8+4h+3 for lane half h, as in
 //                 attention.hip).  W2 is PACKED with that order along K (kernels.param_bf16_kperm16), so its B fragments are
@@ -22,8 +22,8 @@
 // phase 2) out of a ring of R = 8 slots (128 KB).  Every stage opens with: wait until its units have landed (s_waitcnt vmcnt(n), loads
 // complete in order), barrier (all waves are done with the previous stage, its slots are free); the UPS units that now fit are
 // requested one LDS-DMA instruction per MFMA group during the stage (static schedule, MlpSched): a unit is requested two stages
-// (>= 2000 MFMA clocks) before it is read.  Past the last chunk the schedule keeps issuing from a zero page so that the vmcnt
-// arithmetic stays the same.
+// (>= 2000 MFMA clocks) before it is read.  Past the last chunk the schedule keeps requesting (the last chunk's units again, L2
+// hits nobody reads) so that the vmcnt arithmetic stays the same.
 //
 // A stage is a static list of GROUPS = 4 fragment reads (one 16-byte ds_read per 32-row tile) + 4 MFMAs; the reads of group g + 1 are
 // issued before the MFMAs of group g (two fragment buffers).  The reads are inline asm: behind the compiler's back for a reason --
@@ -324,6 +324,8 @@ extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float
     p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.x = x; p.rowmask = rowmask; p.y = y; p.M = (int)M; p.I = (int)I;
     const dim3 grid((unsigned)cdiv(M, 128));
     osp_note_symbol("convnext_mlp_fused_kernel");
+    osp_note_flops(4.0 * (double)M * (double)C * (double)I);                                   // two GEMMs of 2 M C I
+    osp_note_bytes((double)M * C * (2 + 4 + 4) + 4.0 * (double)C * I + 4.0 * (I + 2 * C));      // h in, x in, y out; both weight packs; biases, gamma
     if (C == 384) hipLaunchKernelGGL((convnext_mlp_fused_kernel<384>), grid, dim3(256), MLP_LDS, stream, p);
     else hipLaunchKernelGGL((convnext_mlp_fused_kernel<256>), grid, dim3(256), MLP_LDS, stream, p);
     OSP_LAUNCH_CHECK();
