@@ -1,5 +1,5 @@
 // ConvNeXt block MLP in ONE kernel (no-grad / synthesise path): pwconv1 -> GELU -> pwconv2 -> layer scale + residual (+ mask),
-//   y = (x + gamma * (W2 gelu(W1 h + b1) + b2)) * rowmask          generator/modules/convnext.py:39-46 (+ the backbone mask :99-101)
+//   y = (x + rowscale * gamma * (W2 gelu(W1 h + b1) + b2)) * rowmask     generator/modules/convnext.py:39-46 (+ DropPath :121-129, the backbone mask :99-101)
 // The (rows x I) hidden activations never exist outside registers.  The unfused pair writes and re-reads them through HBM / L2
 // (49k frames x 1152 x 2 B = 113 MB per vocoder block at the synthesise benchmark) and runs two launches whose 128x128 tiles are
 // LDS-bandwidth bound (profiles/r04_synthesise_kernel_stats.csv: 24 x 121 us of the 7.0 ms synthesise call).
@@ -37,7 +37,7 @@
 
 struct MlpP {
     const unsigned short* h; const unsigned short* w1; const unsigned short* w2p;
-    const float *b1, *b2, *gamma, *x, *rowmask; float* y; int M, I;
+    const float *b1, *b2, *gamma, *x, *rowmask, *rowscale; float* y; int M, I;
 };
 
 template <int C> struct MlpSched {
@@ -289,14 +289,34 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
             if (m < p.M) {
                 const int64_t o = (int64_t)m * C + q * CP + 4 * c4;
                 const float4 xv = *reinterpret_cast<const float4*>(p.x + o);
-                const float rmk = p.rowmask ? p.rowmask[m] : 1.f;
+                const float rmk = p.rowmask ? p.rowmask[m] : 1.f, rs = p.rowscale ? p.rowscale[m] : 1.f;
                 float4 yv;
-                yv.x = (xv.x + v.x) * rmk; yv.y = (xv.y + v.y) * rmk; yv.z = (xv.z + v.z) * rmk; yv.w = (xv.w + v.w) * rmk;
+                yv.x = fmaf(rs, v.x, xv.x) * rmk; yv.y = fmaf(rs, v.y, xv.y) * rmk; yv.z = fmaf(rs, v.z, xv.z) * rmk; yv.w = fmaf(rs, v.w, xv.w) * rmk;
                 *reinterpret_cast<float4*>(p.y + o) = yv;
             }
         }
         __builtin_amdgcn_wave_barrier();
     });
+}
+
+// f32 (N, K) -> bf16 (N, K) with every group of 16 along K stored as [0-3, 8-11, 4-7, 12-15] (the phase-2 operand order above)
+__global__ __launch_bounds__(256) void pack_bf16_kperm16_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one float4 = 4 consecutive k of a row
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(w)[i];
+    const int q = (int)(i & 3);                                          // quarter of the 16-group: 0 1 2 3 -> 0 2 1 3
+    const int64_t d = (i & ~(int64_t)3) + ((q & 1) << 1 | (q >> 1));
+    bf16x2 a, b;
+    a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+    reinterpret_cast<uint2*>(o)[d] = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+
+extern "C" int osp_pack_bf16_kperm16(const float* w, void* out, int64_t N, int64_t K, hipStream_t stream) {
+    OSP_CHECK_ARG(w && out && N > 0 && K > 0 && K % 16 == 0, "bad args");
+    const int64_t n4 = N * K / 4;
+    hipLaunchKernelGGL(pack_bf16_kperm16_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned short*>(out), n4);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
 }
 
 static void mlp_attrs() {
@@ -308,10 +328,11 @@ static void mlp_attrs() {
 }
 
 // h (M, C) bf16 = LayerNorm(dwconv7(x)) as osp_dwconv7_ln_fwd leaves it; w1 (I, C) bf16; w2_kperm (C, I) bf16 with every group of 16
-// hidden units stored in the order [0-3, 8-11, 4-7, 12-15]; b1 (I), b2 (C), gamma (C), x / y (M, C) f32; rowmask (M) f32 or NULL.
+// hidden units stored in the order [0-3, 8-11, 4-7, 12-15]; b1 (I), b2 (C), gamma (C), x / y (M, C) f32; rowmask / rowscale (M) f32 or NULL
+// (rowscale = the DropPath factor of a row's utterance: the training step runs the decoder without a tape, DropPath on).
 // C in {256, 384}, I % 128 == 0.
 extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float* b1, const void* w2_kperm, const float* b2,
-                                      const float* gamma, const float* x, const float* rowmask, float* y, int64_t M, int64_t C,
+                                      const float* gamma, const float* x, const float* rowmask, const float* rowscale, float* y, int64_t M, int64_t C,
                                       int64_t I, hipStream_t stream) {
     OSP_CHECK_ARG(h && w1 && b1 && w2_kperm && b2 && gamma && x && y, "null argument");
     OSP_CHECK_ARG(M > 0 && M < (1ll << 31) - 256, "row count out of range");
@@ -321,7 +342,7 @@ extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float
     MlpP p;
     p.h = reinterpret_cast<const unsigned short*>(h); p.w1 = reinterpret_cast<const unsigned short*>(w1);
     p.w2p = reinterpret_cast<const unsigned short*>(w2_kperm);
-    p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.x = x; p.rowmask = rowmask; p.y = y; p.M = (int)M; p.I = (int)I;
+    p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.x = x; p.rowmask = rowmask; p.rowscale = rowscale; p.y = y; p.M = (int)M; p.I = (int)I;
     const dim3 grid((unsigned)cdiv(M, 128));
     osp_note_symbol("convnext_mlp_fused_kernel");
     osp_note_flops(4.0 * (double)M * (double)C * (double)I);                                   // two GEMMs of 2 M C I

@@ -934,21 +934,22 @@ def param_bf16_kperm16(p):
     if cache is None or cache[0] != stamp:
         N, Kd = p.shape
         assert Kd % 16 == 0
-        w = p.detach().view(N, Kd // 16, 2, 2, 4).transpose(2, 3).contiguous().view(N, Kd).to(torch.bfloat16)
+        w = _persistent(p, "_osp_bf16_bufs", "kperm16", (N, Kd), torch.bfloat16)       # refreshed in place: one launch, no torch op
+        call("osp_pack_bf16_kperm16", p.detach(), w, N, Kd)
         cache = (stamp, w)
         p._osp_bf16_kperm16 = cache
     return cache[1]
 
 
-def convnext_mlp_fused(h, W1, b1, W2, b2, gamma, x, rowmask=None):
-    """ConvNeXt block MLP without gradients in one launch (csrc/mlp_fused.hip): y = (x + gamma * (W2 gelu(W1 h + b1) + b2)) * rowmask.
+def convnext_mlp_fused(h, W1, b1, W2, b2, gamma, x, rowmask=None, rowscale=None):
+    """ConvNeXt block MLP without gradients in one launch (csrc/mlp_fused.hip): y = (x + rowscale * gamma * (W2 gelu(W1 h + b1) + b2)) * rowmask.
     h (M, C) bf16 (dwconv7_ln_fwd(..., h_bf16=True)), x (M, C) f32, W1 (I, C) / W2 (C, I) f32 Parameters; C in {256, 384}, I % 128 == 0."""
     M, C = x.shape
     I = W1.shape[0]
     assert h.dtype == torch.bfloat16 and h.shape == (M, C) and h.is_contiguous() and x.is_contiguous()
     _f32(x, b1, b2, gamma)
     y = torch.empty_like(x)
-    call("osp_convnext_mlp_fused", h, param_bf16(W1), b1, param_bf16_kperm16(W2), b2, gamma, x, rowmask, y, M, C, I)
+    call("osp_convnext_mlp_fused", h, param_bf16(W1), b1, param_bf16_kperm16(W2), b2, gamma, x, rowmask, rowscale, y, M, C, I)
     return y
 
 

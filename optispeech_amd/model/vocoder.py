@@ -72,7 +72,7 @@ class WaveNeXtHead(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
-        h = ops.conv_linear(x, self.linear_1.weight, self.linear_1.bias, self.linear_1.cout_p)
+        h = ops.conv_linear(x, self.linear_1.weight, self.linear_1.bias, self.linear_1.cout_p, out_bf16=True)
         a = ops.conv_linear(h, self.linear_2.weight, None, self.linear_2.weight.shape[0])
         a = a.reshape(B, -1)
         if a.is_cuda and a.dtype == torch.float32:

@@ -244,10 +244,10 @@ class ConvNeXtBlockFn(torch.autograd.Function):
         h, xhat, rstd = K.dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, 1e-6, save, h_bf16=ctx.lowp)
         h2 = h.view(M, C)
         z = torch.empty((M, C), device=x.device, dtype=torch.float32) if save else None
-        if ctx.lowp and not save and rowscale is None and _FUSED_MLP and K.mlp_fused_supported(C, I):
-            # no gradient wanted (synthesise): pwconv1 -> GELU -> pwconv2 -> gamma / residual / mask in ONE kernel, the (M, I)
+        if ctx.lowp and not save and _FUSED_MLP and K.mlp_fused_supported(C, I):
+            # no gradient wanted (synthesise; the training step's decoder, which receives none): pwconv1 -> GELU -> pwconv2 -> gamma / residual / mask in ONE kernel, the (M, I)
             # hidden activations stay in registers (csrc/mlp_fused.hip)
-            return K.convnext_mlp_fused(h2, W1, b1, W2, b2, gamma, x.view(M, C), rowmask).view(B, T, C)
+            return K.convnext_mlp_fused(h2, W1, b1, W2, b2, gamma, x.view(M, C), rowmask, rowscale).view(B, T, C)
         if ctx.lowp:
             # performance mode: the I-wide intermediates (pre-activation u, gelu(u)) live in bf16 -- what autocast does
             # to these matmul outputs in the reference's default `16-mixed` precision; the block's input / output /
@@ -366,12 +366,22 @@ class ConvLinearFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, b, cout, taps, pad, act, rowmask):
+    def forward(ctx, x, w, b, cout, taps, pad, act, rowmask, out_bf16=False):
         B, T, Cin = x.shape
         assert w.numel() == cout * taps * Cin and w.is_contiguous(), (tuple(w.shape), cout, taps, Cin)
         x = x.contiguous()
         epi = K.EPI_RELU if act == "relu" else (K.EPI_MASK if rowmask is not None else K.EPI_NONE)
         assert not (act == "relu" and rowmask is not None)
+        if (not _saving(ctx)) and x.is_cuda and _precision.is_bf16() and Cin % 64 == 0 and cout % 64 == 0 and B * T >= 8192:
+            # no gradient wanted and a large row count (synthesise: the vocoder's embedding conv and head at ~50 k frames): a bf16
+            # copy of the rows puts the GEMM on the direct-to-LDS kernels (an f32 A operand takes the register-staged kernel, which
+            # converts behind every load: 196 vs ~110 us per launch here); `out_bf16` hands the next conv_linear its operand as is.
+            # Same values either way: the loaders round an f32 A operand to bf16 in the same place.
+            xb = x if x.dtype == torch.bfloat16 else K.cast_bf16(x)
+            y = K.conv_gemm_bf16(xb.view(B * T, Cin), K._param_pack(w, w, cout, taps, Cin, (taps * Cin, Cin, 1)), cout, M=B * T,
+                                 Trows=T, Tin=T, cin=Cin, taps=taps, a_off=-pad, epi=epi, bias=b, rowmask=rowmask, out_bf16=out_bf16)
+            return y.view(B, T, cout)
+        assert x.dtype == torch.float32                               # (out_bf16 is only a hint: ignored off the no-grad path)
         y = K.conv_gemm(x.view(B * T, Cin), w, cout, T=T, taps=taps, pad=pad, bias=b, epi=epi, rowmask=rowmask, w_param=w)
         if _saving(ctx):
             ctx.save_for_backward(x, y if act == "relu" else None, rowmask)
@@ -398,7 +408,7 @@ class ConvLinearFn(torch.autograd.Function):
             with side_wgrad(g, x, rowmask):
                 K.conv_wgrad(g, x.view(B * T, Cin), gsink(w), gsink(b) if _want(b) else None, T=T, taps=taps, pad=pad,
                              arow=rowmask)
-        return (dx,) + (None,) * 7
+        return (dx,) + (None,) * 8
 
 
 @_grad_aware
@@ -497,8 +507,10 @@ def dropout_add(x, p, training, stream_id, res=None):
     return DropoutAddFn.apply(x, res, float(p), _rng.seed(), stream_id)
 
 
-def conv_linear(x, w, b, cout, taps=1, pad=0, act=None, rowmask=None):
-    return ConvLinearFn.apply(x, w, b, cout, taps, pad, act, rowmask)
+def conv_linear(x, w, b, cout, taps=1, pad=0, act=None, rowmask=None, out_bf16=False):
+    """out_bf16: the caller feeds the result to another conv_linear and wants no gradient (it is honoured only on the no-grad
+    large-row path; otherwise the result is f32 as always)."""
+    return ConvLinearFn.apply(x, w, b, cout, taps, pad, act, rowmask, out_bf16 and not torch.is_grad_enabled())
 
 
 @_grad_aware

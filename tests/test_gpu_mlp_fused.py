@@ -27,13 +27,15 @@ def _case(M, C, I, seed, mask):
     b2 = torch.randn(C, generator=g) * 0.2
     gamma = torch.randn(C, generator=g) * 0.5
     rowmask = (torch.rand(M, generator=g) > 0.25).float() if mask else None
-    return h, x, W1, W2, b1, b2, gamma, rowmask
+    rowscale = ((torch.rand(M, generator=g) > 0.2).float() / 0.8) if mask else None      # DropPath factors (0 or 1 / keep)
+    return h, x, W1, W2, b1, b2, gamma, rowmask, rowscale
 
 
-def _reference(h, x, W1, W2, b1, b2, gamma, rowmask):
+def _reference(h, x, W1, W2, b1, b2, gamma, rowmask, rowscale):
     u = _bf16(h) @ _bf16(W1).T + b1.double()
     gl = _bf16(0.5 * u * (1.0 + torch.erf(u / 2.0 ** 0.5)))
-    y = x.double() + gamma.double() * (gl @ _bf16(W2).T + b2.double())
+    y = gamma.double() * (gl @ _bf16(W2).T + b2.double())
+    y = x.double() + (y * rowscale.double()[:, None] if rowscale is not None else y)
     return y * rowmask.double()[:, None] if rowmask is not None else y
 
 
@@ -41,17 +43,17 @@ def _reference(h, x, W1, W2, b1, b2, gamma, rowmask):
 @pytest.mark.parametrize("M,mask", [(1, False), (31, True), (128, False), (129, True), (1000, True), (4133, False)])
 def test_fused_mlp_matches_restatement_and_two_launch_path(C, I, M, mask):
     from optispeech_amd import kernels as K, precision
-    h, x, W1, W2, b1, b2, gamma, rowmask = _case(M, C, I, 1000 * C + I + M, mask)
-    ref = _reference(h, x, W1, W2, b1, b2, gamma, rowmask)
+    h, x, W1, W2, b1, b2, gamma, rowmask, rowscale = _case(M, C, I, 1000 * C + I + M, mask)
+    ref = _reference(h, x, W1, W2, b1, b2, gamma, rowmask, rowscale)
     d = lambda t: None if t is None else t.to(DEV)
     hb = h.to(DEV).to(torch.bfloat16)
     W1p, W2p = torch.nn.Parameter(W1.to(DEV)), torch.nn.Parameter(W2.to(DEV))
     precision.set_precision("bf16")
     try:
-        y = K.convnext_mlp_fused(hb, W1p, d(b1), W2p, d(b2), d(gamma), d(x), d(rowmask))
+        y = K.convnext_mlp_fused(hb, W1p, d(b1), W2p, d(b2), d(gamma), d(x), d(rowmask), d(rowscale))
         gg = K.conv_gemm_bf16(hb, K.param_bf16(W1p), I, M=M, Trows=M, Tin=M, cin=C, epi=K.EPI_GELU, bias=d(b1), out_bf16=True)
         y2 = K.conv_gemm_bf16(gg, K.param_bf16(W2p), C, M=M, Trows=M, Tin=M, cin=I, epi=K.EPI_SCALE_RES_MASK, bias=d(b2),
-                              gamma=d(gamma), res=d(x), rowmask=d(rowmask))
+                              gamma=d(gamma), res=d(x), rowmask=d(rowmask), rowscale=d(rowscale))
         torch.cuda.synchronize()
     finally:
         precision.set_precision("f32")

@@ -85,6 +85,7 @@ REPLACES = {
     "osp_pack_bf16_multi": "no reference counterpart: osp_pack_bf16 for a list of weights in one launch",
     "osp_lstm_fwd": "recurrence of nn.LSTM(dim, dim, 1, batch_first=True) after the input-projection GEMM: generator/modules/leanspeech.py:49-60 (hx / flags: workspace, flags zeroed)",
     "osp_lstm_bwd": "autograd of the same recurrence: gradient w.r.t. the gate pre-activations for every step (dW / db / dx are GEMMs over it)",
+    "osp_pack_bf16_kperm16": "no reference counterpart: bf16 weight pack of pwconv2 in the k order osp_convnext_mlp_fused reads it in",
     "osp_convnext_mlp_fused": "ConvNeXtBlock.forward pwconv1 -> GELU -> pwconv2 -> gamma, residual (+ backbone mask) without gradients, hidden "
                               "activations never in HBM: generator/modules/convnext.py:39-46,99-101 (callers: OptiSpeechGenerator.synthesise "
                               "generator/__init__.py:170-228, WaveNeXt.forward vocoder/wavenext/__init__.py:77-88)",
