@@ -85,6 +85,54 @@ __device__ __forceinline__ float mlp_gelu(float x) {
     return x * fmaf(xc, q, 0.5f);
 }
 
+// Epilogue of both kernels.  Accumulator element i of lane (column 32 j + l31, half) is row 8 (i / 4) + 4 half + i % 4 of the wave's 32:
+// stored from there a lane would touch 4 bytes per instruction (384 loads + stores per lane; measured ~15 us per workgroup,
+// issue-bound).  Instead gamma * (acc + b2) goes through the wave's own LDS patch (TP tiles = CP columns at a time, row-major) and
+// comes back as one float4 per lane: x in and y out as 16-byte accesses.  All x rows of a pass are REQUESTED before the first is
+// used (the registers the pass's accumulator tiles just vacated hold them): as load / use / store per float4 the pass was a chain
+// of NIT memory latencies, ~20 us per workgroup for the four passes.
+template <int C, int NB>                                             // NB: float4s of x in flight per lane (registers)
+__device__ __forceinline__ void mlp_epilogue(const MlpP& p, f32x16 (&out)[C / 32], float* patch, int m0, int lane) {
+    constexpr int NT = C / 32, TP = (NT % 3 == 0) ? 3 : 2, CP = 32 * TP, Q4 = CP / 4, NIT = 32 * Q4 / 64;
+    static_assert(NT % TP == 0 && (32 * Q4) % 64 == 0, "epilogue tiling");
+    const int l31 = lane & 31, half = lane >> 5;
+    mlp_sfor<0, NT / TP>([&](auto qidx) {
+        constexpr int q = decltype(qidx)::value;
+#pragma unroll
+        for (int tt = 0; tt < TP; ++tt) {
+            const int n = 32 * (q * TP + tt) + l31;
+            const float gm = p.gamma[n], bb = p.b2[n];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                patch[(8 * (i >> 2) + 4 * half + (i & 3)) * CP + 32 * tt + l31] = gm * (out[q * TP + tt][i] + bb);
+        }
+        __builtin_amdgcn_wave_barrier();
+        static_assert(NIT % NB == 0, "batches");
+#pragma unroll
+        for (int b0 = 0; b0 < NIT; b0 += NB) {
+            float4 xv[NB]; float rmk[NB], rs[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4;
+                const int m = m0 + r < p.M ? m0 + r : p.M - 1;                   // (clamped: the loads are unconditional)
+                xv[k] = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + q * CP + 4 * c4);
+                rmk[k] = p.rowmask ? p.rowmask[m] : 1.f;
+                rs[k] = p.rowscale ? p.rowscale[m] : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4, m = m0 + r;
+                const float4 v = *reinterpret_cast<const float4*>(patch + r * CP + 4 * c4);
+                float4 yv;
+                yv.x = fmaf(rs[k], v.x, xv[k].x) * rmk[k]; yv.y = fmaf(rs[k], v.y, xv[k].y) * rmk[k];
+                yv.z = fmaf(rs[k], v.z, xv[k].z) * rmk[k]; yv.w = fmaf(rs[k], v.w, xv[k].w) * rmk[k];
+                if (m < p.M) *reinterpret_cast<float4*>(p.y + (int64_t)m * C + q * CP + 4 * c4) = yv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+
 extern __shared__ __attribute__((aligned(1024))) unsigned short mlp_smem[];
 #define MLP_MAX_I 4096
 #define MLP_LDS (8 * 128 * 64 * 2 + MLP_MAX_I * 4)                      // ring + (hi, lo) bias table
@@ -264,40 +312,14 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail of the schedule (requests nobody reads)
     __syncthreads();                                                  // every wave is done with the ring: it becomes the epilogue's staging
 
-    // ---- epilogue.  Accumulator element i of lane (column 32 j + l31, half) is row 8 (i / 4) + 4 half + i % 4 of the wave's 32: stored
-    // from there a lane would touch 4 bytes per instruction (384 loads + stores per lane; measured ~15 us per workgroup, issue-bound).
-    // Instead gamma * (acc + b2) goes through the wave's own LDS patch (TP tiles = CP columns at a time, row-major) and comes back as
-    // one float4 per lane: x in and y out as 16-byte accesses, 4x fewer instructions.
-    constexpr int TP = (NT % 3 == 0) ? 3 : 2, CP = 32 * TP, Q4 = CP / 4, NIT = 32 * Q4 / 64;
-    static_assert(NT % TP == 0 && (32 * Q4) % 64 == 0, "epilogue tiling");
-    float* patch = reinterpret_cast<float*>(mlp_smem) + wave * (32 * CP);
-    mlp_sfor<0, NT / TP>([&](auto qidx) {
-        constexpr int q = decltype(qidx)::value;
-#pragma unroll
-        for (int tt = 0; tt < TP; ++tt) {
-            const int n = 32 * (q * TP + tt) + l31;
-            const float gm = p.gamma[n], bb = p.b2[n];
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                patch[(8 * (i >> 2) + 4 * half + (i & 3)) * CP + 32 * tt + l31] = gm * (out[q * TP + tt][i] + bb);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = it * 64 + lane, r = idx / Q4, c4 = idx - r * Q4, m = m0 + r;
-            const float4 v = *reinterpret_cast<const float4*>(patch + r * CP + 4 * c4);
-            if (m < p.M) {
-                const int64_t o = (int64_t)m * C + q * CP + 4 * c4;
-                const float4 xv = *reinterpret_cast<const float4*>(p.x + o);
-                const float rmk = p.rowmask ? p.rowmask[m] : 1.f, rs = p.rowscale ? p.rowscale[m] : 1.f;
-                float4 yv;
-                yv.x = fmaf(rs, v.x, xv.x) * rmk; yv.y = fmaf(rs, v.y, xv.y) * rmk; yv.z = fmaf(rs, v.z, xv.z) * rmk; yv.w = fmaf(rs, v.w, xv.w) * rmk;
-                *reinterpret_cast<float4*>(p.y + o) = yv;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    });
+    mlp_epilogue<C, (C == 384 ? 12 : 8)>(p, out, reinterpret_cast<float*>(mlp_smem) + wave * (32 * ((C / 32) % 3 == 0 ? 96 : 64)), m0, lane);
 }
+
+// (A producer / consumer variant of this kernel -- 8 waves, two per SIMD: four waves run phase 1 + GELU and hand the bf16 hidden tile
+// to four phase-2 waves through LDS, GELU deferred by a chunk so that it runs under MFMAs -- was built and measured in round 4:
+// correct on the first run, but the same 3.5 (C = 256) / 4.5 us (C = 384) per 128 hidden units as this kernel for a workgroup that
+// has its CU to itself (tools/probes/mlp_fixed_cost.py), against 2.0 / 3.0 us of MFMA time.  Two designs with opposite issue
+// structure and the same chunk time: the limiter is not the instruction stream of a wave.  Removed from the library; its source is kept, unbuilt, in tools/probes/mlp_pc_kernel.hip.)
 
 // f32 (N, K) -> bf16 (N, K) with every group of 16 along K stored as [0-3, 8-11, 4-7, 12-15] (the phase-2 operand order above)
 __global__ __launch_bounds__(256) void pack_bf16_kperm16_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int64_t n4) {

@@ -3,6 +3,8 @@
 Everything here is channels-last fp32 on the GPU; outputs are allocated with torch (device memory
 plumbing only).  No arithmetic happens in Python.
 """
+import os
+
 import torch
 
 from . import precision as _precision

@@ -37,5 +37,4 @@ for (M, C, I) in [(49152, 384, 1152), (49152, 256, 1024), (51200, 384, 1152), (6
         us = e0.elapsed_time(e1) * 1000 / n
         fl = 4.0 * M * C * I
         print(f"M={M} C={C} I={I} {name}: {us:.1f} us  {fl / us / 1e6:.0f} TFLOP/s", flush=True)
-    d = (fused() - pair()).abs().max().item()
-    print("  max |fused - pair| =", d, flush=True)
+    print("  max |fused - pair| =", (fused() - pair()).abs().max().item(), flush=True)
