@@ -381,7 +381,8 @@ class ConvLinearFn(torch.autograd.Function):
             y = K.conv_gemm_bf16(xb.view(B * T, Cin), K._param_pack(w, w, cout, taps, Cin, (taps * Cin, Cin, 1)), cout, M=B * T,
                                  Trows=T, Tin=T, cin=Cin, taps=taps, a_off=-pad, epi=epi, bias=b, rowmask=rowmask, out_bf16=out_bf16)
             return y.view(B, T, cout)
-        assert x.dtype == torch.float32                               # (out_bf16 is only a hint: ignored off the no-grad path)
+        if x.dtype != torch.float32:                                  # a bf16 hand-over whose consumer is not on the path above (odd widths)
+            x = x.float()
         y = K.conv_gemm(x.view(B * T, Cin), w, cout, T=T, taps=taps, pad=pad, bias=b, epi=epi, rowmask=rowmask, w_param=w)
         if _saving(ctx):
             ctx.save_for_backward(x, y if act == "relu" else None, rowmask)
