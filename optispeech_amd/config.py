@@ -32,7 +32,7 @@ class ModelConfig:
     dec_layers: int = 4                                   # decoder/convnext.yaml
     dec_inter: int = 1024
     dec_drop_path: float = 0.2
-    backbone: str = "convnext"                            # "transformer" = BASELINE config 4 (encoder/decoder/transformer.yaml)
+    backbone: str = "convnext"                            # "transformer" = BASELINE configs[3] (encoder/decoder/transformer.yaml)
     tf_heads: int = 2
     tf_units: int = 1024
     tf_blocks: int = 4

@@ -102,7 +102,7 @@ extern "C" int osp_attn_softmax_bwd(const float* P, float* dPd, int64_t rows, in
 
 // ------------------------------------------------------------------------------------------------ fused (flash-style) forward
 // O = softmax(scale * Q K^T over the valid keys) V per (utterance, head) without ever writing the (T x T) scores: the no-grad /
-// inference path of MultiHeadedAttention (the decode of the Transformer variant, BASELINE config 4: 164 MB of probabilities per
+// inference path of MultiHeadedAttention (the decode of the Transformer variant, BASELINE configs[3]: 164 MB of probabilities per
 // decoder layer at B = 32, T = 800 in the unfused path).  Training keeps the unfused kernels above (attention dropout and the saved
 // probabilities of the backward).
 //
