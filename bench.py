@@ -432,12 +432,18 @@ def main():
     sync()
     for r_ in model._reducers:
         r_.exposed_ms()                                       # drop the warm-up's brackets
+    from optispeech_amd import _lib as _oslib, tape as _tape0
+    calls0 = (_oslib.lib().ncalls, _tape0.stats().get("calls_replayed", 0))
     t0 = time.perf_counter()
     for i in range(a.steps):
         model.training_step(batch, a.warmup + i)
     t_enq = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    calls1 = (_oslib.lib().ncalls, _tape0.stats().get("calls_replayed", 0))
+    abi_calls = {"direct": (calls1[0] - calls0[0]) / a.steps, "replayed_from_tapes": (calls1[1] - calls0[1]) / a.steps,
+                 "note": "C-ABI entry-point calls per timed step (almost all are one kernel launch; stream hand-overs and memsets are calls "
+                         "too); the rocprofv3 launch count of a step, ATen / runtime kernels included, is in profiles/r04_step_kernel_stats.csv (798)"}
     comm_exposed = None
     if world > 1:
         # per rank: how long the step's streams stood still in GradReducer.wait() (generator gradients before AdamW(G), discriminator
@@ -683,6 +689,7 @@ def main():
                           "lengths": "ragged" if a.ragged else "fixed"},
                "per_gpu": value / world, "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
                "host_enqueue_ms_per_step_unblocked": host_free, "transformer_step": tf_fig,
+               "c_abi_calls_per_step": abi_calls,
                "call_tapes": {"enabled": bool(keep_tape and _tape.available()), **tape_stats,
                               "note": "regions of the step recorded once as C-ABI call lists and replayed from C (optispeech_amd/tape.py); "
                                       "counts cover set-up + warm-up + timed steps"},

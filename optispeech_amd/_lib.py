@@ -58,6 +58,7 @@ class _Lib:
         self._sigs = _header_signatures()
         # native argument marshalling (optispeech_amd/fastcall.py): same library, ~5x less interpreter time per call
         self._fcall, self._fidx, self._fast = None, {}, None
+        self.ncalls = 0
         if os.environ.get("OSP_CTYPES_CALL", "0") != "1":
             fast = _load_fast()
             if fast is not None and fast.HEADER_SHA1 != _header_sha1():
@@ -89,6 +90,7 @@ class _Lib:
         # None through the header-derived argtypes; tensors are passed as their device address.
         idx = self._fidx.get(name)
         dev = _cur_device()
+        self.ncalls += 1                               # (direct calls; a tape's replayed calls are counted by the tape)
         if _GUARD:
             # kernels go to the current stream of torch's CURRENT device: a tensor living on another GPU would be addressed
             # from the wrong device's stream (fault, or silent peer access unordered with that GPU's work)

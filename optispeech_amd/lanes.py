@@ -19,12 +19,15 @@ import torch
 N_LANES = int(os.environ.get("OSP_N_LANES", "4"))      # = GPU_MAX_HW_QUEUES of the process (4 unless the environment says otherwise)
 DEPTH = 7                      # pool entries per lane
 
-#: lane per logical stream (None = an unmanaged stream from torch's pool, as before round 4).  The table is the best of a random search
-#: (36 balanced deals) plus a local search around the winner (30 one / two-stream mutations), each candidate = one `bench.py` run:
-#: 16.65-16.81 ms / step in five repeats against 17.5-17.7 for the unmanaged assignment on the same boxes; the 70 candidates span
-#: 16.7 ... 20.3 ms (profiles/r04_lane_search.txt).  OSP_LANES="" with OSP_LANES_OFF=1 gives the unmanaged streams back.
-DEFAULT = {"voc": 1, "ctc": 1, "wg_main": 3, "wg_voc": 0, "wg_other": None, "p0": 3, "p1": 1, "p2": 2, "p3": 0,
-           "p4": 3, "r0": 1, "r1": 0, "r2": 2, "spec": 0, "dphase": 1}
+#: lane per logical stream (None = an unmanaged stream from torch's pool, as before round 4).  The table is the result of two searches.
+#: First: 36 random balanced deals plus 30 one / two-stream mutations of the winner, each candidate = one `bench.py` run: 16.65-16.81 ms /
+#: step against 17.5-17.7 for the unmanaged assignment on the same boxes; the 70 candidates span 16.7 ... 20.3 ms
+#: (profiles/r04_lane_search.txt).  Second (tools/lane_search2.py, 80-120 pipelined steps per candidate, all on one box): 60 mutations
+#: + 30 random deals, then 45 mutations around each new winner until none improved: 15.9 ms / step against 16.3 for the first
+#: table, re-measured three times each on two boxes (profiles/r04_lane_search{2,3,4}.txt).  OSP_LANES="voc:1,..." overrides entries,
+#: OSP_LANES_OFF=1 gives the unmanaged streams back.
+DEFAULT = {"voc": 0, "ctc": 1, "wg_main": 1, "wg_voc": 0, "wg_other": None, "p0": 0, "p1": 3, "p2": 0, "p3": 3,
+           "p4": 2, "r0": 0, "r1": 1, "r2": 2, "spec": 1, "dphase": 1}
 
 _pool = {}
 _taken = {}

@@ -6,7 +6,10 @@ import os, random, re, subprocess, sys
 out, nmut, nrand = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rnd = random.Random(int(sys.argv[4]) if len(sys.argv) > 4 else 1)
 names = ["voc", "ctc", "wg_main", "wg_voc", "p0", "p1", "p2", "p3", "p4", "r0", "r1", "r2", "spec", "dphase"]
-BASE = dict(voc=1, ctc=1, wg_main=3, wg_voc=0, p0=3, p1=1, p2=2, p3=0, p4=3, r0=1, r1=0, r2=2, spec=0, dphase=1)
+DEFAULT = dict(voc=1, ctc=1, wg_main=3, wg_voc=0, p0=3, p1=1, p2=2, p3=0, p4=3, r0=1, r1=0, r2=2, spec=0, dphase=1)   # round-4 table before this search
+BASE = dict(DEFAULT)
+if os.environ.get("BASE"):                                  # mutate around another table: BASE="voc:0,ctc:1,..."
+    BASE.update({k: int(v) for k, v in (kv.split(":") for kv in os.environ["BASE"].split(","))})
 fmt = lambda a: ",".join(f"{k}:{a[k]}" for k in names)
 
 
@@ -40,7 +43,7 @@ with open(out, "w") as fh:
         print(line, flush=True); fh.write(line + "\n"); fh.flush()
     res.sort()
     fh.write("# re-measured (3 x 120 steps each, interleaved with the default)\n")
-    for ms, tag, lanes in [r for r in res[:6]] + [(0, "base", fmt(BASE))]:
+    for ms, tag, lanes in [r for r in res[:6]] + [(0, "base", fmt(BASE)), (0, "default", fmt(DEFAULT))]:
         xs = [measure(lanes, 120) for _ in range(3)]
         line = f"{min(xs):.2f} {sorted(xs)[1]:.2f} {max(xs):.2f}  {tag} {lanes}"
         print("RE", line, flush=True); fh.write(line + "\n"); fh.flush()
