@@ -33,8 +33,8 @@ PMC_MFMA = "r04_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM p
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # (1.6 s of timed region: pipeline fill + drain of the region is ~2.5 ms once)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-am-only", action="store_true", help="skip the acoustic-model-only (pre-training regime) step timing")
     ap.add_argument("--no-infer", action="store_true", help="skip the synthesise() RTF measurement (secondary metric)")
