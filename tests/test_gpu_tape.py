@@ -87,7 +87,7 @@ def test_taped_discriminator_stack_equals_eager(which):
             assert (e[3][k] - t[3][k]).abs().max().item() <= 2e-5 * scale + 1e-12, (i, k)
 
 
-def _train(tapes, steps=4, pipeline=True):
+def _train(tapes, steps=4, pipeline=True, segments=False):
     from optispeech_amd import precision, rng, tape
     from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
     keep = tape.ENABLED
@@ -102,6 +102,7 @@ def _train(tapes, steps=4, pipeline=True):
         rng._state["next_stream"] = 1
         m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
         m.pipeline_steps = pipeline
+        m.tape_segments = segments
         m.generator.segment_rand01 = torch.rand(2, generator=torch.Generator().manual_seed(1)).to(DEV)
         m.optimizers()
         for sch in m.lr_schedulers():
@@ -140,3 +141,21 @@ def test_taped_training_steps_match_eager_steps():
             assert torch.allclose(sa[k], sb[k], rtol=1e-3, atol=1.5e-3), (k, (sa[k] - sb[k]).abs().max().item())
             moved += 1
     assert moved > 100
+
+
+def test_taped_generator_segments_match_eager_steps():
+    """The opt-in taped generator segments (OptiSpeech.tape_segments: acoustic model and vocoder as tape.Segment nodes -- forward AND
+    backward replayed from call lists, dropout seed read from device memory) against the eager steps, same tolerance as above."""
+    from optispeech_amd import tape
+    la, sa, _ = _train(False)
+    s0 = tape.stats()
+    lb, sb, s1 = _train(True, segments=True)
+    assert s1["recorded"] - s0["recorded"] >= 18, (s0, s1)              # the stacks' regions + 2 segments x (forward, backward)
+    assert s1["poisoned"] == s0["poisoned"], "a generator segment fell back to eager execution"
+    for i, (x, y) in enumerate(zip(la, lb)):
+        for k in x:
+            assert np.isfinite(y[k])
+            assert abs(x[k] - y[k]) <= (6e-3 if i == 0 else 2e-2) * abs(x[k]) + 1e-4, (i, k, x[k], y[k])
+    for k in sa:
+        if sa[k].is_floating_point():
+            assert torch.allclose(sa[k], sb[k], rtol=1e-3, atol=1.5e-3), (k, (sa[k] - sb[k]).abs().max().item())
