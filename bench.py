@@ -605,9 +605,10 @@ def main():
                  "conv_wgrad_bf16_tr8_kernel": "8 waves, 256x256 weight-gradient tiles (transposed LDS reads): DiscriminatorP 512->1024 / 1024->1024",
                  "conv_wgrad_bf16_tr_kernel<128>": "weight gradients, 128-channel tiles", "conv_wgrad_bf16_tr_kernel<64>": "weight gradients, 64-channel tiles (DiscriminatorR)",
                  "conv_wgrad_bf16_tr_kernel<64,f32>": "generator weight gradients (f32 operands through registers)",
-                 "conv_gemm_f32_kernel": "exact-f32 MFMA: the index-critical path (text encoder, alignment, duration predictor) and the f32 / mixed modes",
+                 "conv_gemm_f32_glds_kernel": "exact-f32 MFMA on LDS-DMA-staged f32 tiles: the index-critical path and the f32 / mixed modes at >= 192 tiles",
+                 "conv_gemm_f32_kernel": "exact-f32 MFMA (register-staged; small shapes, k-strided weights): the index-critical path (text encoder, alignment, duration predictor) and the f32 / mixed modes",
                  "conv_gemm_bf16_s64_kernel": "small-problem 64x64 kernel (bf16 A)", "conv_gemm_bf16_s64_a32_kernel": "small-problem 64x64 kernel (f32 A)"}
-        F32_SYMS = ("conv_gemm_f32_kernel", "conv_wgrad_f32_kernel")
+        F32_SYMS = ("conv_gemm_f32_kernel", "conv_gemm_f32_glds_kernel", "conv_wgrad_f32_kernel")
         nroof = 3                                                 # serialised steps the events cover
         mf = {k[5:]: v for k, v in ksum.items() if k.startswith("mfma:") and v[1] > 0}
         table = {}

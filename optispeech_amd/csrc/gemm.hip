@@ -244,6 +244,12 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_kernel(GemmP p) {
         }
 }
 
+int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
+                          const float* a_rowscale, const float* B, int64_t sBn, int64_t sBtap, int64_t sBk, int64_t N, float* C,
+                          int64_t ldc, int64_t epi, const float* bias, const float* gamma, const float* res, int64_t ldr,
+                          const float* rowmask, const float* rowscale, float* aux_out, const float* aux_in, int64_t ld_aux,
+                          int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate, hipStream_t stream);   // gemm_f32_glds.hip
+
 template <int BM, int BN>
 static int launch_gemm(const GemmP& p, int b_kcontig, int batch, hipStream_t stream) {
     dim3 grid((unsigned)cdiv(p.N, BN), (unsigned)cdiv(p.M, BM), (unsigned)batch);
@@ -277,6 +283,12 @@ extern "C" int osp_conv_gemm_f32(const float* A, int64_t lda, int64_t M, int64_t
     OSP_CHECK_ARG(epi >= 0 && epi <= EPI_MASK, "unknown epilogue");
     OSP_CHECK_ARG(epi != EPI_SCALE_RES_MASK || res, "epilogue needs res");
     OSP_CHECK_ARG((epi != EPI_GELU_BWD && epi != EPI_RELU_BWD && epi != EPI_AXMY) || aux_in, "epilogue needs aux_in");
+    {   // the direct-to-LDS f32 kernel where its conditions hold (gemm_f32_glds.hip)
+        const int r = osp_try_gemm_f32_glds(A, lda, M, T, Cin, taps, pad, a_rowscale, B, sBn, sBtap, sBk, N, C, ldc, epi, bias, gamma, res, ldr,
+                                            rowmask, rowscale, aux_out, aux_in, ld_aux, batch, sAb, sBb, sCb, sXb, accumulate, stream);
+        if (r < 0) { osp_set_error("osp_conv_gemm_f32: launch failed"); return OSP_ERR_HIP; }
+        if (r > 0) return OSP_OK;
+    }
     GemmP p;
     p.A = A; p.lda = lda; p.M = (int)M; p.T = (int)T; p.Cin = (int)Cin; p.taps = (int)taps; p.pad = (int)pad;
     p.a_rowscale = a_rowscale;

@@ -21,7 +21,10 @@ static __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];     
 //   (128 + 64) rows x 32 B of fragments for 8 MFMAs (the 4-wave 128x128 tile: (64 + 64) x 32 B for 4), and a CU stages
 //   (256 + 256) x 128 B per slab for 4x the flops of a 128x128 tile (2x fewer HBM / L2 bytes per flop); two 64 KB stages,
 //   one barrier per slab, 1 workgroup / CU whose second wave per SIMD covers the other's LDS latency.
-template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false>
+// F32 (round 4, gemm_f32_glds.hip): the operands are f32 and the products exact -- v_mfma_f32_32x32x2_f32.  Staging does not change
+// at all: a 128-byte row is 32 floats instead of 64 bf16, and the caller passes every global stride / extent in 2-byte units (doubled)
+// so that the address arithmetic below is the same; only the fragment reads and the MFMAs of a k-step differ.
+template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false, bool F32 = false>
 __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem, const TileCtx tc) {
     const GemmB pp = gemm_select_phase(pin, tc.z);
     constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
@@ -137,6 +140,36 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         if (ld >= 0) issue_begin();
         auto kstep = [&](auto ksidx) {
             constexpr int ks = decltype(ksidx)::value;
+            if constexpr (F32) {
+                // the two 16-byte slots of this k-step hold 4 floats each = two MFMAs of K = 2.  Lane half lh reads the 8-byte half lh
+                // of a slot, (k, k + 1) with k = 4 slot + 2 lh: the first MFMA contracts k = {4 slot, 4 slot + 2} (its k index IS the
+                // lane half), the second {4 slot + 1, 4 slot + 3} -- A and B fragments follow the same assignment, every k once.
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                static_assert(TM_ == 2, "f32 tiles: 64 rows per wave");
+                if (ld >= 0) issue_quarter(ld, ksidx);
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    f32x2_ a[TM_], b[TN_];
+#pragma unroll
+                    for (int i = 0; i < TM_; ++i) {
+                        const int row = wm0 + 32 * i + l31;
+                        a[i] = *reinterpret_cast<const f32x2_*>(as + row * TBK + ((((2 * ks + g2) ^ ((row >> 1) & 7)) << 3) + 4 * lh));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN_; ++j) {
+                        const int row = wn0 + 32 * j + l31;
+                        b[j] = *reinterpret_cast<const f32x2_*>(bs + row * TBK + ((((2 * ks + g2) ^ ((row >> 1) & 7)) << 3) + 4 * lh));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN_; ++j)
+                                acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc0[i][j], 0, 0, 0);
+                }
+                return;
+            }
             bf16x8 a[TM_], b[TN_];
 #pragma unroll
             for (int i = 0; i < TM_; ++i) {
