@@ -926,6 +926,21 @@ def attn_softmax_fwd(S, klen, B, H, T1, T2, scale, drop_p=0.0, seed=0, stream_id
     return S, (Pd if Pd is not None else S)
 
 
+def param_f32_t(p, kscale=None):
+    """f32 transpose (K, N) of a 2-D f32 parameter (N, K), optionally with row n of p scaled by kscale[n] first -- the k-contiguous
+    operand of an exact-f32 input-gradient GEMM (ConvNeXt block backward in the f32 / mixed modes).  Cached on the Parameter for the
+    current optimizer epoch like the bf16 packs; made with two torch ops (those modes are not the launch-count-critical ones)."""
+    from . import values
+    stamp = (values.param_epoch(), p._version, p.data_ptr(), None if kscale is None else (kscale.data_ptr(), kscale._version))
+    key = "_osp_f32_t" if kscale is None else "_osp_f32_t_scaled"
+    cache = getattr(p, key, None)
+    if cache is None or cache[0] != stamp:
+        w = p.detach() if kscale is None else p.detach() * kscale.detach()[:, None]
+        cache = (stamp, w.t().contiguous())
+        setattr(p, key, cache)
+    return cache[1]
+
+
 def param_bf16_kperm16(p):
     """bf16 copy of a 2-D f32 parameter (N, K) whose K axis is permuted inside every group of 16 to [0-3, 8-11, 4-7, 12-15]: the order
     in which an MFMA 32x32 accumulator tile hands its rows to the next MFMA as an A operand (csrc/mlp_fused.hip, phase 2).  Cached on
