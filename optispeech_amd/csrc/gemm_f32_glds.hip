@@ -27,9 +27,11 @@ int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int
     if (!on || sBk != 1 || a_rowscale || Cin % 32 != 0 || lda % 4 != 0 || sBn % 4 != 0 || sBtap % 4 != 0 || sAb % 4 != 0 || sBb % 4 != 0 ||
         !al16(A) || !al16(B) || N % 8 != 0 || ldc % 4 != 0 || !al16(C))
         return 0;
-    // tile shape: 128 x 128 once that fills the chip (>= 192 tiles), else 128 x 64; fewer than 192 of those: the old kernel's 64 x 64 tiles
+    // tile shape: 128 x 128 once that fills the chip (>= 192 tiles), else 128 x 64; fewer than 64 of those: the old kernel with its 64 x 64 tiles
+    static int64_t tmin = -1;
+    if (tmin < 0) { const char* e = getenv("OSP_GEMM_F32_DMA_MIN"); tmin = e ? atoi(e) : 64; }           // (measured: 10-18 % over the old kernel down to ~60 tiles, profiles/r04_gemm_f32_probe.txt)
     const bool wide = cdiv(M, 128) * cdiv(N, 128) * batch >= 192;
-    if (!wide && cdiv(M, 128) * cdiv(N, 64) * batch < 192) return 0;
+    if (!wide && cdiv(M, 128) * cdiv(N, 64) * batch < tmin) return 0;
     GemmB p;
     // global strides and extents of the two operands in 2-BYTE units (see the body): an f32 element is two of them
     p.A = A; p.a_bf16 = 0; p.lda = 2 * lda; p.M = (int)M; p.Trows = (int)T; p.Tin = (int)T; p.Cin = (int)(2 * Cin);

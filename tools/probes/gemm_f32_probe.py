@@ -3,7 +3,8 @@ import os, torch
 from optispeech_amd import kernels as K
 dev = "cuda"
 for (M, T, cin, taps, n) in [(8192, 128, 256, 1, 1024), (8192, 128, 1024, 1, 256), (8192, 128, 256, 3, 384), (8192, 128, 384, 3, 384),
-                             (25600, 800, 256, 1, 1024), (25600, 800, 1024, 1, 256), (4096, 128, 256, 1, 1024), (4096, 128, 256, 5, 256)]:
+                             (25600, 800, 256, 1, 1024), (25600, 800, 1024, 1, 256), (4096, 128, 256, 1, 1024), (4096, 128, 256, 5, 256),
+                             (2048, 64, 1152, 1, 384), (2048, 64, 384, 1, 1152), (4096, 128, 1024, 1, 256), (4096, 128, 256, 3, 384), (2048, 64, 384, 1, 1088), (2048, 64, 1088, 1, 256)]:
     x = torch.randn(M, cin, device=dev); w = torch.randn(n, taps, cin, device=dev) * 0.03; b = torch.zeros(n, device=dev)
     fn = lambda: K.conv_gemm(x, w, n, T=T, taps=taps, pad=(taps - 1) // 2, bias=b, epi=K.EPI_GELU)
     for _ in range(3): fn()
