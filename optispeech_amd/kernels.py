@@ -93,6 +93,10 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
              rowmask, rowscale, aux_out, aux_in, 0, ld_aux_, 0.0, batch, batch_strides[0], batch_strides[1],
              batch_strides[2], batch_strides[3], bool(accumulate))
         return out
+    if batch == 1 and w_param is not None and w_strides[2] != 1 and a.is_cuda:
+        # exact-f32 modes: a k-strided view of a PARAMETER (the flipped-tap / transposed weights of an input-gradient conv) is
+        # gathered into a k-contiguous f32 pack once per optimizer epoch, so that the GEMM can take the direct-to-LDS kernel
+        w, w_strides = _param_pack_f32(w_param, w, n_out, taps, cin, w_strides), (taps * cin, cin, 1)
     ldc = out.stride(-2) if ldc is None else ldc
     ld_aux = 0
     for t in (aux_out, aux_in):
@@ -103,6 +107,33 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
          n_out, out, ldc, epi, bias, gamma, res, ldr, rowmask, rowscale, aux_out, aux_in, ld_aux, batch,
          batch_strides[0], batch_strides[1], batch_strides[2], batch_strides[3], bool(accumulate))
     return out
+
+
+_F32_IDX = {}           # (device, offset, n_out, taps, cin, strides) -> gather index of an f32 pack
+
+
+def _param_pack_f32(p, w, n_out, taps, cin, w_strides):
+    """(n_out, taps, cin) f32 copy of the strided view ``w`` of Parameter ``p`` (element strides ``w_strides``, negative ones allowed),
+    cached on ``p`` for the current optimizer epoch (same invalidation rule as the bf16 packs); one torch gather per refresh."""
+    from . import values
+    off = (w.data_ptr() - p.data_ptr()) // 4
+    key = (off, n_out, taps, cin, tuple(w_strides))
+    stamp = (values.param_epoch(), p._version, p.data_ptr())
+    cache = getattr(p, "_osp_packs_f32", None)
+    if cache is None or cache[0] != stamp:
+        cache = (stamp, {})
+        p._osp_packs_f32 = cache
+    wp = cache[1].get(key)
+    if wp is None:
+        ik = (str(p.device),) + key
+        idx = _F32_IDX.get(ik)
+        if idx is None:
+            ar = lambda n: torch.arange(n, device=p.device, dtype=torch.int64)
+            idx = (off + ar(n_out)[:, None, None] * w_strides[0] + ar(taps)[None, :, None] * w_strides[1]
+                   + ar(cin)[None, None, :] * w_strides[2]).reshape(-1)
+            _F32_IDX[ik] = idx
+        wp = cache[1][key] = p.detach().reshape(-1)[idx].view(n_out, taps, cin)
+    return wp
 
 
 _PACK_REG = {}          # (id(param), view key) -> (weakref(param), view key): every pack ever asked for through _param_pack
