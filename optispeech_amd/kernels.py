@@ -93,9 +93,11 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
              rowmask, rowscale, aux_out, aux_in, 0, ld_aux_, 0.0, batch, batch_strides[0], batch_strides[1],
              batch_strides[2], batch_strides[3], bool(accumulate))
         return out
-    if batch == 1 and w_param is not None and w_strides[2] != 1 and a.is_cuda:
+    if (batch == 1 and w_param is not None and w_strides[2] != 1 and a.is_cuda and -(-M // 128) * -(-n_out // 64) >= 64
+            and not _tape_recording()):
         # exact-f32 modes: a k-strided view of a PARAMETER (the flipped-tap / transposed weights of an input-gradient conv) is
-        # gathered into a k-contiguous f32 pack once per optimizer epoch, so that the GEMM can take the direct-to-LDS kernel
+        # gathered into a k-contiguous f32 pack once per optimizer epoch, so that the GEMM can take the direct-to-LDS kernel (only at
+        # sizes that kernel takes; the gather is a torch op: never while a call tape is being recorded)
         w, w_strides = _param_pack_f32(w_param, w, n_out, taps, cin, w_strides), (taps * cin, cin, 1)
     ldc = out.stride(-2) if ldc is None else ldc
     ld_aux = 0
@@ -107,6 +109,17 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
          n_out, out, ldc, epi, bias, gamma, res, ldr, rowmask, rowscale, aux_out, aux_in, ld_aux, batch,
          batch_strides[0], batch_strides[1], batch_strides[2], batch_strides[3], bool(accumulate))
     return out
+
+
+def _tape_recording():
+    """True while a call tape is being recorded or a hipGraph captured: no torch-made weight pack may be created (a tape would be
+    poisoned; a pack allocated during a capture lives in the graph's private pool and must not be cached on the Parameter)."""
+    from . import tape
+    return tape.recording() or torch.cuda.is_current_stream_capturing()
+
+
+def f32_packs_ok():
+    return not _tape_recording()
 
 
 _F32_IDX = {}           # (device, offset, n_out, taps, cin, strides) -> gather index of an f32 pack

@@ -306,13 +306,14 @@ class ConvNeXtBlockFn(torch.autograd.Function):
             # exact-f32 path (f32 / "mixed" modes).  The transposed weights are materialised k-contiguous once per optimizer epoch:
             # as k-strided views the two input-gradient GEMMs stay on the register-staged kernel, as packs they take the
             # direct-to-LDS one (csrc/gemm_f32_glds.hip)
-            if dy.is_cuda:
+            packs = dy.is_cuda and K.f32_packs_ok()
+            if packs:
                 du = K.conv_gemm(dy2, K.param_f32_t(W2, gamma), I, cin=C, epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u)
             else:
                 du = K.conv_gemm(dy2, W2 * gamma[:, None], I, cin=C, w_strides=(1, 0, I), epi=K.EPI_GELU_BWD, rowscale=rowf, aux_in=u)
             if _want(W2):
                 K.conv_wgrad(dy2, g, gsink(W2), gsink(b2) if _want(b2) else None, arow=rowf, oscale=gamma)
-            dh = K.conv_gemm(du, K.param_f32_t(W1), C, cin=I) if dy.is_cuda else K.conv_gemm(du, W1, C, cin=I, w_strides=(1, 0, C))
+            dh = K.conv_gemm(du, K.param_f32_t(W1), C, cin=I) if packs else K.conv_gemm(du, W1, C, cin=I, w_strides=(1, 0, C))
             if _want(W1):
                 K.conv_wgrad(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None)
         wl, wd = _want(lnw), _want(dw)
