@@ -467,30 +467,51 @@ extern "C" int osp_gather_rows(const float* src, const int64_t* start, int64_t m
 }
 
 // hard length regulator: out[b, t, :] = x[b, n(t), :] with cum[n] <= t < cum[n+1]; zero past the length  (:283-297)
-__global__ void expand_by_duration_kernel(const float* __restrict__ x, const int64_t* __restrict__ dur,
-                                          float* __restrict__ out, int Nm, int Tout, int C) {
-    __shared__ int tok;
-    const int b = blockIdx.y, t = blockIdx.x;
-    if (threadIdx.x == 0) {
-        int64_t cum = 0;
-        int found = -1;
-        for (int n = 0; n < Nm; ++n) {
-            const int64_t nx = cum + dur[(int64_t)b * Nm + n];
-            if (cum <= t && t < nx) { found = n; break; }
-            cum = nx;
-        }
-        tok = found;
-    }
+// A workgroup = 32 output frames of one utterance: the cumulative durations are scanned ONCE into LDS (Hillis-Steele over the
+// tokens), every wave then takes frames, finds the token by a binary search in LDS (wave-uniform) and copies the row as float4s.
+// (Round 1's kernel was one workgroup per frame whose thread 0 walked the durations serially: 80 us at 64 x 768 frames.)
+#define EXP_FB 32
+__global__ __launch_bounds__(256) void expand_by_duration_kernel(const float* __restrict__ x, const int64_t* __restrict__ dur,
+                                                                 float* __restrict__ out, int Nm, int Tout, int C) {
+    extern __shared__ int exp_cum[];                               // [2][Nm + 1]: ping-pong buffers of the scan
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = Nm + 1;
+    int* a = exp_cum;
+    int* bb = exp_cum + L;
+    for (int n = tid; n < L; n += 256) a[n] = n == 0 ? 0 : (int)dur[(int64_t)b * Nm + n - 1];      // a[n] = dur[n - 1]: inclusive scan -> cum[n]
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-        out[((int64_t)b * Tout + t) * C + c] = tok >= 0 ? x[((int64_t)b * Nm + tok) * C + c] : 0.f;
+    for (int off = 1; off < L; off <<= 1) {
+        for (int n = tid; n < L; n += 256) bb[n] = a[n] + (n >= off ? a[n - off] : 0);
+        __syncthreads();
+        int* t_ = a; a = bb; bb = t_;
+    }
+    const int total = a[Nm];
+    const int t0 = blockIdx.x * EXP_FB;
+    for (int f = wave; f < EXP_FB; f += 4) {
+        const int t = t0 + f;
+        if (t >= Tout) break;
+        int tok = -1;
+        if (t < total) {                                           // largest n with cum[n] <= t (durations may be 0: the last such n has dur > 0)
+            int lo = 0, hi = Nm;                                   // invariant: cum[lo] <= t < cum[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a[mid] <= t) lo = mid; else hi = mid; }
+            tok = lo;
+        }
+        float* o = out + ((int64_t)b * Tout + t) * C;
+        if ((C & 3) == 0) {
+            const float4* src = reinterpret_cast<const float4*>(x + ((int64_t)b * Nm + (tok >= 0 ? tok : 0)) * C);
+            for (int c = lane; c < C / 4; c += 64) reinterpret_cast<float4*>(o)[c] = tok >= 0 ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int c = lane; c < C; c += 64) o[c] = tok >= 0 ? x[((int64_t)b * Nm + tok) * C + c] : 0.f;
+        }
+    }
 }
 extern "C" int osp_expand_by_duration(const float* x, const int64_t* dur, float* out, int64_t B, int64_t Nm,
                                       int64_t Tout, int64_t C, hipStream_t stream) {
     OSP_CHECK_ARG(x && dur && out, "null operand");
     if (Tout == 0) return OSP_OK;
-    hipLaunchKernelGGL(expand_by_duration_kernel, dim3((unsigned)Tout, (unsigned)B), dim3(64), 0, stream, x, dur, out,
-                       (int)Nm, (int)Tout, (int)C);
+    OSP_CHECK_ARG(Nm > 0 && Nm <= 8000, "token count out of range");
+    hipLaunchKernelGGL(expand_by_duration_kernel, dim3((unsigned)cdiv(Tout, EXP_FB), (unsigned)B), dim3(256), 2 * (Nm + 1) * sizeof(int), stream,
+                       x, dur, out, (int)Nm, (int)Tout, (int)C);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

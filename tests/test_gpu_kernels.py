@@ -172,3 +172,21 @@ def test_convnext_backbone_vs_oracle(C, I, L):
     # eval-mode / no-grad path gives the same forward
     with torch.no_grad():
         assert relerr(m(xg, pad.to(DEV)), y) < 1e-4
+
+
+@pytest.mark.parametrize("B,N,C", [(3, 17, 256), (64, 128, 256), (2, 300, 100), (1, 1, 8)])
+def test_expand_by_duration_vs_repeat_interleave(B, N, C):
+    """Hard length regulator (alignments.py:283-297) incl. zero durations and ragged totals: bit-exact copies, zeros past the length."""
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B, N, C, generator=g)
+    dur = torch.randint(0, 9, (B, N), generator=g)
+    dur[:, 0] = torch.randint(0, 3, (B,), generator=g)
+    dur[-1, N // 2:] = 0                                              # a short utterance in the batch
+    Tout = int(dur.sum(1).max().item()) + 3
+    want = torch.zeros(B, Tout, C)
+    for b in range(B):
+        r = torch.repeat_interleave(x[b], dur[b], dim=0)
+        want[b, : r.shape[0]] = r
+    got = K.expand_by_duration(x.to(DEV), dur.to(DEV), Tout)
+    assert torch.equal(got.cpu(), want)
