@@ -37,10 +37,15 @@ __global__ __launch_bounds__(256) void conv_gemm_bf16_glds_n64_kernel(const Gemm
 // and tap; Cin = 1: write N*2 bytes per row), so they get VALU kernels that touch every byte once with 16-byte accesses.
 
 // one output element through the run-time epilogue (same semantics as gemm_bf16_epilogue_t)
+__device__ __forceinline__ void gemm_bf16_epi_elem_at(const GemmB& pp, float acc, int m, int n, int64_t bz, int u, int th, int tw);
 __device__ __forceinline__ void gemm_bf16_epi_elem(const GemmB& pp, float acc, int m, int n, int64_t bz) {
+    const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
+    gemm_bf16_epi_elem_at(pp, acc, m, n, bz, u, th, tw);
+}
+// ... with the row's (utterance, h, w) already known to the caller
+__device__ __forceinline__ void gemm_bf16_epi_elem_at(const GemmB& pp, float acc, int m, int n, int64_t bz, int u, int th, int tw) {
     const float v = acc + (pp.bias ? pp.bias[n] : 0.f);
     const int64_t mr = bz * pp.M + m;
-    const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
     const int64_t crow = (int64_t)u * pp.Tc + (int64_t)(th * pp.c_step_h + pp.c_off_h) * pp.Wc + (int64_t)tw * pp.c_step + pp.c_off;
     const char* aux_in = pp.aux_in ? reinterpret_cast<const char*>(pp.aux_in) + bz * pp.sXb * (pp.aux_bf16 ? 2 : 4) : nullptr;
     float out = v;
@@ -127,24 +132,97 @@ __global__ __launch_bounds__(256) void conv_rowdot_bf16_kernel(const GemmB pp) {
     }
 }
 
+// The same with the tap window (KH x KW), the chunks per lane (CPL = Cin / 8 / L) and the rows per lane group and trip (R) fixed at
+// compile time: every 16-byte load of a trip is requested before the first product, row maps use the multiply-high dividers.
+// (The loop above walks the taps one L2 round trip at a time and spends ~30 VALU instructions per tap on 64-bit row arithmetic --
+// at a 64-lane wave's 4 clocks per instruction that, not memory, set its time: 30 us per phase of the DiscriminatorR first-layer
+// dgrad, 268 k rows x 64 channels x 6-12 taps.)
+template <int L, int KH, int KW, int CPL, int R>
+__global__ __launch_bounds__(256) void conv_rowdot_fixed_bf16_kernel(const GemmB pp) {
+    extern __shared__ uint4 rd_w[];
+    constexpr int TAPS = KH * KW, C8 = L * CPL, RPB = 256 / L;
+    for (int idx = threadIdx.x; idx < TAPS * C8; idx += 256) {
+        const int tap = idx / C8, c8 = idx - tap * C8, kh = tap / KW, kw = tap - kh * KW;
+        rd_w[idx] = ld8_contig(pp.B, pp.b_bf16, kh * pp.sBtap_h + kw * pp.sBtap + c8 * 8, false);
+    }
+    __syncthreads();
+    const unsigned short* __restrict__ A = reinterpret_cast<const unsigned short*>(pp.A);
+    const int sub = threadIdx.x % L, rgrp = threadIdx.x / L;
+    const int rstride = gridDim.x * RPB;
+    const int HT = pp.Hin * pp.Tin;
+    for (int m0 = blockIdx.x * RPB + rgrp; m0 < pp.M; m0 += rstride * R) {
+        uint4 av[R][TAPS][CPL];
+        bool ok[R][TAPS];
+        int us[R], ths[R], tws[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int mm = m0 + r * rstride, m = mm < pp.M ? mm : m0;
+            const int u = fd_div(m, pp.fd_trows), t = m - u * pp.Trows, th = fd_div(t, pp.fd_wrows), tw = t - th * pp.Wrows;
+            us[r] = u; ths[r] = th; tws[r] = tw;
+            const int at = tw * pp.a_step + pp.a_off, ah = th * pp.a_step_h + pp.a_off_h;
+            const int base = u * HT;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int hh = ah + kh * pp.a_tapstep_h, tt = at + kw * pp.a_tapstep;
+                    const bool o = (unsigned)hh < (unsigned)pp.Hin && (unsigned)tt < (unsigned)pp.Tin;
+                    const int row = o ? base + hh * pp.Tin + tt : 0;                         // index select: the load stays unconditional
+                    const uint4* __restrict__ ar = reinterpret_cast<const uint4*>(A + (int64_t)row * pp.lda);
+                    ok[r][kh * KW + kw] = o;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) av[r][kh * KW + kw][j] = ar[sub + j * L];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) d = dot8_bf16(av[r][tap][j], rd_w[tap * C8 + sub + j * L], d);
+                acc += ok[r][tap] ? d : 0.f;
+            }
+#pragma unroll
+            for (int o = L >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            const int mm = m0 + r * rstride;
+            if (sub == 0 && mm < pp.M) gemm_bf16_epi_elem_at(pp, acc, mm, 0, 0, us[r], ths[r], tws[r]);
+        }
+    }
+}
+
 // Cin == 1: y[m, n] = epi(bias[n] + sum_tap A[row(m, tap)] * B[n, tap]), taps <= 9.  One thread owns 8 consecutive n
 // (weights in registers) and walks rows; the LRELU_BWD epilogue on bf16 operands is vectorised (16-byte aux / res / C).
 // Algorithmic bytes per row: N * 2 written (+ N * 2 per bf16 epilogue operand read).
 #define OUTER_MAXT 9
+template <int MAXT>                      // 3: the (3, 1)-tap conv_post layers (24 weight registers instead of 72: twice the waves per CU)
 __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
+    // the taps x N weights go through LDS: consecutive threads fetch consecutive n (stride sBn: a few cache lines per wave
+    // instruction) and every thread then reads its 8 channels of a tap as two 16-byte LDS words.  (Until round 4 each thread
+    // fetched its own 8 x taps weights with 2-byte global loads at stride sBn -- 72 instructions of ~24 cache lines per wave:
+    // ~15 us of every workgroup round at N = 1024, the whole kernel at 1.2 TB/s.)
+    extern __shared__ float ow_lds[];
+    const int Nw = pp.N;
+    for (int idx = threadIdx.x; idx < pp.taps * Nw; idx += 256) {
+        const int tap = idx / Nw, nn = idx - tap * Nw, kh = tap / pp.KW, kw = tap - kh * pp.KW;
+        ow_lds[idx] = ld_elem(pp.B, pp.b_bf16, (int64_t)nn * pp.sBn + kh * pp.sBtap_h + kw * pp.sBtap);
+    }
+    __syncthreads();
     const int N8 = pp.N >> 3, rpb = 256 / N8 > 0 ? 256 / N8 : 1;
     const int n8 = threadIdx.x % N8, rgrp = threadIdx.x / N8;
     if (rgrp >= rpb) return;
     const int n = n8 * 8;
-    float w[OUTER_MAXT][8], bias[8];
+    float w[MAXT][8], bias[8];
 #pragma unroll
-    for (int tap = 0; tap < OUTER_MAXT; ++tap) {
-        const int tp = tap < pp.taps ? tap : 0, kh = tp / pp.KW, kw = tp - kh * pp.KW;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float v = ld_elem(pp.B, pp.b_bf16, (int64_t)(n + q) * pp.sBn + kh * pp.sBtap_h + kw * pp.sBtap);
-            w[tap][q] = tap < pp.taps ? v : 0.f;
+    for (int tap = 0; tap < MAXT; ++tap) {
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (tap < pp.taps) {
+            lo = *reinterpret_cast<const float4*>(ow_lds + tap * Nw + n);
+            hi = *reinterpret_cast<const float4*>(ow_lds + tap * Nw + n + 4);
         }
+        w[tap][0] = lo.x; w[tap][1] = lo.y; w[tap][2] = lo.z; w[tap][3] = lo.w;
+        w[tap][4] = hi.x; w[tap][5] = hi.y; w[tap][6] = hi.z; w[tap][7] = hi.w;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) bias[q] = pp.bias ? pp.bias[n + q] : 0.f;
@@ -152,7 +230,8 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
                          (pp.ldc & 7) == 0 && (pp.ld_aux & 7) == 0 && (pp.ldr & 7) == 0 &&
                          ((reinterpret_cast<uintptr_t>(pp.C) | reinterpret_cast<uintptr_t>(pp.aux_in) |
                            reinterpret_cast<uintptr_t>(pp.res_any)) & 15) == 0;
-    if (vec_epi && pp.taps <= 3) {
+    if constexpr (MAXT <= 3) {
+      if (vec_epi) {
         // the conv_post dgrad (Cin = 1, 3 taps, LeakyReLU' on bf16 rows): 4 rows per trip with every load -- the taps' dy scalars,
         // the y and extra rows -- requested before the first use (round 2 walked one row at a time: a full memory latency per row
         // and 32 bytes in flight per thread, 61 us for the 1024-channel layer = 1.3 TB/s), multiply-high dividers for the row maps
@@ -203,6 +282,7 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
             }
         }
         return;
+      }
     }
     for (int m = blockIdx.x * rpb + rgrp; m < pp.M; m += gridDim.x * rpb) {
         const int u = m / pp.Trows, t = m - u * pp.Trows, th = t / pp.Wrows, tw = t - th * pp.Wrows;
@@ -212,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_outer_bf16_kernel(const GemmB pp) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int tap = 0; tap < OUTER_MAXT; ++tap) {
+        for (int tap = 0; tap < MAXT; ++tap) {
             const int tp = tap < pp.taps ? tap : 0, kh = tp / pp.KW, kw = tp - kh * pp.KW;
             const int hh = ah + kh * pp.a_tapstep_h, tt = at + kw * pp.a_tapstep;
             const bool ok = tap < pp.taps && (unsigned)hh < (unsigned)pp.Hin && (unsigned)tt < (unsigned)pp.Tin;
@@ -291,6 +371,24 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         const dim3 grid((unsigned)(nb < 4096 ? nb : 4096));
         const size_t lds = (size_t)taps * Cin * 2;
         osp_note_symbol("conv_rowdot_bf16_kernel");
+        {   // the hot shapes run with their tap window unrolled (same symbol note: one kernel family)
+            const int kw_ = p.KW > 0 ? p.KW : 1, kh_ = (int)taps / kw_;
+            static int use_fixed = -1;
+            if (use_fixed < 0) { const char* e = getenv("OSP_ROWDOT_FIXED"); use_fixed = (e && atoi(e) == 0) ? 0 : 1; }
+            bool done = false;
+#define OSP_ROWDOT_FX(L_, KH_, KW_, CPL_, R_)                                                                                   \
+            if (!done && use_fixed && M < (1 << 30) && c8 == L_ * CPL_ && kh_ == KH_ && kw_ == KW_ && kh_ * kw_ == taps) {          \
+                const int64_t nbf = cdiv(M, (256 / L_) * R_);                                                                     \
+                hipLaunchKernelGGL((conv_rowdot_fixed_bf16_kernel<L_, KH_, KW_, CPL_, R_>), dim3((unsigned)(nbf < 2048 ? nbf : 2048)), \
+                                   dim3(256), lds, stream, p);                                                                    \
+                done = true;                                                                                                      \
+            }
+            OSP_ROWDOT_FX(8, 3, 4, 1, 1) OSP_ROWDOT_FX(8, 3, 3, 1, 2) OSP_ROWDOT_FX(8, 2, 4, 1, 2) OSP_ROWDOT_FX(8, 2, 3, 1, 2)   // DiscriminatorR: first-layer dgrad phases, conv_post
+            OSP_ROWDOT_FX(64, 1, 3, 2, 2)                                                                                         // DiscriminatorP conv_post (1024 channels, taps along the frame axis)
+            OSP_ROWDOT_FX(4, 1, 2, 1, 4) OSP_ROWDOT_FX(4, 1, 1, 1, 4)                                                             // DiscriminatorP first-layer dgrad phases (32 channels)
+#undef OSP_ROWDOT_FX
+            if (done) { OSP_LAUNCH_CHECK(); return OSP_OK; }
+        }
 #define OSP_ROWDOT(L_) hipLaunchKernelGGL((conv_rowdot_bf16_kernel<L_>), grid, dim3(256), lds, stream, p)
         switch (L) { case 64: OSP_ROWDOT(64); break; case 32: OSP_ROWDOT(32); break; case 16: OSP_ROWDOT(16); break;
                      case 8: OSP_ROWDOT(8); break; case 4: OSP_ROWDOT(4); break; case 2: OSP_ROWDOT(2); break; default: OSP_ROWDOT(1); }
@@ -298,10 +396,14 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
-    if (use_degen && Cin == 1 && single && !a_rowscale && taps <= OUTER_MAXT && N % 8 == 0 && N >= 8 && N <= 2048) {
-        const int64_t rpb = 256 / (N / 8) > 0 ? 256 / (N / 8) : 1, nb = cdiv(M, rpb * 4);
+    if (use_degen && Cin == 1 && single && !a_rowscale && taps <= OUTER_MAXT && N % 8 == 0 && N >= 8 && N <= 2048 && taps * N * 4 <= 65536) {
+        // <= 3 taps: four rows per thread and trip, at most four workgroups per CU (the weights are staged once per workgroup:
+        // 1624 -> 1024 workgroups = 24 -> 20 us at 12992 x 1024).  More taps: one row per thread and trip, so small problems
+        // (the 64-channel conv_post of DiscriminatorR: 4896 rows) still spread over > 100 workgroups instead of 39.
+        const int64_t rpb = 256 / (N / 8) > 0 ? 256 / (N / 8) : 1, nb = cdiv(M, rpb * (taps <= 3 ? 4 : 1));
         osp_note_symbol("conv_outer_bf16_kernel");
-        hipLaunchKernelGGL(conv_outer_bf16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, p);
+        if (taps <= 3) hipLaunchKernelGGL((conv_outer_bf16_kernel<3>), dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), (size_t)(taps * N * 4), stream, p);
+        else hipLaunchKernelGGL((conv_outer_bf16_kernel<OUTER_MAXT>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), (size_t)(taps * N * 4), stream, p);
         OSP_LAUNCH_CHECK();
         return OSP_OK;
     }
