@@ -116,6 +116,7 @@ def test_mpd_bf16_path_matches_f32_path(which):
 @pytest.mark.parametrize("U,H,W,cin,cout,spec", [
     (3, 33, 65, 1, 64, (5, 7, 2, 2, 2, 3)), (2, 17, 40, 64, 64, (3, 5, 1, 2, 1, 2)), (2, 20, 31, 64, 64, (3, 5, 2, 2, 1, 2)),
     (2, 9, 17, 64, 64, (3, 3, 2, 2, 1, 1)), (2, 9, 17, 64, 1, (3, 3, 1, 1, 1, 1)),
+    (5, 1, 203, 1024, 1, (1, 3, 1, 1, 0, 1)), (4, 1, 301, 1, 32, (1, 5, 1, 3, 0, 2)),         # DiscriminatorP conv_post / convs[0]: the fixed-window row-dot kernels (L = 64 with 2 chunks per lane; L = 4, 2- and 1-tap dgrad phases) and the 3-tap outer kernel
     (6, 1, 700, 32, 128, (1, 5, 1, 3, 0, 2)), (3, 2, 97, 32, 64, (1, 5, 1, 3, 0, 2))])      # 32 input channels: DiscriminatorP convs[1] (weight gradient on the 64-tile kernel, upper half zero)
 def test_conv2d_bf16_forward_dgrad_wgrad(U, H, W, cin, cout, spec):
     """channels-last conv2d on the bf16 GEMM vs torch conv2d (asymmetric kernels/strides/paddings per dim)."""
