@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-shape timing of the degenerate-shape kernels (conv_rowdot_bf16_kernel: N = 1, conv_outer_bf16_kernel: Cin = 1) at the shapes a
 B = 32 step really launches them on: every such call of one eager step is re-issued REP times back to back between two events
-(same arguments, buffers still live), so the figure is kernel time without launch gaps.
+(same arguments, buffers still live), so the figure is kernel time without launch gaps.  SYMS=a,b selects other symbols -- but only
+calls issued on torch's CURRENT stream are timed correctly: the events are recorded there, and the weight-gradient entry points
+launch on their own side streams (their figures come out as launch overhead, ~4 us).
     OSP_DISC_STREAMS=0 OSP_VOC_STREAM=0 PYTHONPATH=. python tools/probes/degen_probe.py"""
 import collections, ctypes, os, sys
 import torch
