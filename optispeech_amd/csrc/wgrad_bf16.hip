@@ -7,17 +7,7 @@ __device__ __attribute__((aligned(256))) unsigned osp_zero_page_w[64];
 #define osp_zero_page osp_zero_page_w
 
 // ------------------------------------------------------------------------------------------------ wgrad
-// dW[n, j, c] += oscale[n] * sum_{u,t} arow * dY[u, t, n] * X[u, t*x_step + j - pad, c];  db[n] likewise.
-// Both operands are reduction-major -> transposing loader for both.  Split over the frame dimension, f32 atomics.
-struct WgradB {
-    const void* dY; int y_bf16; int64_t ldy; const void* X; int x_bf16; int64_t ldx;
-    int M, Trows, Tin, N, Cin, taps, pad, x_step;
-    int Wrows, Hin, KW, x_step_h, pad_h;              // 2-D extension (1-D: Wrows = Trows, Hin = 1, KW = taps)
-    FastDiv fd_trows, fd_wrows;
-    const float *arow, *oscale; float* dW; int64_t ldw; float* db; int chunk, splits;
-    int64_t sYb, sXb, sWb, sDb;
-    unsigned y_bytes, x_bytes;                        // extent of one batch slice of dY / X (buffer-resource variant)
-};
+#include "wgrad_common.h"
 
 __device__ __forceinline__ float4 ld4_any(const void* p, int is_bf16, int64_t off, int lim, bool vec) {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -602,11 +592,13 @@ int osp_launch_wgrad_n1(const void* dY, int64_t y_bf16, int64_t ldy, const void*
                         int64_t Tin, int64_t Cin, int64_t taps, int64_t KW, int64_t pad, int64_t pad_h, int64_t x_step, int64_t x_step_h,
                         const float* arow, const float* oscale, float* dW, float* db, hipStream_t stream);      // wgrad_n1.hip
 
+int osp_launch_wgrad_ring(WgradB& p, int64_t batch, float* ws, int64_t ws_bytes, hipStream_t stream);     // wgrad_ring.hip
+
 static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
                                    int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
                                    int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
                                    float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
-                                   hipStream_t stream) {
+                                   float* ws, int64_t ws_bytes, hipStream_t stream) {
     OSP_CHECK_ARG(dY && X && dW, "null operand");
     OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && Trows > 0 && M % Trows == 0 && batch > 0, "bad shape");
     WgradB p;
@@ -627,6 +619,14 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
         (reinterpret_cast<uintptr_t>(X) & 15) == 0)
         return osp_launch_wgrad_n1(dY, y_bf16, ldy, X, ldx, M, Trows, d2[0], d2[1], Tin, Cin, taps, d2[2], pad, d2[4], x_step, d2[3], arow, oscale,
                                    dW, db, stream);
+    // ring-pipelined, atomic-free kernels (wgrad_ring.hip) for every shape they take; the 8-wave 256 x 256 kernel below keeps the
+    // widest DiscriminatorP layers
+    static int w8first = -1;
+    if (w8first < 0) { const char* e = getenv("OSP_WGRAD_W8"); w8first = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!(w8first && N % 256 == 0 && Cin % 256 == 0 && M >= 8192 && batch == 1)) {
+        const int took = osp_launch_wgrad_ring(p, batch, ws, ws_bytes, stream);
+        if (took) { OSP_LAUNCH_CHECK(); return OSP_OK; }
+    }
     const int64_t tiles = cdiv(N, TBM) * taps * cdiv(Cin, TBN) * batch;
     static int64_t tgt_gen = 0;
     if (!tgt_gen) { tgt_gen = 512; }
@@ -678,7 +678,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_tr8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_tr8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         }
-        if (w8 && N % 256 == 0 && Cin % 256 == 0 && M >= 4096) {
+        if (w8 && N % 256 == 0 && Cin % 256 == 0 && M >= 8192) {
             const int64_t tl8 = (N / 256) * taps * (Cin / 256) * batch;
             static int64_t tgt8 = -1;
             if (tgt8 < 0) { tgt8 = 256; }
@@ -730,7 +730,20 @@ extern "C" int osp_conv_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy, 
                                    hipStream_t stream) {
     const int64_t d2[5] = {Trows, 1, taps, 0, 0};
     return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Tin, N, Cin, taps, pad, x_step, arow, oscale, dW, ldw,
-                                db, batch, sYb, sXb, sWb, sDb, stream);
+                                db, batch, sYb, sXb, sWb, sDb, nullptr, 0, stream);
+}
+
+// The same with a caller-supplied workspace (ws_bytes of device memory, 16-byte aligned, private to this call until the stream
+// has passed it): the frame splits leave their partial sums there and a second launch adds them up in a fixed order --
+// no f32 atomics, bit-reproducible weight gradients (csrc/wgrad_ring.hip).  The workspace bounds the number of splits.
+extern "C" int osp_conv_wgrad_bf16_ws(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                      int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
+                                      int64_t x_step, const float* arow, const float* oscale, float* dW, int64_t ldw,
+                                      float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                      float* ws, int64_t ws_bytes, hipStream_t stream) {
+    const int64_t d2[5] = {Trows, 1, taps, 0, 0};
+    return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Tin, N, Cin, taps, pad, x_step, arow, oscale, dW, ldw,
+                                db, batch, sYb, sXb, sWb, sDb, ws, ws_bytes, stream);
 }
 
 // 2-D weight gradient: dW[n, kh, kw, c] += sum dY[u, th, tw, n] * X[u, th*x_step_h + kh - pad_h, tw*x_step + kw - pad, c]
@@ -740,7 +753,16 @@ extern "C" int osp_conv2d_wgrad_bf16(const void* dY, int64_t y_bf16, int64_t ldy
                                      float* dW, float* db, hipStream_t stream) {
     const int64_t d2[5] = {Wrows, Hin, KW, x_step_h, pad_h};
     return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Win, N, Cin, taps, pad, x_step, nullptr, nullptr, dW,
-                                taps * Cin, db, 1, 0, 0, 0, 0, stream);
+                                taps * Cin, db, 1, 0, 0, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int osp_conv2d_wgrad_bf16_ws(const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
+                                        int64_t M, int64_t Trows, int64_t Wrows, int64_t Hin, int64_t Win, int64_t N, int64_t Cin,
+                                        int64_t taps, int64_t KW, int64_t pad_h, int64_t pad, int64_t x_step_h, int64_t x_step,
+                                        float* dW, float* db, float* ws, int64_t ws_bytes, hipStream_t stream) {
+    const int64_t d2[5] = {Wrows, Hin, KW, x_step_h, pad_h};
+    return conv_wgrad_bf16_impl(d2, dY, y_bf16, ldy, X, x_bf16, ldx, M, Trows, Win, N, Cin, taps, pad, x_step, nullptr, nullptr, dW,
+                                taps * Cin, db, 1, 0, 0, 0, 0, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ casts

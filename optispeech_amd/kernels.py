@@ -806,8 +806,24 @@ def conv_gemm_bf16(a, w, n_out, *, M, Trows, Tin, cin, taps=1, a_step=1, a_tapst
     return out
 
 
+_WGRAD_WS_CAP = 32 << 20
+
+
+def wgrad_workspace(n, taps, cin, batch, device):
+    """Scratch for the frame splits of one weight-gradient launch (csrc/wgrad_ring.hip): up to 64 partial copies of dW (+ db),
+    32 MB at most; the library takes as many splits as fit.  From torch's caching allocator, i.e. owned by the current stream
+    (inside a recorded region: by the tape)."""
+    blk = (n * taps * cin + n + 3) // 4 * 16 * batch
+    return torch.empty((min(_WGRAD_WS_CAP, 64 * blk),), device=device, dtype=torch.uint8)
+
+
 def conv_wgrad_bf16(dy, x, dw, db=None, *, M, Trows, Tin, n, cin, taps=1, pad=0, x_step=1, arow=None, oscale=None,
                     batch=1, strides=(0, 0, 0, 0)):
+    if _isbf(dy) and _isbf(x) and arow is None:
+        ws = wgrad_workspace(n, taps, cin, batch, dy.device)
+        call("osp_conv_wgrad_bf16_ws", dy, 1, dy.stride(-2), x, 1, x.stride(-2), M, Trows, Tin, n, cin, taps,
+             pad, x_step, arow, oscale, dw, taps * cin, db, batch, strides[0], strides[1], strides[2], strides[3], ws, ws.numel())
+        return
     call("osp_conv_wgrad_bf16", dy, _isbf(dy), dy.stride(-2), x, _isbf(x), x.stride(-2), M, Trows, Tin, n, cin, taps,
          pad, x_step, arow, oscale, dw, taps * cin, db, batch, strides[0], strides[1], strides[2], strides[3])
 
@@ -827,6 +843,11 @@ def conv2d_gemm_bf16(a, w, n_out, *, M, Trows, Wrows, Hin, Win, cin, taps, KW, a
 
 
 def conv2d_wgrad_bf16(dy, x, dw, db, *, M, Trows, Wrows, Hin, Win, n, cin, taps, KW, pad_h, pad_w, step_h, step_w):
+    if _isbf(dy) and _isbf(x):
+        ws = wgrad_workspace(n, taps, cin, 1, dy.device)
+        call("osp_conv2d_wgrad_bf16_ws", dy, 1, dy.stride(-2), x, 1, x.stride(-2), M, Trows, Wrows, Hin, Win, n, cin,
+             taps, KW, pad_h, pad_w, step_h, step_w, dw, db, ws, ws.numel())
+        return
     call("osp_conv2d_wgrad_bf16", dy, _isbf(dy), dy.stride(-2), x, _isbf(x), x.stride(-2), M, Trows, Wrows, Hin, Win, n, cin,
          taps, KW, pad_h, pad_w, step_h, step_w, dw, db)
 

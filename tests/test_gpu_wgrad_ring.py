@@ -1,0 +1,93 @@
+"""Ring-pipelined, atomic-free weight gradients (csrc/wgrad_ring.hip) against an f64 autograd restatement of the convolution
+whose weight gradient they are (the op: torch autograd of nn.Conv2d / nn.Conv1d at
+optispeech/model/vocoder/wavenext/disc/_discriminators.py:51-60,154-163 and generator/modules/convnext.py:39-41).
+Tolerance: operands are bf16 values held exactly in f64 by the restatement, products accumulate in f32: 2e-4 of the
+gradient's scale (stated per case)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * 0.5).to(torch.bfloat16)
+
+
+def _ref2d(x, dy, KH, KW, sh, sw, ph, pw):
+    """x (U,H,W,C), dy (U,Ho,Wo,N) bf16 -> dW (N,KH,KW,C), db (N) in f64 through torch autograd on the CPU."""
+    xd = x.double().permute(0, 3, 1, 2).contiguous()
+    N, C = dy.shape[-1], x.shape[-1]
+    w = torch.zeros(N, C, KH, KW, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(N, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xd, w, b, stride=(sh, sw), padding=(ph, pw))
+    y.backward(dy.double().permute(0, 3, 1, 2).contiguous())
+    return w.grad.permute(0, 2, 3, 1).contiguous(), b.grad
+
+
+CASES_2D = [
+    # U, H, W, C, N, KH, KW, sh, sw, ph, pw      (DiscriminatorR layer geometries at reduced size, DiscriminatorP as KH = 1)
+    (3, 9, 37, 64, 64, 3, 5, 1, 2, 1, 2),
+    (3, 9, 37, 64, 64, 3, 5, 2, 2, 1, 2),
+    (2, 7, 21, 64, 64, 3, 3, 1, 2, 1, 1),
+    (2, 7, 21, 64, 64, 3, 3, 2, 2, 1, 1),
+    (5, 1, 301, 128, 256, 1, 5, 1, 3, 0, 2),       # 128-tiles, stride 3
+    (5, 1, 301, 32, 128, 1, 5, 1, 3, 0, 2),        # 32 input channels: upper half of the tile reads zeros
+    (4, 1, 150, 128, 128, 1, 5, 1, 1, 0, 2),
+]
+
+
+@pytest.mark.parametrize("case", CASES_2D)
+@pytest.mark.parametrize("one_split", [False, True])
+def test_conv2d_wgrad_ring_vs_f64(case, one_split):
+    from optispeech_amd import kernels as K
+    U, H, W, C, N, KH, KW, sh, sw, ph, pw = case
+    Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+    x, dy = _bf(U, H, W, C, seed=1), _bf(U, Ho, Wo, N, seed=2)
+    want_w, want_b = _ref2d(x, dy, KH, KW, sh, sw, ph, pw)
+    dev = "cuda"
+    xg, dyg = x.to(dev), dy.to(dev)
+    g = torch.Generator().manual_seed(3)
+    w0, b0 = torch.randn(N, KH, KW, C, generator=g), torch.randn(N, generator=g)
+    outs = []
+    for _ in range(2):
+        dw, db = w0.to(dev).clone(), b0.to(dev).clone()
+        M = U * Ho * Wo
+        blk = (N * KH * KW * C + N + 3) // 4 * 16
+        ws = torch.empty((blk if one_split else 64 * blk,), device=dev, dtype=torch.uint8)       # one block: no room for a split
+        K.call("osp_conv2d_wgrad_bf16_ws", dyg.view(M, N), 1, N, xg.view(U * H * W, C), 1, C, M, Ho * Wo, Wo, H, W, N, C, KH * KW, KW, ph,
+               pw, sh, sw, dw, db, ws, ws.numel())
+        outs.append((dw.cpu(), db.cpu()))
+    (dw, db), (dw2, db2) = outs
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "no atomics: two runs must agree bit for bit"
+    sw_, sb_ = want_w.abs().max().item(), want_b.abs().max().item()
+    assert ((dw.double() - w0.double()) - want_w).abs().max().item() <= 2e-4 * sw_ + 1e-6       # `+=` into the existing gradient
+    assert ((db.double() - b0.double()) - want_b).abs().max().item() <= 2e-4 * sb_ + 1e-6
+
+
+@pytest.mark.parametrize("M,N,C,taps,T", [(2048, 384, 1152, 1, 2048), (4096, 1024, 256, 1, 4096), (1024, 128, 192, 3, 128),
+                                          (640, 64, 64, 1, 640)])
+def test_conv_wgrad_ring_pointwise_oscale_batch(M, N, C, taps, T):
+    """The generator's pointwise / k-tap weight gradients: output scale (layer-scale gamma), bias, a batch of 2 problems."""
+    from optispeech_amd import kernels as K
+    dev = "cuda"
+    batch = 2
+    x, dy = _bf(batch, M, C, seed=4), _bf(batch, M, N, seed=5)
+    osc = torch.rand(N, generator=torch.Generator().manual_seed(6)) + 0.5
+    pad = taps // 2
+    want_w = torch.zeros(batch, N, taps, C, dtype=torch.float64)
+    xs = x.double().view(batch, M // T, T, C)
+    ys = dy.double().view(batch, M // T, T, N)
+    for j in range(taps):
+        sh = j - pad
+        lo, hi = max(0, -sh), min(T, T - sh)
+        want_w[:, :, j, :] = torch.einsum("butn,butc->bnc", ys[:, :, lo:hi], xs[:, :, lo + sh:hi + sh])
+    want_w *= osc.double()[None, :, None, None]
+    want_b = dy.double().sum(1) * osc.double()[None]
+    dw = torch.zeros(batch, N, taps, C, device=dev)
+    db = torch.zeros(batch, N, device=dev)
+    K.conv_wgrad_bf16(dy.to(dev), x.to(dev), dw, db, M=M, Trows=T, Tin=T, n=N, cin=C, taps=taps, pad=pad, oscale=osc.to(dev), batch=batch,
+                      strides=(M * N, M * C, N * taps * C, N))
+    assert (dw.cpu().double() - want_w).abs().max().item() <= 2e-4 * want_w.abs().max().item()
+    assert (db.cpu().double() - want_b).abs().max().item() <= 2e-4 * want_b.abs().max().item()

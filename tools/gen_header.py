@@ -15,6 +15,10 @@ REPLACES = {
     "osp_conv_gemm_bf16": "same call sites as osp_conv_gemm_f32 and the weight-normed Conv2d (k,1) stacks of DiscriminatorP "
                           "(vocoder/wavenext/disc/_discriminators.py:51-60,80-90), bf16 operands / f32 accumulate",
     "osp_conv_wgrad_bf16": "weight gradients of the same, bf16 operands / f32 accumulate",
+    "osp_conv_wgrad_bf16_ws": "the same weight gradients with a caller-supplied split workspace: no f32 atomics, bit-reproducible "
+                              "(autograd of nn.Conv1d / nn.Linear: generator/modules/convnext.py:39-41)",
+    "osp_conv2d_wgrad_bf16_ws": "autograd weight gradients of the DiscriminatorP / DiscriminatorR Conv2d stacks "
+                                "(vocoder/wavenext/disc/_discriminators.py:51-60,154-163) with a split workspace instead of atomics",
     "osp_dwconv7_ln_fwd": "ConvNeXtBlock.forward dwconv + LayerNorm: generator/modules/convnext.py:36-38",
     "osp_dwconv7_bwd": "autograd of nn.Conv1d(groups=dim) at generator/modules/convnext.py:36",
     "osp_layernorm_fwd": "nn.LayerNorm: convnext.py:85,102; modules/layers.py:26-45 (eps 1e-12) + nn.Dropout core.py:74; wavenext/__init__.py:84",
