@@ -30,6 +30,23 @@ PMC_SUMMARY = "r04_pmc_glds.json"         # committed summary of the separate ro
 PMC_MFMA = "r04_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM pass (tools/pmc_mfma.sh): matrix-pipe busy share per symbol
 
 
+def _pmc_file(name):
+    """A committed PMC summary (profiles/) + whether it was collected from the sources this library was built from: the summaries
+    carry `source_hash` (tools/pmc_summary.py, tools/pmc_mfma_summary.py); a kernel change without a new counter pass makes them STALE,
+    and the bench line says so instead of quoting old counters as if they belonged to the fresh timings."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        pj = json.load(fh)
+    try:
+        from optispeech_amd.build import source_hash
+        stale = pj.get("source_hash") != source_hash()
+    except Exception:
+        stale = True
+    return pj, stale
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +78,11 @@ def parse():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the GLOBAL batch stays 32 utterances, rank r takes rows [32 r / N, 32 (r + 1) / N) "
                          "(north_star's '>= 6x strong scaling at 8 GPUs'); default is weak scaling, 32 utterances per GPU")
+    ap.add_argument("--local-batch", type=int, default=0,
+                    help="utterances per GPU instead of 32 (VERDICT r04 item 2: the per-rank step of --strong at N = 32 / local-batch "
+                         "ranks, measured on ONE GPU without communication); 0 = the headline configuration")
+    ap.add_argument("--no-scaling-ceiling", action="store_true",
+                    help="skip the strong-scaling ceiling (the eager step at 16 / 8 / 4 utterances on this one GPU)")
     ap.add_argument("--no-transformer", action="store_true", help="skip the configs[3] (Transformer backbone) secondary step figure")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial schedule: do not issue the discriminator phase from its own stream (OptiSpeech.pipeline_steps)")
@@ -430,13 +452,16 @@ def main():
     if a.strong:
         assert B % world == 0, f"--strong splits {B} utterances over {world} ranks"
     Bl = B // world if a.strong else B                       # utterances per rank
+    if a.local_batch:
+        assert not a.strong and world == 1, "--local-batch is a one-GPU measurement"
+        Bl = a.local_batch
     model = make_optispeech(cfg, batch_size=Bl, pretraining_steps=0).to(dev).train()
     if a.strong:                                              # the SAME 32 utterances whatever N is: rank r owns rows [r Bl, (r + 1) Bl)
         full = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234, ragged=a.ragged, device=dev)
         batch = {k: (v[rank * Bl:(rank + 1) * Bl] if (torch.is_tensor(v) or isinstance(v, list)) else v) for k, v in full.items()}
         batch = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in batch.items()}
     else:
-        batch = synthetic_batch(B, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
+        batch = synthetic_batch(Bl, T_TEXT, T_MEL, cfg, seed=1234 + rank, ragged=a.ragged, device=dev)
     model.optimizers()
     for r_ in model._reducers:
         r_.measure = world > 1
@@ -546,7 +571,7 @@ def main():
         sync()
         r_dt = (time.perf_counter() - t2) / 10
         model.replay_disc_forward = keep_r
-        replay = {"ms_per_step": r_dt * 1e3, "mel_frames_per_s": world * B * T_MEL / r_dt, "steps": 10,
+        replay = {"ms_per_step": r_dt * 1e3, "mel_frames_per_s": world * Bl * T_MEL / r_dt, "steps": 10,
                   "note": "OSP_DISC_REPLAY=1: discriminator-phase forward taken from the generator phase's recorded activations (same step, same weights, same waves)"}
     # secondary figure: the same step replayed from a captured hipGraph (one graph on one GPU, five segments with the RCCL
     # all-reduces between them under data parallelism): no Python / autograd / dispatch per step
@@ -567,7 +592,7 @@ def main():
         sync()
         g_dt = (time.perf_counter() - t3) / 10
         model.graph_steps, model.pipeline_steps = keep_g, keep_p
-        graph_fig = {"ms_per_step": g_dt * 1e3, "mel_frames_per_s": world * B * T_MEL / g_dt, "steps": 10,
+        graph_fig = {"ms_per_step": g_dt * 1e3, "mel_frames_per_s": world * Bl * T_MEL / g_dt, "steps": 10,
                      "note": "hipGraph replay of the captured step (OptiSpeech.graph_steps); per-step scalars (dropout seed, AdamW step / lr) "
                              "live in device memory.  Host launch cost of a replay is ~4 ms, but ROCm 7.2 runs the captured branches of "
                              "a multi-stream graph almost serially, so it trails the eager multi-stream schedule"}
@@ -586,7 +611,7 @@ def main():
         sync()
         p_dt = (time.perf_counter() - t4) / 10
         precision.set_precision(a.precision)
-        parity_fig = {"ms_per_step": p_dt * 1e3, "mel_frames_per_s": world * B * T_MEL / p_dt, "steps": 10, "precision": "mixed",
+        parity_fig = {"ms_per_step": p_dt * 1e3, "mel_frames_per_s": world * Bl * T_MEL / p_dt, "steps": 10, "precision": "mixed",
                       "ratio_to_headline": p_dt / (dt / a.steps),
                       "note": "precision 'mixed': generator forward / backward and the spectral losses on the exact-f32 kernels "
                               "(wav_hat / mel <= 1e-3 vs the reference goldens, tests/test_gpu_mixed.py), only the MPD / MRD "
@@ -606,13 +631,35 @@ def main():
             model.training_step(small, 910 + i)
         host_free = (time.perf_counter() - t5) / 20 * 1e3
         sync()
+    # Strong-scaling ceiling: north_star asks >= 6x at 8 GPUs with the GLOBAL batch fixed at 32, i.e. rank steps of
+    # 16 / 8 / 4 utterances.  Their time on this ONE GPU, without any communication, bounds what N ranks can reach:
+    # ceiling(N) = ms(B = 32) / ms(B = 32 / N).  The host needs the same time to enqueue a step whatever the batch, so this is
+    # where the host path shows.
+    ceiling = None
+    if secondary and not a.no_am_only and not a.no_scaling_ceiling and not a.local_batch and not a.graph and a.backbone == "convnext":
+        ceiling = {"how": "the same eager pipelined step at 32 / N utterances on one GPU, 3 warm-up + 20 timed steps each, no communication: "
+                          "ceiling(N) = ms_per_step(32) / ms_per_step(32 / N)", "ms_per_step": {"32": dt / a.steps * 1e3}, "ceiling": {}}
+        for nr in (2, 4, 8):
+            bs = B // nr
+            sb = synthetic_batch(bs, T_TEXT, T_MEL, cfg, seed=1234, ragged=a.ragged, device=dev)
+            for i in range(4):
+                model.training_step(sb, 950 + i)
+            sync()
+            t7 = time.perf_counter()
+            for i in range(20):
+                model.training_step(sb, 960 + i)
+            sync()
+            ms = (time.perf_counter() - t7) / 20 * 1e3
+            ceiling["ms_per_step"][str(bs)] = ms
+            ceiling["ceiling"][str(nr)] = (dt / a.steps * 1e3) / ms
+            del sb
     # secondary figure: BASELINE configs[3], the Transformer backbone at the same batch (eager multi-stream step, same schedule)
     tf_fig = None
     if secondary and not a.no_am_only and not a.no_transformer and a.backbone == "convnext" and a.precision == "bf16":
         tcfg = ModelConfig(backbone="transformer")
-        tm = make_optispeech(tcfg, batch_size=B, pretraining_steps=0).to(dev).train()
+        tm = make_optispeech(tcfg, batch_size=Bl, pretraining_steps=0).to(dev).train()
         tm.pipeline_steps = model.pipeline_steps
-        tb = synthetic_batch(B, T_TEXT, T_MEL, tcfg, seed=1234, ragged=a.ragged, device=dev)
+        tb = synthetic_batch(Bl, T_TEXT, T_MEL, tcfg, seed=1234, ragged=a.ragged, device=dev)
         for i in range(5):
             tm.training_step(tb, i)
         sync()
@@ -621,7 +668,7 @@ def main():
             tm.training_step(tb, 5 + i)
         sync()
         t_dt = (time.perf_counter() - t6) / 10
-        tf_fig = {"ms_per_step": t_dt * 1e3, "mel_frames_per_s": B * T_MEL / t_dt, "steps": 10,
+        tf_fig = {"ms_per_step": t_dt * 1e3, "mel_frames_per_s": Bl * T_MEL / t_dt, "steps": 10,
                   "workload": "configs[3]: Transformer backbone (2 heads, 1 024 linear units, 4 blocks, fused training attention), batch=32, "
                               "T_text=128, T_mel=800, full GAN step"}
         del tm, tb
@@ -674,10 +721,9 @@ def main():
                 "mfma_ms_per_step_total": sum(v["ms_per_step"] for v in table.values())}
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read inside this run);
         # what is reported here is the committed summary of that pass, named so, never a live measurement
-        pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-        if a.precision != "f32" and not a.ragged and os.path.exists(pmc) and dom:
-            with open(pmc) as fh:
-                pj = json.load(fh)
+        pj, pmc_stale = _pmc_file(PMC_SUMMARY)
+        if a.precision != "f32" and not a.ragged and pj is not None and dom:
+            roof["traffic_stale"] = pmc_stale                     # True: collected from other sources than this library's (see _pmc_file)
             for sym, row in roof["mfma_kernels"].items():
                 hit = pj.get(sym.split("<")[0])
                 if hit:
@@ -686,10 +732,10 @@ def main():
             roof["traffic"] = pj.get("traffic_bytes_per_launch")
             roof["l2_hit_rate"] = pj.get("l2_hit_rate")
             roof["traffic_unit"] = "bytes/launch, read from profiles/" + PMC_SUMMARY + " (separate --pmc pass: TCC_EA0 read x 128 B + write x 64 B)"
-        busy = os.path.join(ROOT, "profiles", PMC_MFMA)
-        if a.precision != "f32" and os.path.exists(busy) and dom:
-            with open(busy) as fh:
-                bj = json.load(fh).get("kernels", {})
+        bjf, busy_stale = _pmc_file(PMC_MFMA)
+        if a.precision != "f32" and bjf is not None and dom:
+            bj = bjf.get("kernels", {})
+            roof["mfma_busy_stale"] = busy_stale
             for sym, row in roof["mfma_kernels"].items():
                 hit = bj.get(sym) or bj.get(sym.split("<")[0])
                 if hit and "mfma_busy" in hit:
@@ -710,7 +756,20 @@ def main():
         sched = ("hipGraph replay (one graph per step)" if world == 1 else "hipGraph replay (5 segments, RCCL all-reduces between them)") \
             if model.graph_steps else (("eager multi-stream step" + (", serial" if a.no_pipeline else ", pipelined (pipeline_steps)")
                                         + (", acoustic model + vocoder forward / backward replayed from hipGraph segments" if model.graph_segments else "")))
-        out = {"metric": "mel-frames/sec/GPU (train step) + RTF (synthesize), ConvNeXt@22.05kHz, 1/2/4/8 MI355X",
+        synth = None if (a.no_infer or not secondary) else synthesise_rtf(model, dev, timer=timer, cpu=not a.no_cpu_baseline)
+        # the secondary figures in one short object, printed FIRST and repeated LAST: whichever end of a long line a log keeps shows them
+        summary = {"ms_per_step": ms_per_step, "host_enqueue_ms_per_step_unblocked": host_free,
+                   "transformer_step_ms": tf_fig["ms_per_step"] if tf_fig else None,
+                   "parity_mode_step_ms": parity_fig["ms_per_step"] if parity_fig else None,
+                   "parity_mode_ratio": parity_fig["ratio_to_headline"] if parity_fig else None,
+                   "graph_replay_step_ms": graph_fig["ms_per_step"] if graph_fig else None,
+                   "am_only_step_ms": am_only["ms_per_step"] if am_only else None,
+                   "synthesise_rtf": synth.get("rtf") if isinstance(synth, dict) else None,
+                   "roofline_frac": roof["frac"], "roofline_symbol": dom,
+                   "strong_scaling_ceiling": ceiling["ceiling"] if ceiling else None,
+                   "c_abi_calls_per_step": abi_calls["direct"] + abi_calls["replayed_from_tapes"]}
+        out = {"summary": summary,
+               "metric": "mel-frames/sec/GPU (train step) + RTF (synthesize), ConvNeXt@22.05kHz, 1/2/4/8 MI355X",
                "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
                "dtype": a.precision, "data": "synthetic", "comm_ms_exposed": comm_exposed,
@@ -728,8 +787,9 @@ def main():
                "roofline": roof, "cpu_baseline": cpu,
                "am_only_step": am_only, "replay_disc_forward_step": replay, "graph_replay_step": graph_fig,
                "parity_mode_step": parity_fig,
-               "synthesise": None if (a.no_infer or not secondary) else synthesise_rtf(model, dev, timer=timer, cpu=not a.no_cpu_baseline),
-               "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")}}
+               "synthesise": synth, "strong_scaling_ceiling": ceiling,
+               "final_losses": {k: round(v, 5) for k, v in logs.items() if k.startswith("total_loss/")},
+               "summary_repeated": summary}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

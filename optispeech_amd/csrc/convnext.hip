@@ -653,13 +653,164 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void ln_dwconv7_bwd_kernel(const
 }
 
 
+// ---- the same pass for 256 < C <= 384 (the WaveNeXt trunk: C = 384).  A lane owns six channels: a float4 at 4 * lane (channels
+// 0..255) and a float2 at 256 + 2 * lane (channels 256..383): both loads are coalesced, the wave reductions run over both parts.
+struct V6 { float4 a; float2 b; };
+__device__ __forceinline__ V6 v6zero() { V6 r; r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = make_float2(0.f, 0.f); return r; }
+__device__ __forceinline__ V6 v6load(const float* row, int lane, bool hasb) {
+    V6 r; r.a = *reinterpret_cast<const float4*>(row + 4 * lane);
+    r.b = hasb ? *reinterpret_cast<const float2*>(row + 256 + 2 * lane) : make_float2(0.f, 0.f);
+    return r;
+}
+__device__ __forceinline__ V6 v6fma(V6 x, V6 y, V6 c) {
+    V6 r; r.a = make_float4(fmaf(x.a.x, y.a.x, c.a.x), fmaf(x.a.y, y.a.y, c.a.y), fmaf(x.a.z, y.a.z, c.a.z), fmaf(x.a.w, y.a.w, c.a.w));
+    r.b = make_float2(fmaf(x.b.x, y.b.x, c.b.x), fmaf(x.b.y, y.b.y, c.b.y));
+    return r;
+}
+__device__ __forceinline__ V6 v6mul(V6 x, V6 y) { return v6fma(x, y, v6zero()); }
+__device__ __forceinline__ V6 v6add(V6 x, V6 y) {
+    V6 r; r.a = make_float4(x.a.x + y.a.x, x.a.y + y.a.y, x.a.z + y.a.z, x.a.w + y.a.w); r.b = make_float2(x.b.x + y.b.x, x.b.y + y.b.y); return r;
+}
+__device__ __forceinline__ float v6sum(V6 x) { return ((x.a.x + x.a.y) + (x.a.z + x.a.w)) + (x.b.x + x.b.y); }
+__device__ __forceinline__ V6 v6scale(V6 x, float s) {
+    V6 r; r.a = make_float4(x.a.x * s, x.a.y * s, x.a.z * s, x.a.w * s); r.b = make_float2(x.b.x * s, x.b.y * s); return r;
+}
+
+template <int FR, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ln_dwconv7_bwd_wide_kernel(const float* __restrict__ dh, const float* __restrict__ xhat,
+                                                             const float* __restrict__ rstd, const float* __restrict__ lnw,
+                                                             const float* __restrict__ x, const float* __restrict__ dw,
+                                                             const float* __restrict__ dres, const float* __restrict__ dres_rowmask,
+                                                             float* __restrict__ dx, float* __restrict__ dlnw, float* __restrict__ dlnb,
+                                                             float* __restrict__ ddw, float* __restrict__ ddb, float* __restrict__ ws,
+                                                             int B, int T, int C) {
+    __shared__ float red[NWV][10][384];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int runs_per_utt = (T + FR - 1) / FR, nruns = B * runs_per_utt;
+    const bool hasb = 256 + 2 * lane < C;
+    const float invC = 1.0f / (float)C;
+    const V6 gw = v6load(lnw, lane, hasb);
+    V6 gwt[7], gb = v6zero(), aw = v6zero(), ab = v6zero();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) gwt[j] = v6zero();
+    for (int run = blockIdx.x * NWV + wave; run < nruns; run += gridDim.x * NWV) {
+        const int b = run / runs_per_utt, t0 = (run - b * runs_per_utt) * FR;
+        const int64_t base = (int64_t)b * T * C;
+        V6 dc[FR + 6];
+        {
+            V6 xh[FR + 6];
+            float rs[FR + 6];
+#pragma unroll
+            for (int r = 0; r < FR + 6; ++r) {
+                const int t = t0 + r - 3;
+                const bool in = t >= 0 && t < T;
+                const int64_t off = base + (int64_t)(in ? t : t0) * C;
+                const V6 d = v6load(dh + off, lane, hasb), v = v6load(xhat + off, lane, hasb);
+                rs[r] = in ? rstd[(int64_t)b * T + t] : 0.f;
+                dc[r] = in ? d : v6zero();
+                xh[r] = in ? v : v6zero();
+            }
+#pragma unroll
+            for (int r = 0; r < FR + 6; ++r) {
+                const V6 d = dc[r], v = xh[r];
+                if (r >= 3 && r < FR + 3) { aw = v6fma(d, v, aw); ab = v6add(ab, d); }
+                const V6 g = v6mul(d, gw);
+                const float m1 = wave_sum(v6sum(g)) * invC;
+                const float m2 = wave_sum(v6sum(v6mul(g, v))) * invC;
+                const float sc = rs[r];
+                V6 o;
+                o.a = make_float4(sc * (g.a.x - m1 - v.a.x * m2), sc * (g.a.y - m1 - v.a.y * m2), sc * (g.a.z - m1 - v.a.z * m2), sc * (g.a.w - m1 - v.a.w * m2));
+                o.b = hasb ? make_float2(sc * (g.b.x - m1 - v.b.x * m2), sc * (g.b.y - m1 - v.b.y * m2)) : make_float2(0.f, 0.f);
+                dc[r] = o;
+            }
+        }
+        asm volatile("" ::: "memory");
+        {
+            V6 w[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) w[j] = v6load(dw + (int64_t)j * C, lane, hasb);
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+                const int t = t0 + f;
+                if (t < T) {
+                    V6 a = v6zero();
+                    if (dres) {
+                        const float rm = dres_rowmask ? dres_rowmask[(int64_t)b * T + t] : 1.f;
+                        a = v6scale(v6load(dres + base + (int64_t)t * C, lane, hasb), rm);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) a = v6fma(w[j], dc[f + 6 - j], a);
+                    float* o = dx + base + (int64_t)t * C;
+                    *reinterpret_cast<float4*>(o + 4 * lane) = a.a;
+                    if (hasb) *reinterpret_cast<float2*>(o + 256 + 2 * lane) = a.b;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (ddw) {
+#pragma unroll
+            for (int r = 0; r < FR + 6; ++r) {
+                const int t = t0 + r - 3;
+                const bool in = t >= 0 && t < T;
+                const V6 xr = in ? v6load(x + base + (int64_t)t * C, lane, hasb) : v6zero();
+                // x[t0 + r - 3] meets dc of the owned frame f with tap j = r - f
+#pragma unroll
+                for (int f = 0; f < FR; ++f) {
+                    const int j = r - f;
+                    if (j >= 0 && j < 7) {
+                        const V6 d0 = (t0 + f < T) ? dc[f + 3] : v6zero();
+                        gwt[j] = v6fma(d0, xr, gwt[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                if (t0 + f < T) gb = v6add(gb, dc[f + 3]);
+        }
+        asm volatile("" ::: "memory");
+    }
+    if (!ddw && !dlnw) return;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const V6 v = j < 7 ? gwt[j] : j == 7 ? gb : j == 8 ? aw : ab;
+        *reinterpret_cast<float4*>(&red[wave][j][lane * 4]) = v.a;
+        *reinterpret_cast<float2*>(&red[wave][j][256 + lane * 2]) = v.b;
+    }
+    __syncthreads();
+    float* part = ws ? ws + (int64_t)blockIdx.x * 10 * C : nullptr;
+    for (int i = threadIdx.x; i < 10 * 384; i += 64 * NWV) {
+        const int j = i / 384, c = i - j * 384;
+        float* dst = j < 7 ? (ddw ? ddw + (int64_t)j * C : nullptr) : j == 7 ? ddb : j == 8 ? dlnw : dlnb;
+        if (c < C && (dst || part)) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) sum += red[q][j][c];
+            if (part) part[(int64_t)j * C + c] = sum;
+            else atomicAdd(dst + c, sum);
+        }
+    }
+}
+
 extern "C" int osp_ln_dwconv7_bwd(const float* dh, const float* xhat, const float* rstd, const float* lnw, const float* x,
                                   const float* dw, const float* dres, const float* dres_rowmask, float* dx, float* dlnw, float* dlnb,
                                   float* ddw, float* ddb, int64_t B, int64_t T, int64_t C, float* ws, int64_t ws_blocks, hipStream_t stream) {
     OSP_CHECK_ARG(dh && xhat && rstd && lnw && x && dw && dx, "null operand");
     OSP_CHECK_ARG((dlnw == nullptr) == (dlnb == nullptr) && (ddw == nullptr) == (ddb == nullptr), "dlnw/dlnb and ddw/ddb come in pairs");
-    OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256, "C must be a multiple of 4, <= 256 (wider blocks: osp_layernorm_bwd + osp_dwconv7_bwd)");
+    OSP_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 384, "C must be a multiple of 4, <= 384 (wider blocks: osp_layernorm_bwd + osp_dwconv7_bwd)");
     OSP_CHECK_ARG(!ws || ws_blocks > 0, "ws needs ws_blocks > 0");
+    if (C > 256) {                                                // the WaveNeXt trunk: six channels per lane, four waves per workgroup
+        const bool two = ws && (dlnw || ddw);
+        const int64_t want = cdiv(B * cdiv(T, 4), 4), capw = two ? (ws_blocks < 512 ? ws_blocks : 512) : 512;
+        const unsigned nb = (unsigned)(want < capw ? want : capw);
+        hipLaunchKernelGGL((ln_dwconv7_bwd_wide_kernel<4, 4>), dim3(nb), dim3(256), 0, stream, dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dx,
+                           dlnw, dlnb, ddw, ddb, two ? ws : nullptr, (int)B, (int)T, (int)C);
+        if (two) {
+            PartialDst d = {{ddw, ddb, dlnw, dlnb}, {7 * (int)C, (int)C, (int)C, (int)C}};
+            launch_reduce_partials(ws, (int)nb, 10 * (int)C, d, stream);
+        }
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
     static int fr = -1;
     if (fr < 0) { fr = 4; }      // tools/lndw_probe.py at 32 x 800 x 256: FR 4 / 6 / 8 = 41.9 / 49.7 / 50.6 us (8 spills: 256-VGPR cap for two workgroups / CU)
     // 256 VGPRs per thread: 8 waves per CU are resident, as one workgroup of 8 waves (256 workgroups: half the atomics per address)

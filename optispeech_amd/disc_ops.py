@@ -12,12 +12,40 @@ from . import kernels as K
 from . import tape as _tape
 
 
+_TAPES = {}                  # id(first weight_v Parameter of a stack) -> (call tapes, leases); removed when the Parameter dies
+
+
+def _stack_state(v0):
+    """(call-tape cache, forward leases) of one sub-discriminator stack.  Kept OUTSIDE the Parameter (a Region holds PyCapsules:
+    in the Parameter's __dict__ they made torch.save(model) / pickling fail after the first training step); keyed by id() with a
+    finalizer -- a tensor cannot key a WeakKeyDictionary (its == is element-wise)."""
+    st = _TAPES.get(id(v0))
+    if st is None:
+        st = _TAPES[id(v0)] = ({}, {})
+        __import__("weakref").finalize(v0, _TAPES.pop, id(v0), None)
+    return st
+
+
 def _stack_tapes(v0):
-    """The call-tape cache of one sub-discriminator stack, kept on its first weight_v Parameter (dies with the module)."""
-    d = getattr(v0, "_osp_tapes", None)
-    if d is None:
-        d = v0._osp_tapes = {}
-    return d
+    return _stack_state(v0)[0]
+
+
+class _Lease:
+    """A taped forward's activation buffers are the tape's: a second forward with the same key would replay into them while the
+    first one's backward still needs them (two forwards of one stack before either backward: OSP_SHARE_REAL, any double forward).
+    The forward therefore takes a lease on (key, slot) -- the slot is part of the tape key, i.e. a second buffer set is recorded for
+    an overlapping forward -- and gives it back when its backward has been issued or its graph is dropped."""
+
+    def __init__(self, table, key):
+        self.table, self.key = table, key
+        table[key] = True
+
+    def release(self):
+        if self.table is not None:
+            self.table.pop(self.key, None)
+            self.table = None
+
+    __del__ = release
 
 
 def _tout(tin, taps, stride, pad):
@@ -233,7 +261,13 @@ class ConvStackFn(torch.autograd.Function):
         # activation buffers apart, as the eager allocations were)
         key = ("fwd", tuple(x.shape), spec, float(slope), any(need_w), tuple(t.data_ptr() for pk in packs for t in pk if t is not None),
                tuple(b.data_ptr() for b in biases))
-        acts = list(_tape.run(_stack_tapes(vs[0]), key, [x], layers, "disc stack forward"))
+        tapes, leases = _stack_state(vs[0])
+        slot = 0
+        if need_x or any(need_w):
+            while (key, slot) in leases:                         # an earlier forward with this key still waits for its backward
+                slot += 1
+            ctx.lease = _Lease(leases, (key, slot))
+        acts = list(_tape.run(tapes, key + (slot,), [x], layers, "disc stack forward"))
         if need_x or any(need_w):
             ctx.save_for_backward(x[u0:], *[a[u0:] for a in acts[:5]],
                                   *[t for pk in packs for t in (pk[0], pk[2], pk[3]) if t is not None])
@@ -270,6 +304,7 @@ class ConvStackFn(torch.autograd.Function):
         # the batch dimension later); the last dgrad launch writes the rest in place
         g = _stack_backward(x, acts, packs, ctx.params, spec, slope, need_x, need_w, (d1, d2, d3, d4, d5), ds,
                             full_rows=ctx.U if (need_x and ctx.u0) else 0)
+        ctx.lease.release()            # the backward's launches are queued behind the forward's on the stack's stream: the buffers are free
         return (g if need_x else None, None, None) + (None,) * len(ctx.params)
 
 

@@ -214,6 +214,23 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
 
 
 _WGRAD_BF16_MIN_M = int(__import__('os').environ.get('OSP_WGRAD_BF16_MIN_M', '2048'))
+_WGRAD_CAST = __import__('os').environ.get('OSP_WGRAD_CAST', '1') != '0'
+
+
+def _dense_rows(t):
+    return t.dim() == 2 and t.stride(-1) == 1 and t.stride(-2) == t.shape[-1]
+
+
+def _bf16_rows(t, rowscale=None):
+    """(M, C) operand of a weight-gradient GEMM as bf16 (optionally row-scaled first)."""
+    if t.dtype == torch.bfloat16:
+        assert rowscale is None
+        return t
+    if rowscale is not None:
+        return cast_bf16_rows(t, rowscale)
+    y = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    call("osp_cast_bf16", t, y, t.numel())
+    return y
 
 
 def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=None, batch=1):
@@ -226,6 +243,12 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
     sy = dy.stride(0) if batch > 1 else 0
     sx = x.stride(0) if batch > 1 else 0
     if _precision.is_bf16() and M >= _WGRAD_BF16_MIN_M and N >= 64 and cin >= 64:
+        if _WGRAD_CAST and batch == 1 and N % 64 == 0 and cin % 64 == 0 and _dense_rows(dy) and _dense_rows(x):
+            # f32 activations: one bf16 copy of each operand (the row factor folded into dy's), then the ring kernel -- the register-staged
+            # f32 loader of the tile-per-tap kernel rounds to bf16 at the same place (after the row factor), so the products are
+            # the same; 34 -> ~20 us per launch at the predictor shapes (tools/probes/wgrad_calls.py)
+            conv_wgrad_bf16(_bf16_rows(dy, arow), _bf16_rows(x), dw, db, M=M, Trows=T, Tin=T, n=N, cin=cin, taps=taps, pad=pad, oscale=oscale)
+            return
         call("osp_conv_wgrad_bf16", dy, 0, dy.stride(-2), x, 0, x.stride(-2), M, T, T, N, cin, taps, pad, 1, arow, oscale, dw,
              taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
         return
@@ -253,7 +276,7 @@ def dwconv7_bwd(dc, x, dw, dres, dres_rowmask, ddw, ddb):
 
 
 def ln_dwconv7_bwd(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, ddw, ddb):
-    """LayerNorm backward + depthwise-conv backward of a ConvNeXt block in one pass (C <= 256); dlnw/dlnb/ddw/ddb accumulate."""
+    """LayerNorm backward + depthwise-conv backward of a ConvNeXt block in one pass (C <= 384); dlnw/dlnb/ddw/ddb accumulate."""
     _f32(dh, xhat, rstd, lnw, x, dw, dres, dres_rowmask, dlnw, dlnb, ddw, ddb)
     B, T, C = x.shape
     assert dh.is_contiguous() and xhat.is_contiguous() and x.is_contiguous()
@@ -819,6 +842,10 @@ def wgrad_workspace(n, taps, cin, batch, device):
 
 def conv_wgrad_bf16(dy, x, dw, db=None, *, M, Trows, Tin, n, cin, taps=1, pad=0, x_step=1, arow=None, oscale=None,
                     batch=1, strides=(0, 0, 0, 0)):
+    if _WGRAD_CAST and batch == 1 and _isbf(dy) != _isbf(x) and n % 64 == 0 and cin % 64 == 0 and _dense_rows(dy) and _dense_rows(x):
+        # one bf16 and one f32 operand (a ConvNeXt block whose forward ran on the exact-f32 index path): the mixed pair took the
+        # generic tile kernel (67 us per launch at 4096 x 256 x 1024, eight per step); a bf16 copy of the f32 side puts it on the ring kernel
+        dy, x, arow = _bf16_rows(dy, arow if not _isbf(dy) else None), _bf16_rows(x), (arow if _isbf(dy) else None)
     if _isbf(dy) and _isbf(x) and arow is None:
         ws = wgrad_workspace(n, taps, cin, batch, dy.device)
         call("osp_conv_wgrad_bf16_ws", dy, 1, dy.stride(-2), x, 1, x.stride(-2), M, Trows, Tin, n, cin, taps,

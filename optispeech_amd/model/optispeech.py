@@ -63,6 +63,13 @@ _SYNC_AFTER_G = __import__("os").environ.get("OSP_SYNC_AFTER_G", "0") == "1"
 #: only adds a thread hand-over and GIL traffic per pass (host enqueue 20.2 -> 17.9 ms per step at B = 32; OSP_AUTOGRAD_MT=1 restores it)
 _AUTOGRAD_MT = __import__("os").environ.get("OSP_AUTOGRAD_MT", "0") == "1"
 _D_AFTER_G = __import__("os").environ.get("OSP_D_AFTER_G", "0") == "1"
+#: pipelined steps: the discriminator phase starts when the generator's backward has left the discriminator stacks (not at its end),
+#: and the generator's optimiser update is issued BEFORE the discriminator phase (so that it -- and the next step's acoustic-model
+#: forward behind it -- does not queue behind discriminator-phase packets of a shared hardware queue).  MEASURED AND LEFT OFF (round 5,
+#: DESIGN.md section 9): 15.45 ms (early start alone: the phase still starts when the backward ends) / 16.4-16.7 ms (update first)
+#: against 15.45 ms, with every placement of the phase's stream on the hardware queues tried (profiles/r05_early_d_ab.txt)
+_EARLY_D = __import__("os").environ.get("OSP_EARLY_D", "0") == "1"
+_G_OPT_FIRST = __import__("os").environ.get("OSP_G_OPT_FIRST", "0") == "1"
 
 
 class OptiSpeech(nn.Module):
@@ -105,12 +112,13 @@ class OptiSpeech(nn.Module):
         self.graph_segments = os.environ.get("OSP_GRAPH_SEGMENTS", "0") == "1"
         self._gen_segments = {}
         #: acoustic model + vocoder as TAPED segments (optispeech_amd/tape.py: one autograd node each, forward and backward
-        #: replayed from recorded C-ABI call lists on the eager multi-stream schedule).  OPT-IN: host enqueue 13.4 -> 9.3 ms per step, but
-        #: the step is GPU-bound (17.2 ms) and with the vocoder taped the device needs 20.1 ms for the same kernels in the overlapped
-        #: schedule (17.6 with only the acoustic model taped; serialised stage by stage the three variants are within 1 ms of each
-        #: other; no stream -> hardware-queue assignment of 36 tried recovers it: profiles/r04_tape_segments_ab.txt).  The
-        #: sub-discriminator stacks, whose tapes are a measured win (18.9 -> 17.2 ms), are taped regardless of this switch.
-        self.tape_segments = os.environ.get("OSP_TAPE_SEGMENTS", "0") == "1"
+        #: replayed from recorded C-ABI call lists on the eager multi-stream schedule): host enqueue 13.8 -> 7.5 ms per step.  Default
+        #: since round 5: in round 4 the device needed 0.6-3 ms longer for the same kernels with the vocoder taped (never explained);
+        #: with round 5's weight-gradient kernels and launch order the two schedules measure the same (15.2-15.6 ms, three same-box
+        #: pairs, profiles/r05_tape_segments_ab.txt), and at the small per-rank batches of strong scaling the taped host is what the
+        #: step time is (B = 8: 8.8 vs 14.1 ms).  OSP_TAPE_SEGMENTS=0 restores the eager generator.  The sub-discriminator stacks
+        #: are taped regardless of this switch.
+        self.tape_segments = os.environ.get("OSP_TAPE_SEGMENTS", "1") != "0"
         self._tape_am = self._tape_voc = None
         self._seed_dev = None
         #: how many steps the HOST may run ahead of the device (0 = unbounded).  With the taped regions a step is enqueued in about
@@ -296,7 +304,8 @@ class OptiSpeech(nn.Module):
         # discriminator stream is joined before anything reads discriminator state again (training_step_g, fetch_logs,
         # state_dict, join()).
         recompute = st.train_d and not ta.cache_generator_outputs
-        if recompute:
+        opt_first = (not recompute) and st.train_d and self.pipeline_steps and _G_OPT_FIRST
+        if recompute or opt_first:
             # cache_generator_outputs: false (base_lightning_module.py:111-113, :165-169): the discriminator phase re-runs the
             # generator without a tape -- AFTER the generator update (:103), so that update is issued first and the phase
             # cannot be pipelined behind the next step's generator forward
@@ -310,7 +319,7 @@ class OptiSpeech(nn.Module):
                 # disc_ops._stack_backward): gradient-ready order, overlapping the other stacks' backward; this adds the rest
                 if st.apply:
                     red_d.start_rest(self.optimizers()[1].arena.grad)
-        if not recompute:
+        if not (recompute or opt_first):
             red_g.wait()
             self._stage_opt_g(st)
         if st.train_d:
@@ -406,7 +415,11 @@ class OptiSpeech(nn.Module):
         if self._dstream is None:
             from .. import lanes
             self._dstream = lanes.stream("dphase", self.device) if lanes.managed() else torch.cuda.Stream(device=self.device)
-        self._dstream.wait_stream(torch.cuda.current_stream())
+        ev, self._dgrad_done = getattr(self, "_dgrad_done", None), None
+        if ev is not None:
+            self._dstream.wait_event(ev)
+        else:
+            self._dstream.wait_stream(torch.cuda.current_stream())
         return torch.cuda.stream(self._dstream)
 
     def join(self):
@@ -432,6 +445,18 @@ class OptiSpeech(nn.Module):
                      "gen_subloss/train_energy_loss": gen_outputs["energy_loss"]})
         wav, wav_hat = gen_outputs["wav"], gen_outputs["wav_hat"]
         self._real_pass = None
+        self._dgrad_done = None
+        if train_discriminator and self.pipeline_steps and _EARLY_D and wav_hat.requires_grad and wav_hat.is_cuda:
+            # The discriminator phase reads the discriminator weights and wav_hat.detach(): nothing of the generator's backward
+            # BELOW the discriminators (vocoder, acoustic model: ~3 ms of small-grid kernels).  It may start as soon as the generator
+            # phase has left the discriminator stacks, i.e. when the gradient w.r.t. wav_hat is complete -- this hook fires then
+            # (all stack streams joined into the calling stream), and the discriminator-phase stream waits for THIS event instead
+            # of the end of the generator's backward (profiles/r05_phase_events_*.txt)
+            def _mark(grad, self=self):
+                if not torch.cuda.is_current_stream_capturing():
+                    self._dgrad_done = torch.cuda.current_stream().record_event()
+                return None
+            wav_hat.register_hook(_mark)
         if train_discriminator:
             self.join()                          # a pipelined discriminator update of the previous step must have landed
             if share_real:

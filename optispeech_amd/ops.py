@@ -317,7 +317,7 @@ class ConvNeXtBlockFn(torch.autograd.Function):
             if _want(W1):
                 K.conv_wgrad(du, h.view(M, C), gsink(W1), gsink(b1) if _want(b1) else None)
         wl, wd = _want(lnw), _want(dw)
-        if C <= 256 and dy.is_cuda and _FUSED_LN_DW:
+        if C <= 384 and dy.is_cuda and _FUSED_LN_DW:
             # one pass: the LayerNorm input gradient dc never goes to HBM (csrc/convnext.hip: ln_dwconv7_bwd_kernel)
             dx = K.ln_dwconv7_bwd(dh, xhat.view(M, C), rstd.view(M), lnw, x, dw, dy2.view(B, T, C), rowmask,
                                   gsink(lnw) if wl else None, gsink(lnb) if wl else None, gsink(dw) if wd else None,

@@ -289,6 +289,14 @@ class Region:
         self.extra = None
 
     def replay(self, inputs):
+        # what Recorder.__enter__ checked at record time holds for every replay: same byte extent and type, contiguous, on the device
+        # (a same-shape view with other strides or another dtype would make the patched launches read the wrong memory silently)
+        sig = self.meta["sig"]
+        if len(inputs) != len(sig):
+            raise ValueError(f"tape {self.meta['label']!r}: {len(inputs)} inputs given, {len(sig)} recorded")
+        for t, want in zip(inputs, sig):
+            if (t is None) != (want is None) or (t is not None and ((_extent(t), t.dtype) != want or not t.is_contiguous() or not t.is_cuda)):
+                raise ValueError(f"tape {self.meta['label']!r}: an input differs from the recorded one (extent / dtype / layout)")
         bases = [0 if t is None else t.data_ptr() for t in inputs]
         rc = fast().tape_replay(self.cap, bases, _lib._STREAM_OVERRIDE[0] or _lib._raw_stream(_lib._cur_device()))
         if rc != 0:
@@ -368,7 +376,8 @@ class Recorder:
         # aliases taken NOW (inside the caller's Function.forward the outputs carry no autograd history yet): the objects handed to
         # the caller get a grad_fn later, and holding those would pin the first step's graph
         return Region(self.cap, _alias(outs), len(self.inputs), ncalls,
-                      {"patches": npatches, "rerouted": self.rerouted, "label": self.label, "names": names})
+                      {"patches": npatches, "rerouted": self.rerouted, "label": self.label, "names": names,
+                       "sig": [None if t is None else (_extent(t), t.dtype) for t in self.inputs]})
 
 
 def run(cache, key, inputs, fn, label=""):
@@ -378,7 +387,7 @@ def run(cache, key, inputs, fn, label=""):
         return fn(*inputs)                                       # (inside a hipGraph capture the graph owns the memory: stay eager)
     ent = cache.get(key)
     if ent is None:
-        if len(cache) >= 16:                                     # each region owns its activation buffers: bound the set
+        if len(cache) >= 32:                                     # each region owns its activation buffers: bound the set
             cache.pop(next(iter(cache)))
         with Recorder(inputs, label) as rec:
             outs = fn(*inputs)
@@ -423,11 +432,16 @@ class _SegmentFn(torch.autograd.Function):
         ctx.seg, ctx.key = seg, key
         ctx.set_materialize_grads(False)
         inputs = [t.contiguous() if isinstance(t, torch.Tensor) else t for t in inputs]
+        # the backward reads the segment's INPUTS too (token ids, lengths: embedding / loss / mask kernels): they are declared inputs
+        # of the backward tape as well, or it would keep reading the tensors of the recording step (round 5: a replay on another
+        # ragged batch of the same shape gave 2.5e-2 wrong acoustic-model gradients; invisible while every step saw the same tensors)
+        ctx.fwd_inputs = inputs
         ent = seg.cache.get(key)
         if ent is not None:
             outs = ent[0].replay(inputs)
             ctx.inner = None
             ctx.diff = ent[2]
+            ctx.ent = ent                                          # (the cache may evict the key before the backward arrives)
         else:
             if len(seg.cache) >= 8:
                 seg.cache.pop(next(iter(seg.cache)))
@@ -451,11 +465,12 @@ class _SegmentFn(torch.autograd.Function):
         pattern = tuple(None if g is None else (tuple(g.shape), g.dtype) for g in gin)
         nin = len(ctx.needs_input_grad)
         if ctx.inner is None:
-            fwd, bwd, diff, pat = seg.cache[key]
+            fwd, bwd, diff, pat = ctx.ent
             if pat != pattern:
                 raise RuntimeError(f"taped segment {seg.label!r}: the step asks for gradients of a different set of outputs than the "
                                    f"recorded backward has ({pattern} vs {pat}); give such a step its own key")
-            bwd.replay(gin)
+            bwd.replay(gin + list(ctx.fwd_inputs))
+            ctx.fwd_inputs = None
             return (None,) * nin
         inner, fwd = ctx.inner
         ctx.inner = None
@@ -468,7 +483,7 @@ class _SegmentFn(torch.autograd.Function):
         from . import ops as _ops
         outer = _ops.nested_backward_begin()                       # the segment joins its own weight-gradient side streams: on the tape
         try:
-            with Recorder(gin, seg.label + " backward") as rec:
+            with Recorder(gin + list(ctx.fwd_inputs), seg.label + " backward") as rec:
                 torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         finally:
             _ops.nested_backward_end(outer)

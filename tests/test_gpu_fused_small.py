@@ -175,7 +175,7 @@ def test_drop_path_rows_distribution_and_mask():
     assert abs(frac - 0.3) < 0.02, frac
 
 
-@pytest.mark.parametrize("B,T,C", [(3, 37, 256), (2, 800, 256), (4, 8, 64), (1, 5, 200)])
+@pytest.mark.parametrize("B,T,C", [(3, 37, 256), (2, 800, 256), (4, 8, 64), (1, 5, 200), (32, 64, 384), (3, 37, 384), (2, 9, 320)])
 @pytest.mark.parametrize("with_res", [True, False])
 def test_fused_ln_dwconv7_backward_equals_the_two_kernel_path(B, T, C, with_res):
     """osp_ln_dwconv7_bwd against osp_layernorm_bwd followed by osp_dwconv7_bwd (which test_gpu_kernels pins to the oracle):

@@ -121,6 +121,95 @@ def _train(tapes, steps=4, pipeline=True, segments=False):
         precision.set_precision("f32")
 
 
+def test_taped_segments_on_changing_ragged_batches_equal_eager():
+    """A taped generator segment replayed on ANOTHER ragged batch of the same padded shape (what real training does every step; the
+    benchmark re-uses one batch and cannot see it).  Round 5 found the backward tape reading the recording step's token ids and
+    lengths (they were not declared inputs of the backward region): 2.5e-2 wrong acoustic-model gradients.  Steps: batch 0
+    (records), 1, 1, 0 without an optimizer update; gradients of both networks, taped vs eager, to the tolerance of two eager
+    runs (f32 atomics)."""
+    from oracle import schema as S
+    from optispeech_amd import precision, rng, tape
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    precision.set_precision("f32")
+    keep = tape.ENABLED
+
+    def run(tapes):
+        tape.ENABLED = tapes
+        c = S.SMALL
+        cfg = ModelConfig(dim=c.dim, enc_inter=c.enc_inter, dec_inter=c.dec_inter, dur=c.dur + (0.0,), pitch=c.pitch + (0.0,),
+                          energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers).no_dropout()
+        torch.manual_seed(7); rng.manual_seed(7, 0)
+        m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
+        m.tape_segments = True
+        got = {}
+        for name, o in zip(("g", "d"), m.optimizers()):
+            o.step = (lambda n, oo: (lambda *a, **k: got.__setitem__(n, oo.arena.grad.detach().clone())))(name, o)
+        out = []
+        for r in (0, 1, 1, 0):
+            b = synthetic_batch(2, 24, 96, cfg, seed=50 + r, ragged=True, device=DEV)
+            m.generator.segment_rand01 = torch.tensor([0.25 + 0.5 * r, 0.6 - 0.3 * r], device=DEV)
+            m.training_step(b, 0)
+            torch.cuda.synchronize()
+            out.append((got["g"].clone(), got["d"].clone()))
+        return out
+
+    try:
+        s0 = tape.stats()
+        a, b = run(False), run(True)
+        s1 = tape.stats()
+    finally:
+        tape.ENABLED = keep
+    assert s1["replayed"] - s0["replayed"] >= 6 and s1["poisoned"] == s0["poisoned"], (s0, s1)
+    for i, ((ga, da), (gb, db)) in enumerate(zip(a, b)):
+        assert ((ga - gb).norm() / ga.norm()).item() < 1e-5, (i, "generator")
+        assert ((da - db).norm() / da.norm()).item() < 1e-5, (i, "discriminator")
+
+
+def test_two_forwards_before_either_backward_keep_their_activations():
+    """a taped forward's outputs are the tape's buffers.  Two forwards of one stack with the same key before
+    either backward (what OSP_SHARE_REAL=1 does: forward_real(wav), then d(wav_hat.detach())) must not share them -- the second
+    forward takes another lease slot (disc_ops._Lease), i.e. its own buffer set.  Input gradients are deterministic: taped ==
+    eager bit for bit; weight gradients (now atomic-free as well) too."""
+    from optispeech_amd import precision, tape
+    from optispeech_amd.model.discriminator import DiscriminatorP
+    from optispeech_amd.ops import gsink
+    precision.set_precision("bf16")
+    keep = tape.ENABLED
+    res = {}
+    try:
+        for mode in (False, True):
+            tape.ENABLED = mode
+            torch.manual_seed(0)
+            d = DiscriminatorP(3).to(DEV)
+            outs = []
+            for it in range(3):                                          # pass 0 records (both slots), passes 1-2 replay
+                g = torch.Generator().manual_seed(50 + it)
+                xa = torch.randn(4, 8192, generator=g).to(DEV).requires_grad_(True)
+                xb = torch.randn(4, 8192, generator=g).to(DEV).requires_grad_(True)
+                for p in d.parameters():
+                    gsink(p).zero_()
+                sa, fa = d(xa)
+                sb, fb = d(xb)                                           # same shapes, same weights, same key: would replay over sa / fa
+                wa = torch.randn(sa.shape, generator=g).to(DEV)
+                wb = torch.randn(sb.shape, generator=g).to(DEV)
+                la = (sa * wa).sum() + sum((f.float() ** 2).mean() for f in fa[:-1])
+                lb = (sb * wb).sum() + sum((f.float() ** 2).mean() for f in fb[:-1])
+                la.backward()
+                lb.backward()
+                torch.cuda.synchronize()
+                outs.append((xa.grad.clone(), xb.grad.clone(), sa.detach().clone(), {k: gsink(p).detach().clone() for k, p in d.named_parameters()}))
+            res[mode] = outs
+    finally:
+        tape.ENABLED = keep
+        precision.set_precision("f32")
+    for (ga0, gb0, s0, w0), (ga1, gb1, s1, w1) in zip(res[False], res[True]):
+        assert torch.equal(s0, s1)
+        assert torch.equal(ga0, ga1), (ga0 - ga1).abs().max().item()      # the FIRST forward's backward saw its own activations
+        assert torch.equal(gb0, gb1)
+        for k in w0:
+            assert torch.allclose(w0[k], w1[k], rtol=0, atol=2e-5 * float(w0[k].abs().max()) + 1e-12), k
+
+
 def test_taped_training_steps_match_eager_steps():
     """Four full GAN steps (multi-stream, pipelined, dropout on) with the taped regions replaying from step 2 on, against the same
     steps run eagerly: same logged losses and the same weights afterwards, to the tolerance of two eager runs against each other

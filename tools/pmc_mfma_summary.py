@@ -12,6 +12,8 @@ so that 1.0 would be the dense peak AT THE CLOCK THE KERNEL RAN AT (the 2.5 PFLO
 part clocks lower, same guide, DVFS note).  The quad-cycle SQ counters (WAVE_CYCLES, WAIT_*, ACTIVE_INST_*) are given as shares of
 SQ_WAVE_CYCLES: parked (s_waitcnt / barrier), issue-stalled, issuing."""
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optispeech_amd.build import source_hash       # the summary names the sources its counters were collected from (bench.py marks others stale)
 
 dirs, out, cmd = sys.argv[1].split(","), sys.argv[2], sys.argv[3]
 avg = collections.defaultdict(dict)                      # kernel -> counter -> per-launch average
@@ -55,5 +57,5 @@ for k in sorted(avg, key=lambda k: -avg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) 
 with open(out + ".txt", "w") as fh:
     fh.write("\n".join(lines) + "\n")
 with open(out + ".json", "w") as fh:
-    json.dump({"source": cmd + " (own passes, counters only)", "simds": N_SIMD, "xcds": N_XCD, "kernels": res}, fh, indent=1)
+    json.dump({"source_hash": source_hash(), "source": cmd + " (own passes, counters only)", "simds": N_SIMD, "xcds": N_XCD, "kernels": res}, fh, indent=1)
 print("\n".join(lines[:16]))

@@ -3,6 +3,8 @@
 per-launch counter averages -> <out>.txt, plus the roofline.traffic json for conv_gemm_bf16_glds_kernel -> <out>.json.
 usage: pmc_summary.py <rocprof output dir> <out prefix> "<command line that was profiled>" """
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optispeech_amd.build import source_hash       # the summary names the sources its counters were collected from (bench.py marks others stale)
 
 d, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
 per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -26,7 +28,8 @@ with open(out + ".txt", "w") as fh:
 js_all = {}
 for k in per:
     sym = k.split("(")[0]
-    if sym.startswith("conv_gemm_bf16_glds") or sym.startswith("conv_gemm_bf16_s64") or "ln_dwconv7" in sym or "dwconv7_ln_fwd" in sym:
+    sym = sym.replace("void ", "")
+    if sym.startswith("conv_gemm_bf16_glds") or sym.startswith("conv_gemm_bf16_s64") or "ln_dwconv7" in sym or "dwconv7_ln_fwd" in sym or "wgrad" in sym:
         n = len(launches[k]); c = {a: b / n for a, b in per[k].items()}
         rd_b = c["TCC_EA0_RDREQ_sum"] * 64 * 2          # gfx950: wide streaming reads are counted at half size (guide, HBM section)
         wr_b = c["TCC_EA0_WRREQ_sum"] * 64
@@ -36,6 +39,7 @@ for k in per:
                        "correction": "MI355X_MICROARCH.md, HBM section: FETCH_SIZE = TCC_EA0_RDREQ x 64 B reports half of a wide (16 B/lane) streaming read on gfx950 -> doubled; WRREQ x 64 B is uncalibrated",
                        "l2_hit_rate": c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
                        "traffic_bytes_per_launch": int(rd_b + wr_b)}
+js_all["source_hash"] = source_hash()
 with open(out + ".json", "w") as fh:
     json.dump(js_all, fh, indent=1)
 print("\n".join(lines[:12]))
