@@ -26,8 +26,8 @@ B, T_TEXT, T_MEL = 32, 128, 800
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r04_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/): TCC traffic / L2 hit
-PMC_MFMA = "r04_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM pass (tools/pmc_mfma.sh): matrix-pipe busy share per symbol
+PMC_SUMMARY = "r05_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/): TCC traffic / L2 hit
+PMC_MFMA = "r05_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM pass (tools/pmc_mfma.sh): matrix-pipe busy share per symbol
 
 
 def _pmc_file(name):

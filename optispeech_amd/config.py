@@ -65,6 +65,7 @@ class ModelConfig:
         c = copy.deepcopy(self)
         c.text_dropout = c.enc_drop_path = c.dec_drop_path = c.voc_drop_path = 0.0
         c.pitch_embed_dropout = c.energy_embed_dropout = 0.0
+        c.tf_dropout = 0.0                                     # the Transformer backbone's dropout / positional / attention rates
         c.dur, c.pitch, c.energy = c.dur[:3] + (0.0,), c.pitch[:3] + (0.0,), c.energy[:3] + (0.0,)
         return c
 

@@ -64,6 +64,12 @@ def _make_pool(device):
             with torch.cuda.stream(s):
                 K.store_i64(scratch, i)                      # first use binds the stream to its hardware queue: do it in pool order
             streams.append(s)
+        # torch deals streams from a pool of 32 per priority: past that, requests ALIAS pool entries and two logical lanes would
+        # silently share one HIP stream.  28 are taken here; say so if the process had already used up the pool.
+        if len({st.cuda_stream for st in streams}) != len(streams):
+            import warnings
+            warnings.warn("optispeech_amd.lanes: torch's stream pool is exhausted, lane streams alias each other -- the measured "
+                          "stream -> hardware-queue table does not hold in this process")
         torch.cuda.synchronize(device)
         _pool[idx], _taken[idx] = streams, set()
     return idx

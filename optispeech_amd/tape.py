@@ -152,6 +152,8 @@ def _r_mul(func, args, kwargs):
     if a.numel() < b.numel() and not inplace:
         a, b = b, a
     if _plain(a) and b.is_cuda and b.dtype == torch.float32 and b.numel() == 1:           # times a device scalar
+        if tuple(torch.broadcast_shapes(a.shape, b.shape)) != tuple(a.shape):            # (1,) * (1, 1): the result is not a's shape
+            return NotImplemented
         out = a if inplace else torch.empty_like(a)
         _lib.call("osp_ew_scale_dev", a, b, out, a.numel(), 1.0)
         return out
@@ -175,6 +177,8 @@ def _r_neg(func, args, kwargs):
 
 def _r_div(func, args, kwargs):
     a, b = args[0], args[1]
+    if (kwargs or {}).get("rounding_mode") is not None:           # floor / trunc division is not a scale: poison the recording
+        return NotImplemented
     if _plain(a) and not isinstance(b, torch.Tensor):
         out = torch.empty_like(a)
         _lib.call("osp_ew_axpby", a, None, out, a.numel(), 1.0 / float(b), 0.0)

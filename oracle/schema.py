@@ -146,5 +146,5 @@ def make_weights(schema, seed=1234, dtype=torch.float32):
         else:
             fan_in = int(np.prod(shape[1:]))
             a = n * (1.0 / np.sqrt(fan_in))
-        out[name] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dtype)
+        out[name] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(tuple(shape)).to(dtype)   # (0-d entries stay 0-d)
     return out

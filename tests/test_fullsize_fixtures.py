@@ -21,6 +21,13 @@ def test_regenerated_inputs_match_the_generating_run(golden):
     assert b["mel"].shape == (32, 100, 800) and b["wav"].shape == (32, 800 * 256)
     sd, lens, x, Gc = GI.transformer_case(golden("full_b32_transformer"))
     assert x.shape == (32, 800, 256) and len(sd) == len(golden("full_b32_transformer")["keys"])
+    # configs[3] as a whole model (round 5): same batch recipe, the reference module's own state-dict names / shapes stored
+    gt = golden("full_b32_transformer_gan")
+    bt = GI.gan_batch(gt)
+    assert bt["mel"].shape == (32, 100, 800)
+    names = gt["state_names"].tolist()
+    assert any(k.startswith("encoder.transformer.encoders.3.self_attn.linear_q") for k in names) and len(names) == len(gt["state_shapes"])
+    assert np.isfinite(float(gt["loss_g"])) and len(gt["grad_g_norms"]) > 100 and int((gt["durations"].sum(1) == gt["in_mel_lengths"]).sum()) == 32
 
 
 def test_oracle_gan_step_at_the_benchmark_size(golden):

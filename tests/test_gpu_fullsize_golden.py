@@ -26,16 +26,93 @@ def _close(got, want, rel):
 
 # (wav_hat L2 checksum, acoustic losses, MR-STFT loss, adversarial terms, loss_g, AM grad norms, vocoder grad norms, loss_d, D grad norms)
 TOL = {"mixed": dict(wav=1e-4, am=1e-4, stft=2e-4, adv=3e-2, loss_g=2e-2, g_am=2e-3, g_voc=6e-2, loss_d=2e-2, g_d=6e-2),
-       "bf16": dict(wav=2e-3, am=1e-3, stft=3e-2, adv=3e-2, loss_g=2e-2, g_am=3e-2, g_voc=None, loss_d=2e-2, g_d=6e-2)}
+       "bf16": dict(wav=2e-3, am=1e-3, stft=3e-2, adv=3e-2, loss_g=2e-2, g_am=3e-2, g_voc=1.2e-1, loss_d=2e-2, g_d=6e-2)}   # g_voc measured 6.7e-2 (round 5: no bound before)
+# the Transformer backbone: softmax attention over 800 keys and 8 blocks of f32 / bf16 GEMMs per stack
+TOL_TF = {"mixed": dict(wav=2e-4, am=2e-4, stft=4e-4, adv=3e-2, loss_g=2e-2, g_am=5e-3, g_voc=6e-2, loss_d=2e-2, g_d=6e-2),
+          "bf16": dict(wav=4e-3, am=2e-3, stft=3e-2, adv=3e-2, loss_g=2e-2, g_am=5e-2, g_voc=2.5e-1, loss_d=2e-2, g_d=6e-2)}
+
+
+def _report(tag, worst):
+    """Measured worst errors of a run -> $OSP_TEST_REPORT/<tag>.txt (how the stated bounds were chosen; not an assertion)."""
+    import os
+    d = os.environ.get("OSP_TEST_REPORT")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, tag + ".txt"), "w") as fh:
+            for k, v in worst.items():
+                fh.write(f"{k}: {v}\n")
+
+
+def _gan_step_check(m, g, tol, tag, min_am=60, min_voc=30):
+    """One GAN step of ``m`` (weights loaded, dropout off) on the fixture's regenerated batch against the reference's checksums."""
+    from tests.test_gpu_training import _ref_grads
+    worst = {}
+
+    def rel(name, got, want, bound, floor=0.0):
+        e = abs(float(got) - float(want)) / max(abs(float(want)), 1e-30)
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert abs(float(got) - float(want)) <= bound * abs(float(want)) + floor, (name, float(got), float(want), bound)
+    m.generator.segment_rand01 = torch.from_numpy(g["rand01"])
+    batch = {k: torch.from_numpy(v) for k, v in GI.gan_batch(g).items()}
+    batch.update(sids=None, lids=None)
+    m.discriminator.lambda_mel = 0.0                  # the reference run could not evaluate torchaudio's mel
+    logs = {}
+    for p in m.discriminator.parameters():
+        p.requires_grad_(False)
+    loss_g, (wav, wav_hat) = m.training_step_g(batch, True, logs)
+    out = m._last_gen_outputs
+    aux = out["_aux"]
+    assert np.array_equal(out["start_idx"].cpu().numpy(), g["start_idx"])               # segment starts: exact
+    ndiff = int((aux["durations"].cpu().numpy() != g["durations"]).sum())
+    assert ndiff == 0, f"{ndiff} of {g['durations'].size} durations differ from the reference's MAS paths"
+    assert _close(wav.double().norm().item(), g["wav_cks"][1], 1e-9)                     # ground-truth segment gather: exact
+    assert _close(wav.double().sum().item(), g["wav_cks"][0], 1e-6)
+    for k, kk in (("p_avg", "p_avg"), ("e_avg", "e_avg")):
+        d = (aux[k].cpu().double() - torch.from_numpy(g[kk]).double()).abs().max().item()
+        assert d <= 1e-4 * np.abs(g[kk]).max(), (k, d)
+    for k in ("loss", "align_loss", "duration_loss", "pitch_loss", "energy_loss"):
+        rel("am:" + k, out[k].item(), g[k], tol["am"])
+    rel("wav_hat_l2", wav_hat.double().norm().item(), g["wav_hat_l2"], tol["wav"])
+    rel("mr_stft", logs["gen_adv_loss/train_mr_stft_loss"].item(), float(g["genlog_mr_stft_loss"]), tol["stft"])
+    for k in ("loss_gen_mp", "loss_gen_mrd", "loss_fm_mp", "loss_fm_mrd"):
+        rel("adv:" + k, logs["gen_adv_loss/train_" + k].item(), float(g["genlog_" + k]), tol["adv"], 1e-3)
+    rel("loss_g", loss_g.item(), g["loss_g"], tol["loss_g"])
+    loss_g.backward()
+    gg = _ref_grads(m.generator)
+    n_am = n_voc = 0
+    for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
+        if n < 1e-3:
+            # a sum of large cancelling terms (the positional-embedding scale: one scalar, sum over every token and channel,
+            # 2.3e-4 here): its relative error is the terms' absolute round-off -- bounded absolutely
+            assert gg[k].double().norm().item() < 1e-2, (k, gg[k].double().norm().item(), n)
+            continue
+        if k.startswith("vocoder."):
+            rel("g_voc", gg[k].double().norm().item(), n, tol["g_voc"])
+            n_voc += 1
+        else:
+            rel("g_am", gg[k].double().norm().item(), n, tol["g_am"])
+            n_am += 1
+    assert n_am > min_am and n_voc > min_voc, (n_am, n_voc)
+    for k in g["grad_g_none"].tolist():                                                  # decoder / energy embed: no gradient
+        assert gg[k] is None or float(gg[k].abs().max()) == 0.0, k
+    for p in m.discriminator.parameters():
+        p.requires_grad_(True)
+    m.optimizers()[1].zero_grad()
+    loss_d = m.training_step_d(batch, (wav, wav_hat.detach()), logs)
+    rel("loss_d", loss_d.item(), g["loss_d"], tol["loss_d"])
+    loss_d.backward()
+    gd = _ref_grads(m.discriminator)
+    for k, n in zip(g["grad_d_names"].tolist(), g["grad_d_norms"].tolist()):
+        if n > 1e-4:
+            rel("g_d", gd[k].double().norm().item(), n, tol["g_d"])
+    _report(tag, worst)
 
 
 @pytest.mark.parametrize("mode", ["mixed", "bf16"])
 def test_b32_gan_step_vs_reference_checksums(golden, mode):
     from optispeech_amd import precision
     from optispeech_amd.config import ModelConfig, make_optispeech
-    from tests.test_gpu_training import _ref_grads
     g = golden("full_b32_gan")
-    tol = TOL[mode]
     precision.set_precision(mode)
     try:
         m = make_optispeech(ModelConfig().no_dropout(), batch_size=32, pretraining_steps=0).to(DEV).train()
@@ -43,63 +120,33 @@ def test_b32_gan_step_vs_reference_checksums(golden, mode):
         W.update(S.make_weights(S.discriminator_schema(), int(g["disc_seed"])))
         missing, unexpected = m.load_state_dict(W, strict=False)
         assert not unexpected and all(("melspec" in k or "window" in k) for k in missing), (missing, unexpected)
-        m.generator.segment_rand01 = torch.from_numpy(g["rand01"])
-        batch = {k: torch.from_numpy(v) for k, v in GI.gan_batch(g).items()}
-        batch.update(sids=None, lids=None)
-        m.discriminator.lambda_mel = 0.0                  # the reference run could not evaluate torchaudio's mel
-        logs = {}
-        for p in m.discriminator.parameters():
-            p.requires_grad_(False)
-        loss_g, (wav, wav_hat) = m.training_step_g(batch, True, logs)
-        out = m._last_gen_outputs
-        aux = out["_aux"]
-        assert np.array_equal(out["start_idx"].cpu().numpy(), g["start_idx"])               # segment starts: exact
-        ndiff = int((aux["durations"].cpu().numpy() != g["durations"]).sum())
-        assert ndiff == 0, f"{ndiff} of {g['durations'].size} durations differ from the reference's MAS paths"
-        assert _close(wav.double().norm().item(), g["wav_cks"][1], 1e-9)                     # ground-truth segment gather: exact
-        assert _close(wav.double().sum().item(), g["wav_cks"][0], 1e-6)
-        for k, kk in (("p_avg", "p_avg"), ("e_avg", "e_avg")):
-            d = (aux[k].cpu().double() - torch.from_numpy(g[kk]).double()).abs().max().item()
-            assert d <= 1e-4 * np.abs(g[kk]).max(), (k, d)
-        for k in ("loss", "align_loss", "duration_loss", "pitch_loss", "energy_loss"):
-            assert _close(out[k].item(), g[k], tol["am"]), (k, out[k].item(), float(g[k]))
-        assert _close(wav_hat.double().norm().item(), g["wav_hat_l2"], tol["wav"]), (wav_hat.double().norm().item(), float(g["wav_hat_l2"]))
-        got, want = logs["gen_adv_loss/train_mr_stft_loss"].item(), float(g["genlog_mr_stft_loss"])
-        assert abs(got - want) <= tol["stft"] * abs(want), (got, want)
-        for k in ("loss_gen_mp", "loss_gen_mrd", "loss_fm_mp", "loss_fm_mrd"):
-            got, want = logs["gen_adv_loss/train_" + k].item(), float(g["genlog_" + k])
-            assert abs(got - want) <= tol["adv"] * abs(want) + 1e-3, (k, got, want)
-        assert _close(loss_g.item(), g["loss_g"], tol["loss_g"])
-        loss_g.backward()
-        gg = _ref_grads(m.generator)
-        n_am = n_voc = 0
-        for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
-            if n < 1e-3:
-                # a sum of large cancelling terms (the positional-embedding scale: one scalar, sum over every token and channel,
-                # 2.3e-4 here): its relative error is the terms' absolute round-off -- bounded absolutely
-                assert gg[k].double().norm().item() < 1e-2, (k, gg[k].double().norm().item(), n)
-                continue
-            e = abs(gg[k].double().norm().item() - n) / n
-            if k.startswith("vocoder."):
-                if tol["g_voc"] is not None:
-                    assert e <= tol["g_voc"], (k, gg[k].double().norm().item(), n)
-                n_voc += 1
-            else:
-                assert e <= tol["g_am"], (k, gg[k].double().norm().item(), n)
-                n_am += 1
-        assert n_am > 60 and n_voc > 30, (n_am, n_voc)
-        for k in g["grad_g_none"].tolist():                                                  # decoder / energy embed: no gradient
-            assert gg[k] is None or float(gg[k].abs().max()) == 0.0, k
-        for p in m.discriminator.parameters():
-            p.requires_grad_(True)
-        m.optimizers()[1].zero_grad()
-        loss_d = m.training_step_d(batch, (wav, wav_hat.detach()), logs)
-        assert _close(loss_d.item(), g["loss_d"], tol["loss_d"]), (loss_d.item(), float(g["loss_d"]))
-        loss_d.backward()
-        gd = _ref_grads(m.discriminator)
-        for k, n in zip(g["grad_d_names"].tolist(), g["grad_d_norms"].tolist()):
-            if n > 1e-4:
-                assert abs(gd[k].double().norm().item() - n) <= tol["g_d"] * n, (k, gd[k].double().norm().item(), n)
+        _gan_step_check(m, g, TOL[mode], "b32_gan_" + mode)
+    finally:
+        precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("mode", ["mixed", "bf16"])
+def test_b32_transformer_gan_step_vs_reference_checksums(golden, mode):
+    """BASELINE configs[3] as a WHOLE MODEL at its own size: Transformer encoder + decoder
+    (configs/model/generator/{encoder,decoder}/transformer.yaml) inside the full generator, the GAN step, B = 32, T_mel <= 800,
+    against checksums of the reference run (tools/make_golden_b32.py transformer_gan).  The weights are make_weights over the
+    REFERENCE module's own state-dict names and shapes, which this model must expose exactly."""
+    from collections import OrderedDict
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_optispeech
+    g = golden("full_b32_transformer_gan")
+    precision.set_precision(mode)
+    try:
+        m = make_optispeech(ModelConfig(backbone="transformer").no_dropout(), batch_size=32, pretraining_steps=0).to(DEV).train()
+        names, shapes = g["state_names"].tolist(), g["state_shapes"].tolist()
+        mine = {k: tuple(v.shape) for k, v in m.generator.state_dict().items()}
+        ref = {k: tuple(int(d) for d in sh.split(",") if d) for k, sh in zip(names, shapes)}
+        assert mine == ref, (sorted(set(mine) ^ set(ref))[:6], [k for k in mine if k in ref and mine[k] != ref[k]][:6])
+        W = S.make_weights(OrderedDict(("generator." + k, ref[k]) for k in names), int(g["seed"]))
+        W.update(S.make_weights(S.discriminator_schema(), int(g["disc_seed"])))
+        missing, unexpected = m.load_state_dict(W, strict=False)
+        assert not unexpected and all(("melspec" in k or "window" in k) for k in missing), (missing, unexpected)
+        _gan_step_check(m, g, TOL_TF[mode], "b32_transformer_gan_" + mode, min_am=40)
     finally:
         precision.set_precision("f32")
 

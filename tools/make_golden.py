@@ -21,6 +21,7 @@ Stubs / shims:
   * torchaudio is inert -> MelSpecReconstructionLoss is NOT exercised (parity unpinned).
 """
 import functools
+from collections import OrderedDict
 import os
 import sys
 import types
@@ -189,10 +190,14 @@ def to_t(batch):
     return {k: torch.from_numpy(v) for k, v in batch.items()}
 
 
-def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors=True, disc=None, dweights=None):
+def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors=True, disc=None, dweights=None, gen=None):
     torch.manual_seed(0)
-    gen = build_generator(c).train()                 # train mode, all dropout rates 0
-    schema = S.generator_schema(c)
+    if gen is None:
+        gen = build_generator(c).train()                 # train mode, all dropout rates 0
+        schema = S.generator_schema(c)
+    else:                                                # another backbone: the schema IS the reference module's state dict
+        gen = gen.train()
+        schema = OrderedDict(("generator." + k, tuple(v.shape)) for k, v in gen.state_dict().items())
     weights = S.make_weights(schema, seed)
     load_weights(gen, weights, "generator.")
     batch = make_batch(c, B, tt_rng, tm_rng, seed + 1)

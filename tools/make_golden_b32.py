@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Checksum fixtures at the BENCHMARK'S OWN SIZE, produced by RUNNING THE REFERENCE in the build container.
 
-    python tools/make_golden_b32.py [gan] [synth] [transformer]     # writes tests/golden/full_b32_*.npz (a few hundred KB in all)
+    python tools/make_golden_b32.py [gan] [synth] [transformer] [transformer_gan]     # writes tests/golden/full_b32_*.npz (a few hundred KB in all)
 
   * ``full_b32_gan``   BASELINE configs[1]: B = 32, T_text <= 128, T_mel <= 800, ConvNeXt generator + the GAN step (G phase with the
                        frozen discriminators, D phase), dropout rates 0, fixed segment starts.  Stored: integer paths (durations,
@@ -63,6 +63,67 @@ def gan_case(name="full_b32_gan", B=32, seed=7788):
             res["wav_cks"] = _cks(v)
             continue
         res[k] = v
+    res["disc_seed"] = np.int64(seed + 11)
+    res["batch_args"] = np.array([B, 96, 128, 600, 800, seed + 1], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    print(name, "written in", round(time.time() - t0, 1), "s;", os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024, "KB")
+
+
+def transformer_gan_case(name="full_b32_transformer_gan", B=32, seed=6655):
+    """BASELINE configs[3] as a WHOLE MODEL: the reference OptiSpeechGenerator with the Transformer encoder / decoder of
+    configs/model/generator/{encoder,decoder}/transformer.yaml (dropout rates 0) + the GAN step, B = 32, T_text <= 128, T_mel <= 800.
+    Weights: oracle.schema.make_weights over the reference module's own state-dict names and shapes (stored, so that the test can
+    check its model exposes exactly those).  Checksums / norms only, like full_b32_gan."""
+    import functools
+    from types import SimpleNamespace
+    from optispeech.model.generator import OptiSpeechGenerator
+    from optispeech.model.generator import modules as RM
+    from optispeech.model.vocoder.wavenext import WaveNeXt
+    t0 = time.time()
+    c = S.Cfg()
+    P = functools.partial
+    fe = SimpleNamespace(n_feats=c.n_feats, n_fft=c.n_fft, hop_length=c.hop, win_length=c.n_fft, sample_rate=22050, f_min=80, f_max=8000)
+    lc = SimpleNamespace(lambda_align=5.0, lambda_duration=1.0, lambda_pitch=1.0, lambda_energy=1.0)
+    tr = P(RM.Transformer, attention_heads=2, linear_units=1024, num_blocks=4, dropout_rate=0.0, positional_dropout_rate=0.0,
+           attention_dropout_rate=0.0, normalize_before=True, concat_after=False, positionwise_layer_type="conv1d",
+           positionwise_conv_kernel_size=1, use_scaled_pos_enc=True, init_alpha=1.0, init_type="xavier_uniform")
+
+    def pred(cls, spec, **kw):
+        return P(cls, num_layers=spec[0], intermediate_dim=spec[1], kernel_size=spec[2], dropout=0.0, conv_layer_class=torch.nn.Conv1d, **kw)
+    gen = OptiSpeechGenerator(
+        dim=c.dim, segment_size=c.segment_size,
+        text_embedding=P(RM.TextEmbedding, n_vocab=c.n_vocab, dropout=0.0, padding_idx=0, max_source_positions=2000),
+        encoder=tr, duration_predictor=pred(RM.DurationPredictor, c.dur),
+        pitch_predictor=pred(RM.PitchPredictor, c.pitch, embed_kernel_size=c.embed_kernel, embed_dropout=0.0),
+        energy_predictor=pred(RM.EnergyPredictor, c.energy, embed_kernel_size=c.embed_kernel, embed_dropout=0.0),
+        decoder=tr, vocoder=P(WaveNeXt, dim=c.voc_dim, intermediate_dim=c.voc_inter, num_layers=c.voc_layers, drop_path=0.0),
+        loss_coeffs=lc, feature_extractor=fe, num_speakers=1, num_languages=1, data_statistics=None)
+    disc, _ = MG.build_disc(seed + 11)
+    tmp = "/tmp/osp_golden_b32"
+    os.makedirs(tmp, exist_ok=True)
+    keep_out, MG.OUT = MG.OUT, tmp
+    try:
+        MG.run_generator_case(name, c, B, (96, 128), (600, 800), seed, with_disc=True, full_tensors=False, disc=disc, gen=gen)
+    finally:
+        MG.OUT = keep_out
+    g = np.load(os.path.join(tmp, name + ".npz"), allow_pickle=False)
+    res = {}
+    for k in g.files:
+        v = g[k]
+        if k.startswith("in_"):
+            if k in ("in_x_lengths", "in_mel_lengths"):
+                res[k] = v
+            res["cks_" + k] = _cks(v)
+            continue
+        if k.startswith("grad_d/") or k.startswith("grad_g/"):
+            continue
+        if k == "wav":
+            res["wav_cks"] = _cks(v)
+            continue
+        res[k] = v
+    sd = gen.state_dict()
+    res["state_names"] = np.array(list(sd.keys()))
+    res["state_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
     res["disc_seed"] = np.int64(seed + 11)
     res["batch_args"] = np.array([B, 96, 128, 600, 800, seed + 1], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
@@ -148,3 +209,5 @@ if __name__ == "__main__":
         synth_case()
     if "transformer" in which:
         transformer_case()
+    if "transformer_gan" in which:
+        transformer_gan_case()
