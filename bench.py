@@ -47,6 +47,24 @@ def _pmc_file(name):
     return pj, stale
 
 
+def _pmc_lookup(table, sym):
+    """The counter summary's row for a dispatcher symbol: exact name, the name without template arguments, or the instantiation whose
+    first template argument matches (`conv_wgrad_ring_kernel<128>` -> `conv_wgrad_ring_kernel<128, 2>`)."""
+    if not table:
+        return None
+    base = sym.split("<")[0]
+    if sym in table:
+        return table[sym]
+    if base in table:
+        return table[base]
+    arg = sym[len(base) + 1:].rstrip(">").split(",")[0].strip() if "<" in sym else None
+    cands = [k for k in table if k.split("<")[0] == base and isinstance(table[k], dict)]
+    if arg is not None:
+        hit = [k for k in cands if k[len(base) + 1:].split(",")[0].strip(" >") == arg]
+        cands = hit or cands
+    return table[sorted(cands, key=lambda k: -table[k].get("launches", 0))[0]] if cands else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -725,10 +743,10 @@ def main():
         if a.precision != "f32" and not a.ragged and pj is not None and dom:
             roof["traffic_stale"] = pmc_stale                     # True: collected from other sources than this library's (see _pmc_file)
             for sym, row in roof["mfma_kernels"].items():
-                hit = pj.get(sym.split("<")[0])
+                hit = _pmc_lookup(pj, sym)
                 if hit:
                     row["traffic"], row["l2_hit_rate"] = hit.get("traffic_bytes_per_launch"), hit.get("l2_hit_rate")
-            pj = pj.get(dom.split("<")[0], {})
+            pj = _pmc_lookup(pj, dom) or {}
             roof["traffic"] = pj.get("traffic_bytes_per_launch")
             roof["l2_hit_rate"] = pj.get("l2_hit_rate")
             roof["traffic_unit"] = "bytes/launch, read from profiles/" + PMC_SUMMARY + " (separate --pmc pass: TCC_EA0 read x 128 B + write x 64 B)"
@@ -737,13 +755,13 @@ def main():
             bj = bjf.get("kernels", {})
             roof["mfma_busy_stale"] = busy_stale
             for sym, row in roof["mfma_kernels"].items():
-                hit = bj.get(sym) or bj.get(sym.split("<")[0])
+                hit = _pmc_lookup(bj, sym)
                 if hit and "mfma_busy" in hit:
                     row["mfma_busy"] = hit["mfma_busy"]
                     for kk in ("waves_parked", "waves_issue_stalled", "waves_issuing"):
                         if kk in hit:
                             row[kk] = hit[kk]
-            hit = bj.get(dom) or bj.get(dom.split("<")[0]) or {}
+            hit = _pmc_lookup(bj, dom) or {}
             roof["mfma_busy"] = hit.get("mfma_busy")
             roof["mfma_busy_unit"] = ("share of SIMD time the matrix pipe is busy: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x kernel clocks), read "
                                       "from profiles/" + PMC_MFMA + " (separate rocprofv3 --pmc passes, tools/pmc_mfma.sh)")
