@@ -623,7 +623,10 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
     // widest DiscriminatorP layers
     static int w8first = -1;
     if (w8first < 0) { const char* e = getenv("OSP_WGRAD_W8"); w8first = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!(w8first && N % 256 == 0 && Cin % 256 == 0 && M >= 8192 && batch == 1)) {
+    // (the 8-wave kernel only where its 256 x 256 tiles are many: N x Cin >= 512 x 512.  A 256 <- 256 layer at M = 25 600 -- the alignment
+    // module's feature convs -- is ONE tile per tap there, i.e. 85 frame splits and 16.7 M atomics: 76 us, on the tail of the generator's backward)
+    const bool wide8 = N % 256 == 0 && Cin % 256 == 0 && M >= 8192 && N * Cin >= 512 * 512;
+    if (!(w8first && wide8 && batch == 1)) {
         const int took = osp_launch_wgrad_ring(p, batch, ws, ws_bytes, stream);
         if (took) { OSP_LAUNCH_CHECK(); return OSP_OK; }
     }
@@ -678,7 +681,7 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_tr8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_tr8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         }
-        if (w8 && N % 256 == 0 && Cin % 256 == 0 && M >= 8192) {
+        if (w8 && wide8) {
             const int64_t tl8 = (N / 256) * taps * (Cin / 256) * batch;
             static int64_t tgt8 = -1;
             if (tgt8 < 0) { tgt8 = 256; }
