@@ -204,7 +204,7 @@ class _Multi(nn.Module):
         assert len(streams) == len(self.discriminators)
         if ready is None:
             ready = main.record_event()
-        outs = []
+        outs, fms = [], []
         for d, st in zip(self.discriminators, streams):
             st.wait_event(ready)
             with torch.cuda.stream(st):
@@ -218,11 +218,17 @@ class _Multi(nn.Module):
                 else:                                        # generator phase: no-grad head = the real waves
                     (r, fr), (g, fg) = d(x, nograd_head=B)
                     out = (r, g, fr, fg)
+                    if _FM_PER_STACK and _fused_losses(fg[0]):
+                        # this stack's share of the feature-matching sum, on the stack's own stream: the |a - b| reduction runs beside the
+                        # other stacks' GEMMs instead of after the join of all eight, and its backward (sign kernel) at the head of this
+                        # stack's backward, again on this stream (autograd replays a node where its forward ran)
+                        fms.append(FeatureMatchSumFn.apply(len(fg), *[a.detach() for a in fr], *fg))
             x.record_stream(st)
             outs.append(out)
+        self._fm_partials = fms if len(fms) == len(self.discriminators) else None
         rs, gs, frs, fgs = [], [], [], []
-        for (r, g, fr, fg), st in zip(outs, streams):
-            _PENDING.append((st, [r, g] + list(fr) + list(fg)))
+        for i, ((r, g, fr, fg), st) in enumerate(zip(outs, streams)):
+            _PENDING.append((st, [r, g] + list(fr) + list(fg) + ([fms[i]] if self._fm_partials is not None else [])))
             rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
         if not defer_join:
             join_streams()
@@ -230,6 +236,9 @@ class _Multi(nn.Module):
 
 
 _DISC_STREAMS = os.environ.get("OSP_DISC_STREAMS", "1") != "0"
+#: generator phase: the feature-matching loss as one node PER sub-discriminator on that stack's stream (round 5) instead of one node
+#: per family after all stacks have joined
+_FM_PER_STACK = os.environ.get("OSP_FM_PER_STACK", "1") != "0"
 _PERIOD_FOLD = os.environ.get("OSP_PERIOD_FOLD", "1") != "0"
 #: hinge / feature-matching means as one autograd node per loss term (fused reductions) instead of ~10 torch ops per map
 _FUSED_LOSSES = os.environ.get("OSP_FUSED_LOSSES", "1") != "0"
@@ -422,8 +431,11 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         if _fused_losses(g_mp[0]):
             from ..ops import weighted_sum
             n_mp, n_mr = len(g_mp), len(g_mr)
-            s = [_hinge_g(g_mp, raw=True), _hinge_g(g_mr, raw=True), _feature_matching(fr_mp, fg_mp, raw=True),
-                 _feature_matching(fr_mr, fg_mr, raw=True)]
+            pm, pr = getattr(self.multiperioddisc, "_fm_partials", None), getattr(self.multiresddisc, "_fm_partials", None)
+            self.multiperioddisc._fm_partials = self.multiresddisc._fm_partials = None
+            fm_mp = weighted_sum(pm, [1.0] * len(pm)) if pm else _feature_matching(fr_mp, fg_mp, raw=True)
+            fm_mr = weighted_sum(pr, [1.0] * len(pr)) if pr else _feature_matching(fr_mr, fg_mr, raw=True)
+            s = [_hinge_g(g_mp, raw=True), _hinge_g(g_mr, raw=True), fm_mp, fm_mr]
             loss = weighted_sum(s + [mel_loss, mr_stft_loss], [1.0 / n_mp, lam / n_mr, 1.0 / n_mp, lam / n_mr, 1.0, 1.0])
             logs = dict(loss_gen_mp=s[0].detach() / n_mp, loss_gen_mrd=s[1].detach() / n_mr, loss_fm_mp=s[2].detach() / n_mp,
                         loss_fm_mrd=s[3].detach() / n_mr, mel_loss=mel_loss.detach(), mr_stft_loss=mr_stft_loss.detach())

@@ -275,6 +275,9 @@ class _AtenGuard(TorchDispatchMode):
             if out is not NotImplemented:
                 return out
             self.rec.rerouted -= 1
+        if os.environ.get("OSP_TAPE_DUMP", "0") == "1":            # every offending operator, not only the first (what to re-route next)
+            shapes = [tuple(a.shape) if isinstance(a, torch.Tensor) else a for a in args][:4]
+            print(f"[tape] {self.rec.label}: {func} {shapes} is not re-routed", flush=True)
         self.rec.poison(f"ATen operator {func} launched a kernel inside the region")
         return func(*args, **(kwargs or {}))
 
