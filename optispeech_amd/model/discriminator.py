@@ -204,7 +204,7 @@ class _Multi(nn.Module):
         assert len(streams) == len(self.discriminators)
         if ready is None:
             ready = main.record_event()
-        outs, fms = [], []
+        outs, fms, hgs = [], [], []
         for d, st in zip(self.discriminators, streams):
             st.wait_event(ready)
             with torch.cuda.stream(st):
@@ -215,6 +215,19 @@ class _Multi(nn.Module):
                     o, fm = d(x)
                     r_, g_ = SplitHalvesFn.apply(o, B)
                     out = (r_, g_, [f[: f.shape[0] // 2] for f in fm], [f[f.shape[0] // 2:] for f in fm])
+                    if _FM_PER_STACK and _fused_losses(r_):
+                        # this stack's hinge term as its own node on its own stream: its backward needs nothing of the OTHER stacks, so the
+                        # stack goes from forward to backward without the phase-wide join in between
+                        hgs.append(HingeSumFn.apply((-1.0, 1.0), r_, g_))
+                        inl = _INLINE["on"]
+                        if inl is not None:
+                            # ... and RUNS that backward right here (discriminator phase of the pipelined step): the phase's loss is
+                            # sum_i c_i * hinge_i with host-known c_i, so stack i's gradient seed is a constant -- no loss node on the
+                            # phase's calling stream whose kernels (and the join in front of them) every stack's backward would wait for
+                            st.wait_event(inl["zeroed"])                   # the gradient arena was cleared on the phase's stream
+                            with torch.autograd.set_multithreading_enabled(False):
+                                torch.autograd.backward([hgs[-1]], [_const_scalar(inl["coef"][id(self)], x.device)])
+                            hgs[-1] = hgs[-1].detach()
                 else:                                        # generator phase: no-grad head = the real waves
                     (r, fr), (g, fg) = d(x, nograd_head=B)
                     out = (r, g, fr, fg)
@@ -223,12 +236,15 @@ class _Multi(nn.Module):
                         # other stacks' GEMMs instead of after the join of all eight, and its backward (sign kernel) at the head of this
                         # stack's backward, again on this stream (autograd replays a node where its forward ran)
                         fms.append(FeatureMatchSumFn.apply(len(fg), *[a.detach() for a in fr], *fg))
+                        hgs.append(HingeSumFn.apply((-1.0,), g))
             x.record_stream(st)
             outs.append(out)
         self._fm_partials = fms if len(fms) == len(self.discriminators) else None
+        self._hinge_partials = hgs if len(hgs) == len(self.discriminators) else None
         rs, gs, frs, fgs = [], [], [], []
         for i, ((r, g, fr, fg), st) in enumerate(zip(outs, streams)):
-            _PENDING.append((st, [r, g] + list(fr) + list(fg) + ([fms[i]] if self._fm_partials is not None else [])))
+            _PENDING.append((st, [r, g] + list(fr) + list(fg) + ([fms[i]] if self._fm_partials is not None else [])
+                             + ([hgs[i]] if self._hinge_partials is not None else [])))
             rs.append(r); gs.append(g); frs.append(fr); fgs.append(fg)
         if not defer_join:
             join_streams()
@@ -247,6 +263,21 @@ _STREAMS = {}
 _DISC_PRIORITY = int(os.environ.get("OSP_PRIO_DISC", "0"))
 _MAX_STREAMS = int(os.environ.get("OSP_DISC_MAX_STREAMS", "8"))     # streams per discriminator family
 _PENDING = []
+#: set by OptiSpeech._stage_d around forward_disc: {"coef": {id(family): d loss / d hinge_i}, "zeroed": event after zero_grad}
+_INLINE = {"on": None}
+_CONSTS = {}
+
+
+def _const_scalar(v, device):
+    """A persistent 0-d f32 device tensor holding ``v`` (gradient seeds of the inline per-stack backward)."""
+    k = (float(v), str(device))
+    t = _CONSTS.get(k)
+    if t is None:
+        if len(_CONSTS) > 64:
+            _CONSTS.clear()
+        t = _CONSTS[k] = torch.full((), float(v), device=device, dtype=torch.float32)
+        torch.cuda.current_stream().synchronize()            # created once: every stream may read it from now on
+    return t
 
 
 def join_streams():
@@ -378,9 +409,22 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         with precision.disc_scope():
             return self._prepare_disc_inputs(wav, wav_hat)
 
-    def forward_disc(self, wav, wav_hat, real=None, pre=None, replay=False):
+    def forward_disc(self, wav, wav_hat, real=None, pre=None, replay=False, inline_backward=None):
+        """inline_backward = (1 / accumulation scale, event recorded after the gradient arena was cleared): every sub-discriminator
+        runs its backward right behind its forward on its own stream (see _forward_concurrent); the returned loss is then a detached
+        value -- there is nothing left to call backward() on."""
         with precision.disc_scope():
-            return self._forward_disc(wav, wav_hat, real=real, pre=pre, replay=replay)
+            inl = None
+            if (inline_backward is not None and real is None and not replay and precision.is_bf16() and _DISC_STREAMS and _FM_PER_STACK
+                    and wav.is_cuda and torch.is_grad_enabled()):
+                n_mp, n_mr = len(self.multiperioddisc.discriminators), len(self.multiresddisc.discriminators)
+                inl = {"coef": {id(self.multiperioddisc): inline_backward[0] / n_mp,
+                                id(self.multiresddisc): inline_backward[0] * self.loss_coeffs.lambda_mrd / n_mr}, "zeroed": inline_backward[1]}
+            _INLINE["on"] = inl
+            try:
+                return self._forward_disc(wav, wav_hat, real=real, pre=pre, replay=replay)
+            finally:
+                _INLINE["on"] = None
 
     def forward_gen(self, wav, wav_hat, real=None):
         with precision.disc_scope():
@@ -405,7 +449,10 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
         if _fused_losses(r_mp[0]):
             # the 1 / #sub-discriminators of each family and lambda_mrd are coefficients of ONE weighted-sum node
             from ..ops import weighted_sum
-            s_mp, s_mr = _hinge_d(r_mp, g_mp, raw=True), _hinge_d(r_mr, g_mr, raw=True)
+            hm, hr = getattr(self.multiperioddisc, "_hinge_partials", None), getattr(self.multiresddisc, "_hinge_partials", None)
+            self.multiperioddisc._hinge_partials = self.multiresddisc._hinge_partials = None
+            s_mp = weighted_sum(hm, [1.0] * len(hm)) if hm else _hinge_d(r_mp, g_mp, raw=True)
+            s_mr = weighted_sum(hr, [1.0] * len(hr)) if hr else _hinge_d(r_mr, g_mr, raw=True)
             n_mp, n_mr = len(r_mp), len(r_mr)
             loss = weighted_sum([s_mp, s_mr], [1.0 / n_mp, self.loss_coeffs.lambda_mrd / n_mr])
             return loss, dict(loss_mp=s_mp.detach() / n_mp, loss_mrd=s_mr.detach() / n_mr)
@@ -435,7 +482,10 @@ class VocosDiscriminator(BaseVocoderDiscriminator):
             self.multiperioddisc._fm_partials = self.multiresddisc._fm_partials = None
             fm_mp = weighted_sum(pm, [1.0] * len(pm)) if pm else _feature_matching(fr_mp, fg_mp, raw=True)
             fm_mr = weighted_sum(pr, [1.0] * len(pr)) if pr else _feature_matching(fr_mr, fg_mr, raw=True)
-            s = [_hinge_g(g_mp, raw=True), _hinge_g(g_mr, raw=True), fm_mp, fm_mr]
+            hm, hr = getattr(self.multiperioddisc, "_hinge_partials", None), getattr(self.multiresddisc, "_hinge_partials", None)
+            self.multiperioddisc._hinge_partials = self.multiresddisc._hinge_partials = None
+            s = [weighted_sum(hm, [1.0] * len(hm)) if hm else _hinge_g(g_mp, raw=True),
+                 weighted_sum(hr, [1.0] * len(hr)) if hr else _hinge_g(g_mr, raw=True), fm_mp, fm_mr]
             loss = weighted_sum(s + [mel_loss, mr_stft_loss], [1.0 / n_mp, lam / n_mr, 1.0 / n_mp, lam / n_mr, 1.0, 1.0])
             logs = dict(loss_gen_mp=s[0].detach() / n_mp, loss_gen_mrd=s[1].detach() / n_mr, loss_fm_mp=s[2].detach() / n_mp,
                         loss_fm_mrd=s[3].detach() / n_mr, mel_loss=mel_loss.detach(), mr_stft_loss=mr_stft_loss.detach())

@@ -69,6 +69,10 @@ _D_AFTER_G = __import__("os").environ.get("OSP_D_AFTER_G", "0") == "1"
 #: DESIGN.md section 9): 15.45 ms (early start alone: the phase still starts when the backward ends) / 16.4-16.7 ms (update first)
 #: against 15.45 ms, with every placement of the phase's stream on the hardware queues tried (profiles/r05_early_d_ab.txt)
 _EARLY_D = __import__("os").environ.get("OSP_EARLY_D", "0") == "1"
+#: pipelined discriminator phase: per-stack forward -> loss term -> backward without a phase-wide join (round 5).  MEASURED AND LEFT OFF:
+#: 15.09-15.11 vs 14.92-14.99 ms per step (eight small backward() calls cost the host more than the missing join gives the device;
+#: DESIGN.md section 9); OSP_INLINE_D=1 turns it on
+_INLINE_D = __import__("os").environ.get("OSP_INLINE_D", "0") == "1"
 _G_OPT_FIRST = __import__("os").environ.get("OSP_G_OPT_FIRST", "0") == "1"
 
 
@@ -380,13 +384,23 @@ class OptiSpeech(nn.Module):
             # calling stream (instead of as soon as the waves exist)
             st.pre = (st.pre[0], self._g_done_event if self._g_done_event is not None else torch.cuda.current_stream().record_event())
         try:
-            loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre,
-                                          replay=self.replay_disc_forward and self.train_args.cache_generator_outputs)
-            if st.apply:
+            replay = self.replay_disc_forward and self.train_args.cache_generator_outputs
+            inline = None
+            if (_INLINE_D and self.pipeline_steps and st.apply and not shared and not replay and st.pre is not None
+                    and not torch.cuda.is_current_stream_capturing()):
+                # every sub-discriminator goes forward -> hinge -> backward on its own stream without the phase-wide join in
+                # between (model/discriminator.py: _forward_concurrent); the arena is cleared first, and the stacks wait for that
                 self.optimizers()[1].zero_grad()
-            ops.begin_backward()
-            with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):
-                (loss_d / st.scale).backward()
+                inline = (1.0 / st.scale, torch.cuda.current_stream().record_event())
+            loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre, replay=replay, inline_backward=inline)
+            if loss_d.requires_grad:
+                if st.apply and inline is None:
+                    self.optimizers()[1].zero_grad()
+                elif inline is not None:
+                    raise RuntimeError("inline discriminator backward was requested but the phase returned a differentiable loss")
+                ops.begin_backward()
+                with torch.autograd.set_multithreading_enabled(_AUTOGRAD_MT):
+                    (loss_d / st.scale).backward()
         finally:
             if shared and red_d is not None:
                 red_d.eager_ranges = keep_ranges
@@ -473,11 +487,11 @@ class OptiSpeech(nn.Module):
         self._last_gen_outputs = gen_outputs
         return loss, (wav.detach(), wav_hat)
 
-    def training_step_d(self, batch, wav_outputs, logs, pre=None, replay=False):
+    def training_step_d(self, batch, wav_outputs, logs, pre=None, replay=False, inline_backward=None):
         """base_lightning_module.py:163-186; D sees wav_hat.detach()."""
         wav, wav_hat = wav_outputs
         real, self._real_pass = getattr(self, "_real_pass", None), None
-        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real, pre=pre, replay=replay)
+        loss, log_dict = self.discriminator.forward_disc(wav, wav_hat, real=real, pre=pre, replay=replay, inline_backward=inline_backward)
         logs["total_loss/discriminator"] = loss.detach()
         logs.update({f"discriminator/{k}": v for k, v in log_dict.items()})
         return loss
