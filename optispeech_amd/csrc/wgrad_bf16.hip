@@ -467,7 +467,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
     const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
     const int blk_kh = j / p.KW, blk_kw = j - blk_kh * p.KW;
     const bool do_bias = (p.db != nullptr) && (within == 0);
-    const bool bias_wave = __builtin_amdgcn_readfirstlane((int)(do_bias && wn == 0)) != 0;
+    const bool do_bias_wg = __builtin_amdgcn_readfirstlane((int)do_bias) != 0;
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(osp_zero_page);
     const int64_t ldy = p.ldy, ldx = p.ldx;
     auto swz = [](int row) { return 4 * (row & 3); };
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
     // staging: per slab and operand 2 sub-slabs x 16 row blocks of 4 rows; wave w, pair i: sub-slab i & 1, row block 2 w + (i >> 1)
     const int srow = lane / S, lslot = (lane % S) ^ swz(srow);
     const int ldy32 = (int)ldy, ldx32 = (int)ldx;
@@ -525,6 +525,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
         const unsigned short* ys = smem + buf * (4 * SUB) + wm * SUB;
         const unsigned short* xs = smem + buf * (4 * SUB) + (2 + (wn >> 1)) * SUB;
         const int xc0 = (wn & 1) * 64;
+        // (requesting the fragments of k-step s + 1 before the MFMAs of k-step s -- what helps the one-wave-per-SIMD ring kernels --
+        // measured 184 vs 187 us here: two waves per SIMD already cover each other's LDS latency; not kept)
 #pragma unroll
         for (int ks = 0; ks < SK / 16; ++ks) {
             bf16x8 a[4], b[2];
@@ -538,14 +540,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
-            if (bias_wave) {                                  // scalar condition; lane (l31, lh) holds channel l31, frames 8 lh .. 8 lh + 7
+            if (do_bias_wg) {                                 // workgroup-uniform; lane (l31, lh) holds channel l31, frames 8 lh .. 8 lh + 7
+                // the four waves that share these A fragments (wn = 0..3) take ONE 32-channel block each: summing all four in the
+                // wn = 0 waves (32 cvt + 32 add per k-step on 2 of 8 waves) made them the stragglers of every slab barrier --
+                // 200 -> 185 us on the 1024 <- 1024 layer, 131 -> 121 us on 1024 <- 512 (round 5)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float sacc = 0.f;
+                for (int i = 0; i < 4; ++i)
+                    if (wn == i) {                            // wave-uniform
+                        float sacc = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) sacc += (float)a[i][q];
-                    bsum[i] += sacc;
-                }
+                        for (int q = 0; q < 8; ++q) sacc += (float)a[i][q];
+                        bsum += sacc;
+                    }
             }
         }
     };
@@ -578,13 +584,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_tr8_kernel(WgradB p) {
                 else atomicAdd(dst, val);
             }
         }
-    if (bias_wave) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);                     // the two 8-frame halves of every k-step
-            const int n = n0 + wm * 128 + 32 * i + l31;
-            if (lh == 0) atomicAdd(p.db + (int64_t)bz * p.sDb + n, (p.oscale ? p.oscale[n] : 1.f) * tot);
-        }
+    if (do_bias_wg) {
+        const float tot = bsum + __shfl_xor(bsum, 32, 64);                               // the two 8-frame halves of every k-step
+        const int n = n0 + wm * 128 + 32 * wn + l31;
+        if (lh == 0) atomicAdd(p.db + (int64_t)bz * p.sDb + n, (p.oscale ? p.oscale[n] : 1.f) * tot);
     }
 }
 

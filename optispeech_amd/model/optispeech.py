@@ -390,8 +390,11 @@ class OptiSpeech(nn.Module):
                     and not torch.cuda.is_current_stream_capturing()):
                 # every sub-discriminator goes forward -> hinge -> backward on its own stream without the phase-wide join in
                 # between (model/discriminator.py: _forward_concurrent); the arena is cleared first, and the stacks wait for that
-                self.optimizers()[1].zero_grad()
-                inline = (1.0 / st.scale, torch.cuda.current_stream().record_event())
+                ev, self._d_zeroed = getattr(self, "_d_zeroed", None), None
+                if ev is None:
+                    self.optimizers()[1].zero_grad()
+                    ev = torch.cuda.current_stream().record_event()
+                inline = (1.0 / st.scale, ev)
             loss_d = self.training_step_d(batch, (st.wav, st.wav_hat.detach()), st.logs, pre=st.pre, replay=replay, inline_backward=inline)
             if loss_d.requires_grad:
                 if st.apply and inline is None:
@@ -417,6 +420,12 @@ class OptiSpeech(nn.Module):
             self.optimizers()[1].step(max_norm=self.train_args.gradient_clip_val, grad_scale=1.0 / self._reducers[1].world)
             self.lr_schedulers()[1].step()
             self.global_step += 1
+            if _INLINE_D and self.pipeline_steps and not torch.cuda.is_current_stream_capturing():
+                # inline discriminator backward: clear the arena NOW (nothing writes it before the next discriminator phase: the
+                # generator phase runs with the discriminator frozen), so that the next phase's stacks need not wait for a clear that
+                # is ordered behind the generator's whole backward
+                self.optimizers()[1].zero_grad()
+                self._d_zeroed = torch.cuda.current_stream().record_event()
 
     def _disc_params(self):
         """The discriminator's parameter list, walked once (toggled twice per step: toggle_optimizer of the reference)."""

@@ -50,7 +50,7 @@ def mpd(tag, U, Tin, cin, cout, st=3):
     Tout = (Tin + 4 - 5) // st + 1
     x, dy = bf(U, Tin, cin), bf(U, Tout, cout)
     dw = torch.zeros(cout, 5, cin, device=dev)
-    db = torch.zeros(cout, device=dev)
+    db = None if os.environ.get("NOBIAS", "0") == "1" else torch.zeros(cout, device=dev)
     M = U * Tout
 
     def f():
