@@ -517,7 +517,7 @@ def main():
     calls1 = (_oslib.lib().ncalls, _tape0.stats().get("calls_replayed", 0))
     abi_calls = {"direct": (calls1[0] - calls0[0]) / a.steps, "replayed_from_tapes": (calls1[1] - calls0[1]) / a.steps,
                  "note": "C-ABI entry-point calls per timed step (almost all are one kernel launch; stream hand-overs and memsets are calls "
-                         "too); the rocprofv3 launch count of a step, ATen / runtime kernels included, is in profiles/r04_step_kernel_stats.csv (798)"}
+                         "too); the rocprofv3 launch count of a step, ATen / runtime kernels included, is in profiles/r05_step_kernel_stats.csv (946: the split reductions and bf16 operand copies of the weight gradients are launches of their own)"}
     comm_exposed = None
     if world > 1:
         # per rank: how long the step's streams stood still in GradReducer.wait() (generator gradients before AdamW(G), discriminator

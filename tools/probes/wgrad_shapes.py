@@ -37,7 +37,7 @@ def mrd(tag, U, H, W, KH, KW, sh, sw, ph, pw, C=64):
     Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
     x, dy = bf(U, H, W, C), bf(U, Ho, Wo, C)
     dw = torch.zeros(C, KH, KW, C, device=dev)
-    db = torch.zeros(C, device=dev)
+    db = None if os.environ.get("NOBIAS", "0") == "1" else torch.zeros(C, device=dev)
     M = U * Ho * Wo
 
     def f():
@@ -63,7 +63,7 @@ def pw(tag, M, n, cin, taps=1, f32=False, T=None):
     x = torch.randn(M, cin, device=dev) if f32 else bf(M, cin)
     dy = torch.randn(M, n, device=dev) if f32 else bf(M, n)
     dw = torch.zeros(n, taps, cin, device=dev)
-    db = torch.zeros(n, device=dev)
+    db = None if os.environ.get("NOBIAS", "0") == "1" else torch.zeros(n, device=dev)
     T = M if T is None else T
 
     def f():
