@@ -829,11 +829,14 @@ extern "C" int osp_pack_bf16(const float* w, const float* kscale, void* out, int
 
 // Many weight packs in one launch (the ConvNeXt blocks of a backbone need 3-4 bf16 copies each per optimiser step: W1, W2,
 // W1^T and gamma * W2^T; one osp_pack_bf16 launch apiece was 48-64 launches per step).  desc_host: count rows of 10 int64
-// {w, kscale (0 = none), out, N, taps, K, sN, sT, sK, reserved}; a workgroup finds its item in a prefix table of 32x32 tiles.
+// {w, kscale (0 = none), out, N, taps, K, sN, sT, sK, out_f32}; a workgroup finds its item in a prefix table of 32x32 tiles.
+// out_f32 = 1: the pack stays f32 (the k-contiguous weight copies of the exact-f32 input-gradient GEMMs, round 5: made by a torch gather
+// before, which a call tape cannot hold -- the taped segments therefore kept the k-strided views and the register-staged kernel).
 #define PACK_MULTI_MAX 32
 struct PackMulti { const float* w[PACK_MULTI_MAX]; const float* ks[PACK_MULTI_MAX]; unsigned short* out[PACK_MULTI_MAX];
                    int N[PACK_MULTI_MAX], taps[PACK_MULTI_MAX], K[PACK_MULTI_MAX], tk[PACK_MULTI_MAX], tn[PACK_MULTI_MAX];
-                   long long sN[PACK_MULTI_MAX], sT[PACK_MULTI_MAX], sK[PACK_MULTI_MAX]; int first[PACK_MULTI_MAX + 1]; int count; };
+                   long long sN[PACK_MULTI_MAX], sT[PACK_MULTI_MAX], sK[PACK_MULTI_MAX]; int first[PACK_MULTI_MAX + 1]; int f32[PACK_MULTI_MAX];
+                   int count; };
 __global__ __launch_bounds__(256) void pack_bf16_multi_kernel(PackMulti d) {
     __shared__ float tile[32][33];
     int it = 0;
@@ -857,7 +860,11 @@ __global__ __launch_bounds__(256) void pack_bf16_multi_kernel(PackMulti d) {
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
-        if (n < N && k < K) d.out[it][((long long)n * taps + tap) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][r]);
+        if (n < N && k < K) {
+            const long long o = ((long long)n * taps + tap) * K + k;
+            if (d.f32[it]) reinterpret_cast<float*>(d.out[it])[o] = tile[tx][r];
+            else d.out[it][o] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][r]);
+        }
     }
 }
 extern "C" int osp_pack_bf16_multi(const int64_t* desc_host, int64_t count, hipStream_t stream) {
@@ -871,7 +878,7 @@ extern "C" int osp_pack_bf16_multi(const int64_t* desc_host, int64_t count, hipS
             const int64_t* r = desc_host + 10 * i;
             const int k = (int)(i - lo);
             d.w[k] = (const float*)(intptr_t)r[0]; d.ks[k] = (const float*)(intptr_t)r[1]; d.out[k] = (unsigned short*)(intptr_t)r[2];
-            d.N[k] = (int)r[3]; d.taps[k] = (int)r[4]; d.K[k] = (int)r[5]; d.sN[k] = r[6]; d.sT[k] = r[7]; d.sK[k] = r[8];
+            d.N[k] = (int)r[3]; d.taps[k] = (int)r[4]; d.K[k] = (int)r[5]; d.sN[k] = r[6]; d.sT[k] = r[7]; d.sK[k] = r[8]; d.f32[k] = r[9] != 0;
             OSP_CHECK_ARG(d.w[k] && d.out[k] && d.N[k] > 0 && d.taps[k] > 0 && d.K[k] > 0, "bad descriptor");
             d.tk[k] = (d.K[k] + 31) / 32; d.tn[k] = (d.N[k] + 31) / 32;
             d.first[k] = blocks;

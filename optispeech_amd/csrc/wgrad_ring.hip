@@ -274,6 +274,161 @@ __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------ exact f32 (round 5)
+// The same plan for the exact-f32 weight gradients of the f32 / "mixed" parity modes (conv_wgrad_f32_kernel, gemm.hip: register-staged
+// 16-frame slabs, one __syncthreads() per slab, f32 atomics for the frame splits: 41 launches x 75 us = 3.1 ms of the mixed step).
+// f32 operands are staged as they lie by LDS-DMA (a row of 64 channels = 256 B, four rows per wave instruction, no swizzle: a
+// fragment read is 32 consecutive floats of one frame), products on v_mfma_f32_32x32x2_f32 whose operands ARE one element per
+// lane (A: dY[frame lh][channel l31], B: X[frame lh][channel l31]) -- no transposition anywhere.  64 x 64 tiles, four waves of
+// 32 x 32, 64-frame slabs, two stages (66 KB: two workgroups per CU).  The row factor `arow` (padding mask / DropPath) is staged
+// beside the slab and multiplied into the A operand; the bias gradient is a VALU sum of the same operand.
+template <bool AROW>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, float* __restrict__ ws) {
+    constexpr int T = 64, SK = 64, NI = SK / 16;            // pairs of DMA instructions per wave and slab
+    constexpr int STAGE = 2 * SK * T + SK;                   // floats of one stage: dY slab, X slab, row factors
+    float* smem = reinterpret_cast<float*>(wgr_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int ctiles = (p.Cin + T - 1) / T, ntiles = p.N / T, inner = p.taps * ctiles;
+    const int total = gridDim.x, lin = blockIdx.x, xcd = lin & 7, local = lin >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int pid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + local;
+    const int grp = pid / inner, within = pid - grp * inner;
+    const int zs = grp / ntiles, n0 = (grp - zs * ntiles) * T;
+    const int j = within / ctiles, c0 = (within - j * ctiles) * T;
+    const int bz = zs / p.splits, sp = zs - bz * p.splits;
+    const float* dY = reinterpret_cast<const float*>(p.dY) + (int64_t)bz * p.sYb;
+    const float* X = reinterpret_cast<const float*>(p.X) + (int64_t)bz * p.sXb;
+    const int mbeg = sp * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const bool do_bias = (p.db != nullptr) && (within == 0);
+    const bool bias_wave = __builtin_amdgcn_readfirstlane((int)(do_bias && wn0 == 0)) != 0;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const int srow = lane >> 4, lslot = lane & 15;
+    const int ldy32 = (int)p.ldy, ldx32 = (int)p.ldx;
+    const unsigned ycol4 = (unsigned)(n0 + lslot * 4) * 4u, xcol4 = (unsigned)(c0 + lslot * 4) * 4u;
+    const bool xcol_ok = c0 + lslot * 4 < p.Cin;
+    __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, (int)p.y_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AROW ? p.arow + (int64_t)bz * p.M : dY), 0,
+                                                                    AROW ? p.M * 4 : 0, 0x00020000);
+    auto issue_pair = [&](int mk, int buf, int i) {
+        float* ys = smem + buf * STAGE;
+        float* xs = ys + SK * T;
+        const int row0 = 4 * (NI * wave + i), m = mk + row0 + srow;
+        const bool mv = m < mend;
+        const unsigned yo = mv ? (unsigned)(m * ldy32) * 4u + ycol4 : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (__attribute__((address_space(3))) void*)(ys + row0 * T), 16, yo, 0, 0, 0);
+        const int u = fd_div(m, p.fd_trows), t = m - u * p.Trows, tt = t + j - p.pad;
+        const bool xv = mv && (unsigned)tt < (unsigned)p.Tin && xcol_ok;
+        const unsigned xo = xv ? (unsigned)((u * p.Tin + tt) * ldx32) * 4u + xcol4 : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(xs + row0 * T), 16, xo, 0, 0, 0);
+    };
+    auto issue_arow = [&](int mk, int buf) {               // the slab's 64 row factors, 4 bytes per lane (every wave: same bytes)
+        if constexpr (AROW) {
+            float* ar = smem + buf * STAGE + 2 * SK * T;
+            const int m = mk + lane;
+            const unsigned ao = m < mend ? (unsigned)m * 4u : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(asrd, (__attribute__((address_space(3))) void*)ar, 4, ao, 0, 0, 0);
+        }
+    };
+    // operands of frame pair kk of stage `buf` (inline asm: a builtin LDS read would make the compiler drain the DMA queue first)
+    auto lds_addr = [](const float* q) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)q; };
+    auto rd4 = [&](unsigned ya, unsigned xa, unsigned ra, auto gidx, float (&a)[4], float (&b)[4], float (&r)[4]) {
+        constexpr int G = decltype(gidx)::value;
+#define WGF_RD(Q)                                                                                                                  \
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[Q]) : "v"(ya), "n"((4 * G + Q) * 2 * T * 4) : "memory");             \
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[Q]) : "v"(xa), "n"((4 * G + Q) * 2 * T * 4) : "memory");             \
+        if constexpr (AROW) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r[Q]) : "v"(ra), "n"((4 * G + Q) * 8) : "memory");
+        WGF_RD(0) WGF_RD(1) WGF_RD(2) WGF_RD(3)
+#undef WGF_RD
+    };
+    auto wait4 = [](float (&a)[4], float (&b)[4], float (&r)[4], auto left) {
+        constexpr int LEFT = decltype(left)::value;
+        asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                     "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(LEFT) : "memory");
+    };
+    constexpr int RD = AROW ? 12 : 8;                        // LDS reads of one group of four frame pairs
+    auto mma = [&](int buf, int mk_next, int nxt) {
+        const float* ys = smem + buf * STAGE;
+        const unsigned ya = lds_addr(ys + lh * T + wm0 + l31), xa = lds_addr(ys + SK * T + lh * T + wn0 + l31);
+        const unsigned ra = lds_addr(ys + 2 * SK * T + lh);
+        float a[2][4], b[2][4], r[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { r[0][q] = 1.f; r[1][q] = 1.f; }
+        auto group = [&](auto gidx) {
+            constexpr int G = decltype(gidx)::value, cur = G & 1, oth = cur ^ 1;
+            if constexpr (G + 1 < SK / 8) rd4(ya, xa, ra, std::integral_constant<int, G + 1>{}, a[oth], b[oth], r[oth]);
+            if (mk_next >= 0) {
+                if constexpr (G < NI) issue_pair(mk_next, nxt, G);
+                if constexpr (G == NI) issue_arow(mk_next, nxt);
+            }
+            if constexpr (G + 1 < SK / 8) wait4(a[cur], b[cur], r[cur], std::integral_constant<int, RD>{});
+            else wait4(a[cur], b[cur], r[cur], std::integral_constant<int, 0>{});
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float av = AROW ? a[cur][q] * r[cur][q] : a[cur][q];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[cur][q], acc, 0, 0, 0);
+                if (bias_wave) bsum += av;
+            }
+        };
+        rd4(ya, xa, ra, std::integral_constant<int, 0>{}, a[0], b[0], r[0]);
+        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+        group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+    };
+    const int niter = (mend - mbeg + SK - 1) / SK;
+    if (niter > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_pair(mbeg, 0, i);
+        issue_arow(mbeg, 0);
+    }
+    for (int it = 0; it < niter; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // slab `it` has landed for every wave; stage (it + 1) & 1 is free (its reads were waited for)
+        asm volatile("" ::: "memory");
+        mma(it & 1, it + 1 < niter ? mbeg + (it + 1) * SK : -1, (it + 1) & 1);
+    }
+    // ---- epilogue (layouts of conv_wgrad_ring_kernel)
+    bsum += __shfl_xor(bsum, 32);
+    if (p.splits > 1) {
+        float* wb = ws + (int64_t)zs * wgr_block_elems(p.N, p.taps, p.Cin);
+        const int c = c0 + wn0 + l31;
+        if (c < p.Cin) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                wb[((int64_t)n * p.taps + j) * p.Cin + c] = acc[r];
+            }
+        }
+        if (do_bias && wn0 == 0 && lh == 0) wb[(int64_t)p.N * p.taps * p.Cin + n0 + wm0 + l31] = bsum;
+        return;
+    }
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+    const int c = c0 + wn0 + l31;
+    if (c < p.Cin) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            old[r] = dW[(int64_t)n * p.ldw + (int64_t)j * p.Cin + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            dW[(int64_t)n * p.ldw + (int64_t)j * p.Cin + c] = old[r] + (p.oscale ? p.oscale[n] : 1.f) * acc[r];
+        }
+    }
+    if (do_bias && wn0 == 0 && lh == 0) {
+        const int n = n0 + wm0 + l31;
+        p.db[(int64_t)bz * p.sDb + n] += (p.oscale ? p.oscale[n] : 1.f) * bsum;
+    }
+}
+
 // Launch plan.  Returns 1 when the ring kernel took the problem, 0 when it declines (the caller falls back to the kernels of
 // wgrad_bf16.hip).  `p` arrives filled in except chunk / splits / y_bytes / x_bytes.  ws may be null: then only problems that
 // need no split are taken.
@@ -335,4 +490,72 @@ int osp_launch_wgrad_ring(WgradB& p, int64_t batch, float* ws, int64_t ws_bytes,
                            (int)N, (long long)p.sWb, (long long)p.sDb);
     }
     return 1;
+}
+
+extern "C" int osp_conv_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T, int64_t N, int64_t Cin,
+                                  int64_t taps, int64_t pad, const float* arow, const float* oscale, float* dW, int64_t ldw, float* db,
+                                  int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb, hipStream_t stream);     // gemm.hip
+
+// Exact-f32 weight gradient with a caller-supplied split workspace (see osp_conv_wgrad_bf16_ws): the ring kernel above where its
+// conditions hold -- no atomics, bit-reproducible -- and osp_conv_wgrad_f32 (f32 atomics) otherwise.
+//   dW[n, j, c] += oscale[n] * sum_m arow[m] * dY[m, n] * X[m + j - pad, c],  db[n] += oscale[n] * sum_m arow[m] * dY[m, n]
+// Reference op: autograd of nn.Conv1d / nn.Linear (generator/modules/convnext.py:39-41, variance_predictor.py, alignments.py:55-64).
+extern "C" int osp_conv_wgrad_f32_ws(const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T, int64_t N,
+                                     int64_t Cin, int64_t taps, int64_t pad, const float* arow, const float* oscale, float* dW,
+                                     int64_t ldw, float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                     float* ws, int64_t ws_bytes, hipStream_t stream) {
+    OSP_CHECK_ARG(dY && X && dW, "null operand");
+    OSP_CHECK_ARG(batch > 0, "batch");
+    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && T > 0 && M % T == 0, "bad shape");
+    static int on = -1, tgt = 0;
+    if (on < 0) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ring_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 64 * 64 + 64) * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ring_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 64 * 64 + 64) * 4);
+        const char* e = getenv("OSP_WGRAD_RING_F32_TARGET"); tgt = e ? atoi(e) : 512;
+        e = getenv("OSP_WGRAD_RING_F32"); on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int64_t yb = ((M - 1) * ldy + N) * 4, xb = ((M - 1) * ldx + Cin) * 4;
+    bool take = on && N % 64 == 0 && Cin % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && al16(dY) && al16(X) && sYb % 4 == 0 && sXb % 4 == 0 &&
+                ldw % 4 == 0 && sWb % 4 == 0 && al16(dW) && ldw == taps * Cin && yb > 0 && xb > 0 && yb < (int64_t)0x7fffff00 &&
+                xb < (int64_t)0x7fffff00 && M * 4 < (int64_t)0x7fffff00;
+    int64_t sp = 1, ch = 0;
+    const int64_t tl = (N / 64) * taps * cdiv(Cin, 64) * batch;
+    if (take) {
+        const int64_t slabs = cdiv(M, 64);
+        sp = tl >= tgt ? 1 : (tgt + tl / 2) / tl;
+        if (sp > slabs / 4) sp = slabs / 4 > 0 ? slabs / 4 : 1;
+        const int64_t blk = wgr_block_elems(N, taps, Cin);
+        const int64_t cap = (ws && al16(ws)) ? ws_bytes / (blk * 4 * batch) : 1;
+        if (sp > cap) sp = cap;
+        if (sp < 1) sp = 1;
+        ch = cdiv(cdiv(M, sp), 64) * 64;
+        sp = cdiv(M, ch);
+        // a single split with very few tiles would leave the chip idle: the tile-per-tap kernel (atomics) then has more parallelism
+        if (sp == 1 && tl < 64 && M > 1024) take = false;
+    }
+    if (!take) return osp_conv_wgrad_f32(dY, ldy, X, ldx, M, T, N, Cin, taps, pad, arow, oscale, dW, ldw, db, batch, sYb, sXb, sWb, sDb, stream);
+    WgradB p;
+    p.dY = dY; p.y_bf16 = 0; p.ldy = ldy; p.X = X; p.x_bf16 = 0; p.ldx = ldx;
+    p.M = (int)M; p.Trows = (int)T; p.Tin = (int)T; p.N = (int)N; p.Cin = (int)Cin; p.taps = (int)taps; p.pad = (int)pad; p.x_step = 1;
+    p.Wrows = (int)T; p.Hin = 1; p.KW = (int)taps; p.x_step_h = 0; p.pad_h = 0;
+    p.fd_trows = make_fastdiv((unsigned)T); p.fd_wrows = make_fastdiv((unsigned)T);
+    p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db; p.chunk = (int)ch; p.splits = (int)sp;
+    p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb; p.y_bytes = (unsigned)yb; p.x_bytes = (unsigned)xb;
+    osp_note_symbol("conv_wgrad_ring_f32_kernel");
+    osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);
+    osp_note_bytes(4.0 * batch * ((double)M * N + (double)M * Cin + (double)N * taps * Cin));
+    const dim3 g((unsigned)(tl * sp));
+    constexpr int LDS = 2 * (2 * 64 * 64 + 64) * 4;
+    if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true>), g, dim3(256), LDS, stream, p, ws);
+    else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false>), g, dim3(256), LDS, stream, p, ws);
+    if (sp > 1) {
+        const int64_t blk = wgr_block_elems(N, taps, Cin);
+        const int64_t E = N * taps * Cin, K = taps * Cin, tot = db ? E + N : E;
+        hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3((unsigned)cdiv(tot, 1024), (unsigned)batch), dim3(256), 0, stream, ws, (int)sp,
+                           (long long)blk, (long long)E, (int)K, make_fastdiv((unsigned)(K / 4)), oscale, dW, (long long)ldw, db,
+                           (int)N, (long long)sWb, (long long)sDb);
+    }
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
 }

@@ -94,10 +94,10 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
              batch_strides[2], batch_strides[3], bool(accumulate))
         return out
     if (batch == 1 and w_param is not None and w_strides[2] != 1 and a.is_cuda and -(-M // 128) * -(-n_out // 64) >= 64
-            and not _tape_recording()):
+            and f32_packs_ok()):
         # exact-f32 modes: a k-strided view of a PARAMETER (the flipped-tap / transposed weights of an input-gradient conv) is
-        # gathered into a k-contiguous f32 pack once per optimizer epoch, so that the GEMM can take the direct-to-LDS kernel (only at
-        # sizes that kernel takes; the gather is a torch op: never while a call tape is being recorded)
+        # packed k-contiguous once per optimizer epoch, so that the GEMM can take the direct-to-LDS kernel (only at sizes that
+        # kernel takes)
         w, w_strides = _param_pack_f32(w_param, w, n_out, taps, cin, w_strides), (taps * cin, cin, 1)
     ldc = out.stride(-2) if ldc is None else ldc
     ld_aux = 0
@@ -118,47 +118,34 @@ def _tape_recording():
     return tape.recording() or torch.cuda.is_current_stream_capturing()
 
 
+_F32_PACKS_UNDER_TAPE = __import__('os').environ.get('OSP_F32_PACKS_UNDER_TAPE', '1') != '0'
+
+
 def f32_packs_ok():
-    return not _tape_recording()
-
-
-_F32_IDX = {}           # (device, offset, n_out, taps, cin, strides) -> gather index of an f32 pack
+    """f32 weight packs are made by the library (osp_pack_bf16_multi, out_f32 rows) into persistent buffers: a call tape can hold them.
+    Not inside a hipGraph capture (a pack refreshed there would be baked into the graph's first replay only)."""
+    if _F32_PACKS_UNDER_TAPE:
+        return not torch.cuda.is_current_stream_capturing()
+    return not _tape_recording()                  # OSP_F32_PACKS_UNDER_TAPE=0: round 4's rule (A/B runs)
 
 
 def _param_pack_f32(p, w, n_out, taps, cin, w_strides):
     """(n_out, taps, cin) f32 copy of the strided view ``w`` of Parameter ``p`` (element strides ``w_strides``, negative ones allowed),
-    cached on ``p`` for the current optimizer epoch (same invalidation rule as the bf16 packs); one torch gather per refresh."""
-    from . import values
-    off = (w.data_ptr() - p.data_ptr()) // 4
-    key = (off, n_out, taps, cin, tuple(w_strides))
-    stamp = (values.param_epoch(), p._version, p.data_ptr())
-    cache = getattr(p, "_osp_packs_f32", None)
-    if cache is None or cache[0] != stamp:
-        cache = (stamp, {})
-        p._osp_packs_f32 = cache
-    wp = cache[1].get(key)
-    if wp is None:
-        ik = (str(p.device),) + key
-        idx = _F32_IDX.get(ik)
-        if idx is None:
-            ar = lambda n: torch.arange(n, device=p.device, dtype=torch.int64)
-            idx = (off + ar(n_out)[:, None, None] * w_strides[0] + ar(taps)[None, :, None] * w_strides[1]
-                   + ar(cin)[None, None, :] * w_strides[2]).reshape(-1)
-            _F32_IDX[ik] = idx
-        wp = cache[1][key] = p.detach().reshape(-1)[idx].view(n_out, taps, cin)
-    return wp
+    cached on ``p`` for the current optimizer epoch: the same registry, buffers and multi launch as the bf16 packs (round 5; a torch
+    gather before, which no call tape could hold)."""
+    return _param_pack(p, w, n_out, taps, cin, w_strides, f32=True)
 
 
 _PACK_REG = {}          # (id(param), view key) -> (weakref(param), view key): every pack ever asked for through _param_pack
 
 
-def _param_pack(p, w, n_out, taps, cin, w_strides):
+def _param_pack(p, w, n_out, taps, cin, w_strides, f32=False):
     """(n_out, taps, cin) bf16 pack of the view ``w`` of Parameter ``p`` (element strides ``w_strides``), cached on ``p`` with the
     invalidation rule of param_bf16: optimizer epoch, in-place version, storage address.  A miss refreshes EVERY registered pack
     that is stale (all of them after an optimizer step) in one multi launch instead of one launch per weight and view."""
     import weakref
     from . import values
-    key = (w.data_ptr() - p.data_ptr(), n_out, taps, cin, tuple(w_strides))
+    key = (w.data_ptr() - p.data_ptr(), n_out, taps, cin, tuple(w_strides)) + (("f32",) if f32 else ())
     rk = (id(p), key)
     reg = _PACK_REG.get(rk)
     if reg is None or reg[0]() is not p:        # (id() of a collected Parameter is re-used: an entry with a dead weakref is not p's)
@@ -175,6 +162,7 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
         if cache is None or cache[0] != stamp:
             cache = (stamp, {})
             p._osp_packs = cache
+        assert not f32, "f32 packs are not made inside a hipGraph capture (f32_packs_ok)"
         wp = _persistent(p, "_osp_pack_bufs", key, (n_out, taps, cin), torch.bfloat16)
         call("osp_pack_bf16", w, None, wp, n_out, taps, cin, w_strides[0], w_strides[1], w_strides[2])
         cache[1][key] = wp
@@ -199,9 +187,10 @@ def _param_pack(p, w, n_out, taps, cin, w_strides):
             q._osp_packs = c2
         if k2 in c2[1]:
             continue
-        off, n2, t2, c_in, strd = k2
-        out = _persistent(q, "_osp_pack_bufs", k2, (n2, t2, c_in), torch.bfloat16)
-        rows.append([q.data_ptr() + off, 0, out.data_ptr(), n2, t2, c_in, strd[0], strd[1], strd[2], 0])
+        off, n2, t2, c_in, strd = k2[:5]
+        as_f32 = len(k2) > 5
+        out = _persistent(q, "_osp_pack_bufs", k2, (n2, t2, c_in), torch.float32 if as_f32 else torch.bfloat16)
+        rows.append([q.data_ptr() + off, 0, out.data_ptr(), n2, t2, c_in, strd[0], strd[1], strd[2], int(as_f32)])
         fills.append((c2[1], k2, out))
         _keep(q, out)
     for rk2 in dead:
@@ -252,8 +241,10 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
         call("osp_conv_wgrad_bf16", dy, 0, dy.stride(-2), x, 0, x.stride(-2), M, T, T, N, cin, taps, pad, 1, arow, oscale, dw,
              taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
         return
-    call("osp_conv_wgrad_f32", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
-         taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0)
+    # exact f32: the ring kernel with a split workspace where it applies (csrc/wgrad_ring.hip: no atomics), else the tile-per-tap kernel
+    ws = wgrad_workspace(N, taps, cin, batch, dy.device)
+    call("osp_conv_wgrad_f32_ws", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
+         taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0, ws, ws.numel())
 
 
 def dwconv7_ln_fwd(x, dw, dwb, lnw, lnb, eps, save, h_bf16=False):
@@ -1021,14 +1012,20 @@ def attn_softmax_fwd(S, klen, B, H, T1, T2, scale, drop_p=0.0, seed=0, stream_id
 def param_f32_t(p, kscale=None):
     """f32 transpose (K, N) of a 2-D f32 parameter (N, K), optionally with row n of p scaled by kscale[n] first -- the k-contiguous
     operand of an exact-f32 input-gradient GEMM (ConvNeXt block backward in the f32 / mixed modes).  Cached on the Parameter for the
-    current optimizer epoch like the bf16 packs; made with two torch ops (those modes are not the launch-count-critical ones)."""
+    current optimizer epoch like the bf16 packs and refreshed in place by the library (one osp_pack_bf16_multi row with out_f32 set:
+    tape-safe; two torch ops before round 5)."""
+    import numpy as np
     from . import values
     stamp = (values.param_epoch(), p._version, p.data_ptr(), None if kscale is None else (kscale.data_ptr(), kscale._version))
     key = "_osp_f32_t" if kscale is None else "_osp_f32_t_scaled"
     cache = getattr(p, key, None)
     if cache is None or cache[0] != stamp:
-        w = p.detach() if kscale is None else p.detach() * kscale.detach()[:, None]
-        cache = (stamp, w.t().contiguous())
+        N, Kd = p.shape
+        out = _persistent(p, "_osp_f32_t_bufs", key, (Kd, N), torch.float32)
+        row = [[p.data_ptr(), 0 if kscale is None else kscale.data_ptr(), out.data_ptr(), Kd, 1, N, 1, 0, Kd, 1]]
+        _keep(p, kscale, out)
+        call("osp_pack_bf16_multi", np.asarray(row, dtype=np.int64), 1)
+        cache = (stamp, out)
         setattr(p, key, cache)
     return cache[1]
 

@@ -91,3 +91,52 @@ def test_conv_wgrad_ring_pointwise_oscale_batch(M, N, C, taps, T):
                       strides=(M * N, M * C, N * taps * C, N))
     assert (dw.cpu().double() - want_w).abs().max().item() <= 2e-4 * want_w.abs().max().item()
     assert (db.cpu().double() - want_b).abs().max().item() <= 2e-4 * want_b.abs().max().item()
+
+
+def _f32(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * 0.5
+
+
+@pytest.mark.parametrize("M,N,C,taps,T,arow,batch", [
+    (2048, 384, 1152, 1, 2048, False, 1),          # vocoder pointwise pair
+    (4096, 256, 256, 5, 128, True, 1),             # variance-predictor conv with the padding mask as row factor
+    (1024, 128, 192, 3, 128, True, 2),             # a batch of two problems
+    (1600, 256, 100, 3, 800, False, 1),            # alignment feature conv: Cin = 100 (second channel tile reads zeros past 100)
+    (640, 64, 64, 1, 640, False, 1),               # one split, one workgroup per tile: adds straight into dW
+])
+def test_conv_wgrad_f32_ring_vs_f64(M, N, C, taps, T, arow, batch):
+    """Exact-f32 weight gradient on the ring kernel (conv_wgrad_ring_f32_kernel) against an f64 restatement; products are exact, sums
+    are f32: 2e-5 of the gradient's scale.  Two runs must agree bit for bit (no atomics); the call adds into dW / db."""
+    from optispeech_amd import kernels as K
+    dev = "cuda"
+    x, dy = _f32(batch, M, C, seed=11), _f32(batch, M, N, seed=12)
+    osc = torch.rand(N, generator=torch.Generator().manual_seed(13)) + 0.5
+    ar = (torch.rand(batch, M, generator=torch.Generator().manual_seed(14)) > 0.2).float() * 1.25 if arow else None
+    pad = taps // 2
+    xs = x.double().view(batch, M // T, T, C)
+    ys = dy.double().view(batch, M // T, T, N)
+    if ar is not None:
+        ys = ys * ar.double().view(batch, M // T, T, 1)
+    want_w = torch.zeros(batch, N, taps, C, dtype=torch.float64)
+    for j in range(taps):
+        sh = j - pad
+        lo, hi = max(0, -sh), min(T, T - sh)
+        want_w[:, :, j, :] = torch.einsum("butn,butc->bnc", ys[:, :, lo:hi], xs[:, :, lo + sh:hi + sh])
+    want_w *= osc.double()[None, :, None, None]
+    want_b = ys.sum((1, 2)) * osc.double()[None]
+    g = torch.Generator().manual_seed(15)
+    w0, b0 = torch.randn(batch, N, taps, C, generator=g), torch.randn(batch, N, generator=g)
+    outs = []
+    for _ in range(2):
+        dw, db = w0.to(dev).clone(), b0.to(dev).clone()
+        if batch == 1:
+            K.conv_wgrad(dy[0].to(dev), x[0].to(dev), dw, db, T=T, taps=taps, pad=pad, arow=None if ar is None else ar[0].to(dev), oscale=osc.to(dev))
+        else:
+            K.conv_wgrad(dy.to(dev), x.to(dev), dw, db, T=T, taps=taps, pad=pad, arow=None if ar is None else ar.to(dev), oscale=osc.to(dev),
+                         batch=batch)
+        outs.append((dw.cpu(), db.cpu()))
+    (dw, db), (dw2, db2) = outs
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "no atomics: two runs must agree bit for bit"
+    assert ((dw.double() - w0.double()) - want_w).abs().max().item() <= 2e-5 * want_w.abs().max().item() + 1e-6
+    assert ((db.double() - b0.double()) - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item() + 1e-6

@@ -17,6 +17,8 @@ REPLACES = {
     "osp_conv_wgrad_bf16": "weight gradients of the same, bf16 operands / f32 accumulate",
     "osp_conv_wgrad_bf16_ws": "the same weight gradients with a caller-supplied split workspace: no f32 atomics, bit-reproducible "
                               "(autograd of nn.Conv1d / nn.Linear: generator/modules/convnext.py:39-41)",
+    "osp_conv_wgrad_f32_ws": "exact-f32 weight gradients (the f32 / mixed parity modes) with a split workspace: no f32 atomics "
+                             "(autograd of nn.Conv1d / nn.Linear: generator/modules/convnext.py:39-41, generator/alignments.py:55-64)",
     "osp_conv2d_wgrad_bf16_ws": "autograd weight gradients of the DiscriminatorP / DiscriminatorR Conv2d stacks "
                                 "(vocoder/wavenext/disc/_discriminators.py:51-60,154-163) with a split workspace instead of atomics",
     "osp_dwconv7_ln_fwd": "ConvNeXtBlock.forward dwconv + LayerNorm: generator/modules/convnext.py:36-38",
