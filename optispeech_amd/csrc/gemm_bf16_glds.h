@@ -29,7 +29,8 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
     const GemmB pp = gemm_select_phase(pin, tc.z);
     constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
     constexpr int RA = BM_ / (8 * NW), RB = BN_ / (8 * NW), TM_ = BM_ / (32 * WM_), TN_ = BN_ / (32 * WN_);   // rows staged per thread (A, B); 32x32 tiles per wave
-    static_assert(TM_ == 2 || TM_ == 4, "wave tile is 64 or 128 rows");
+    static_assert(TM_ == 2 || TM_ == 4 || (TM_ == 1 && F32), "wave tile is 64 or 128 rows (32: the 64 x 64 exact-f32 tiles only)");
+    constexpr int TMA = TM_ < 2 ? 1 : 2;                                                          // 32-row blocks per accumulator array
     unsigned short* As = smem;                       // [NST][BM_][64]
     unsigned short* Bs = smem + NST * BM_ * TBK;     // [NST][BN_][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,9 +74,9 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
     }
     // accumulators as 64-row halves: the epilogue is instantiated per half with compile-time indices only (one 512-byte
     // array indexed through the epilogue's nested loops stayed a stack object and was stored to scratch every iteration)
-    f32x16 acc0[2][TN_], acc1[2][TN_];
+    f32x16 acc0[TMA][TN_], acc1[TMA][TN_];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMA; ++i)
 #pragma unroll
         for (int j = 0; j < TN_; ++j)
 #pragma unroll
@@ -145,7 +146,7 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
                 // of a slot, (k, k + 1) with k = 4 slot + 2 lh: the first MFMA contracts k = {4 slot, 4 slot + 2} (its k index IS the
                 // lane half), the second {4 slot + 1, 4 slot + 3} -- A and B fragments follow the same assignment, every k once.
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                static_assert(TM_ == 2, "f32 tiles: 64 rows per wave");
+                static_assert(TM_ <= 2, "f32 tiles: 32 or 64 rows per wave");
                 if (ld >= 0) issue_quarter(ld, ksidx);
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
@@ -163,7 +164,7 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
 #pragma unroll
                     for (int e = 0; e < 2; ++e)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < TMA; ++i)
 #pragma unroll
                             for (int j = 0; j < TN_; ++j)
                                 acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc0[i][j], 0, 0, 0);
@@ -192,7 +193,7 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
                 if (ld >= 0) issue_quarter(ld, ksidx);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TMA; ++i)
 #pragma unroll
                 for (int j = 0; j < TN_; ++j) {
                     acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc0[i][j], 0, 0, 0);
@@ -239,7 +240,8 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         __syncthreads();
     }
     constexpr int SP_ = 32 * TN_ + 8;
-    gemm_bf16_epilogue<2, TN_>(pp, acc0, m0, n0, wm0, wn0, lane, bz, smem + wave * (32 * TM_) * SP_);
+    // (wave-private staging: max(32 * TM_, 64) 16-bit rows = one 32-row block of f32)
+    gemm_bf16_epilogue<TMA, TN_>(pp, acc0, m0, n0, wm0, wn0, lane, bz, smem + wave * (TM_ < 2 ? 64 : 32 * TM_) * SP_);
     if constexpr (TM_ == 4) gemm_bf16_epilogue<2, TN_>(pp, acc1, m0, n0, wm0 + 64, wn0, lane, bz, smem + wave * (32 * TM_) * SP_ + 64 * SP_);
 }
 

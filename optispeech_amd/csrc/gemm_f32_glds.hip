@@ -15,6 +15,13 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_glds_n64_kernel(const GemmB
     conv_gemm_bf16_glds_body<128, 2, 64, 4, false, true>(pp, glds_smem, grid_tile_ctx());
 }
 
+// 64 x 64 tiles (four waves of 32 x 32, two 16 KB stages: five workgroups per CU), round 5: the generator's GEMMs at 2 048 - 4 096 rows are
+// 96 - 128 tiles of 128 x 64 -- a third of the CUs -- and the exact-f32 matrix pipe is 16x slower than the bf16 one, so what such a launch
+// costs is (tiles in flight) x (k-slabs), not bytes: four times the tiles at twice the operand traffic per flop
+__global__ __launch_bounds__(256) void conv_gemm_f32_glds_s64_kernel(const GemmB pp) {
+    conv_gemm_bf16_glds_body<64, 2, 64, 4, false, true>(pp, glds_smem, grid_tile_ctx());
+}
+
 // returns 1 when the launch was taken, 0 when the caller should use its own kernel, < 0 on a launch error
 int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
                           const float* a_rowscale, const float* B, int64_t sBn, int64_t sBtap, int64_t sBk, int64_t N, float* C,
@@ -31,7 +38,12 @@ int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int
     static int64_t tmin = -1;
     if (tmin < 0) { const char* e = getenv("OSP_GEMM_F32_DMA_MIN"); tmin = e ? atoi(e) : 64; }           // (measured: 10-18 % over the old kernel down to ~60 tiles, profiles/r04_gemm_f32_probe.txt)
     const bool wide = cdiv(M, 128) * cdiv(N, 128) * batch >= 192;
-    if (!wide && cdiv(M, 128) * cdiv(N, 64) * batch < tmin) return 0;
+    // 128 x 64 while those tiles fill the chip; below that 64 x 64 tiles (down to 32 of them)
+    static int64_t s64max = -1;
+    if (s64max < 0) { const char* e = getenv("OSP_GEMM_F32_S64_BELOW"); s64max = e ? atoi(e) : 384; }
+    const int64_t t64 = cdiv(M, 128) * cdiv(N, 64) * batch;
+    const bool small = !wide && t64 < s64max && cdiv(M, 64) * cdiv(N, 64) * batch >= 32;
+    if (!wide && !small && t64 < tmin) return 0;
     GemmB p;
     // global strides and extents of the two operands in 2-BYTE units (see the body): an f32 element is two of them
     p.A = A; p.a_bf16 = 0; p.lda = 2 * lda; p.M = (int)M; p.Trows = (int)T; p.Tin = (int)T; p.Cin = (int)(2 * Cin);
@@ -46,16 +58,19 @@ int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int
     p.Wrows = (int)T; p.Hin = 1; p.KW = (int)taps; p.a_step_h = 0; p.a_tapstep_h = 0; p.a_off_h = 0; p.Wc = (int)T; p.c_step_h = 0;
     p.c_off_h = 0; p.sBtap_h = 0;
     constexpr int LDS64 = 2 * (128 + 64) * TBK * 2;
+    constexpr int LDSS = 2 * (64 + 64) * TBK * 2;
     static int attr = 0;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_glds_n64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_glds_s64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
         attr = 1;
     }
     osp_note_symbol("conv_gemm_f32_glds_kernel");
     osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);
     osp_note_bytes(4.0 * batch * ((double)M * Cin + (double)N * taps * Cin + (double)M * N));
-    if (wide) hipLaunchKernelGGL(conv_gemm_f32_glds_kernel, dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch), dim3(256), GLDS_LDS, stream, p);
+    if (small) hipLaunchKernelGGL(conv_gemm_f32_glds_s64_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)batch), dim3(256), LDSS, stream, p);
+    else if (wide) hipLaunchKernelGGL(conv_gemm_f32_glds_kernel, dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch), dim3(256), GLDS_LDS, stream, p);
     else hipLaunchKernelGGL(conv_gemm_f32_glds_n64_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 128), (unsigned)batch), dim3(256), LDS64, stream, p);
     return hipGetLastError() == hipSuccess ? 1 : -1;
 }

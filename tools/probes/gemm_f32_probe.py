@@ -14,4 +14,4 @@ for (M, T, cin, taps, n) in [(8192, 128, 256, 1, 1024), (8192, 128, 1024, 1, 256
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 50
-    print(f"DMA={os.environ.get('OSP_GEMM_F32_DMA','1')} M={M} Cin={cin} taps={taps} N={n}: {us:.1f} us  {2.0*M*cin*taps*n/us/1e6:.1f} TFLOP/s", flush=True)
+    print(f"S64_BELOW={os.environ.get('OSP_GEMM_F32_S64_BELOW','384')} DMA={os.environ.get('OSP_GEMM_F32_DMA','1')} M={M} Cin={cin} taps={taps} N={n}: {us:.1f} us  {2.0*M*cin*taps*n/us/1e6:.1f} TFLOP/s", flush=True)

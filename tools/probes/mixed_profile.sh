@@ -8,5 +8,5 @@ f=glob.glob("/tmp/mp/**/mp_kernel_stats.csv", recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 print("kernel ms/step:", tot/13e6)
-for r in rows[:16]: print("%7.2f ms/step %4d x %7.1f us  %s" % (float(r["TotalDurationNs"])/13e6, int(r["Calls"])//13, float(r["AverageNs"])/1e3, r["Name"][:80]))
+for r in rows[:26]: print("%7.2f ms/step %4d x %7.1f us  %s" % (float(r["TotalDurationNs"])/13e6, int(r["Calls"])//13, float(r["AverageNs"])/1e3, r["Name"][:80]))
 PY
