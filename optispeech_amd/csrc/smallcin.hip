@@ -244,15 +244,27 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_mfma_kernel(SmallCin p) {
     constexpr int LD = NT * 32 + 8, CPR = NT * 4;                              // staged row pitch (bf16), 16-byte chunks per row
     unsigned short* dyl = dy_stage[wv];
     const int r16 = lane & 15, g16 = (lane >> 4) & 1;
+    // the dY rows of the wave's NEXT step are requested before this step's x gather and MFMAs (round 5: with one step in flight the
+    // loop was a chain of HBM latency + L2 latency + compute per 16 rows: 0.8 TB/s of dY)
+    constexpr int PER = 16 * CPR / 64;
+    uint4 nv[PER];
+    auto fetch = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = lane + 64 * i, rowl = c / CPR, cc = c - rowl * CPR, m = st * 16 + rowl;
+            nv[i] = make_uint4(0, 0, 0, 0);
+            if (st < nsteps && m < p.M) nv[i] = *reinterpret_cast<const uint4*>(dy + (int64_t)m * p.Cout + cc * 8);
+        }
+    };
+    fetch(blockIdx.x * 4 + wv);
     for (int step = blockIdx.x * 4 + wv; step < nsteps; step += nwaves) {
         const int ms = step * 16;
 #pragma unroll
-        for (int c = lane; c < 16 * CPR; c += 64) {
-            const int rowl = c / CPR, cc = c - rowl * CPR, m = ms + rowl;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < p.M) v = *reinterpret_cast<const uint4*>(dy + (int64_t)m * p.Cout + cc * 8);
-            *reinterpret_cast<uint4*>(dyl + rowl * LD + cc * 8) = v;
+        for (int i = 0; i < PER; ++i) {
+            const int c = lane + 64 * i, rowl = c / CPR, cc = c - rowl * CPR;
+            *reinterpret_cast<uint4*>(dyl + rowl * LD + cc * 8) = nv[i];
         }
+        fetch(step + nwaves);
         sc_bf16x8 a[TT], al[TT], b[NT];                                        // x as hi + lo bf16 halves (see the forward kernel)
 #pragma unroll
         for (int run = 0; run < 2; ++run) {
@@ -414,7 +426,7 @@ extern "C" int osp_smallcin_conv_wgrad(const float* x, const void* dy, int64_t y
     if (y_bf16 && (Cout == 32 || Cout == 64) && taps < 64 && !getenv("OSP_SMALLCIN_VALU")) {
         const int64_t steps = cdiv(M, 16), nb = cdiv(steps, 4 * 8);
         static int64_t wg_cap = 0;
-        if (!wg_cap) { wg_cap = 256; }
+        if (!wg_cap) { const char* e = getenv("OSP_SMALLCIN_WGS"); wg_cap = e ? atoi(e) : 512; }      // 256 / 512 / 1024: 87 / 61 / 69 us (profiles/r05_smallcin_wgs.txt)
         const dim3 grid((unsigned)(nb < wg_cap ? nb : wg_cap)), block(256);  // one atomic epilogue per block
         const int tt_ = taps < 32 ? 1 : 2, nt_ = Cout == 32 ? 1 : 2, E = tt_ * nt_ * 1024;
         if (ws && ws_floats >= (int64_t)grid.x * E) p.ws = ws;

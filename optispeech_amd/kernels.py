@@ -878,8 +878,11 @@ def smallcin_fwd(x, w, b, *, U, Hin, Win, Ho, Wo, cout, KH, KW, sh, sw, ph, pw, 
     return y
 
 
+_SMALLCIN_WGS = int(__import__('os').environ.get('OSP_SMALLCIN_WGS', '512'))      # workgroup cap of the MFMA weight-gradient kernel (csrc/smallcin.hip)
+
+
 def smallcin_wgrad(x, dy, dw, db, *, U, Hin, Win, Ho, Wo, cout, KH, KW, sh, sw, ph, pw):
-    ws = torch.empty((256 * 4096,), device=x.device, dtype=torch.float32) if _isbf(dy) else None     # two-stage reduction scratch (4 MB)
+    ws = torch.empty((_SMALLCIN_WGS * 4096,), device=x.device, dtype=torch.float32) if _isbf(dy) else None     # two-stage reduction scratch
     call("osp_smallcin_conv_wgrad", x, dy, _isbf(dy), dw, db, U * Ho * Wo, Ho * Wo, Wo, Hin, Win, cout, KH * KW, KW, sh, sw, ph,
          pw, ws, 0 if ws is None else ws.numel())
 
