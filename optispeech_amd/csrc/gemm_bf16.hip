@@ -444,7 +444,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         static int64_t w8_min = 0;
         if (w8 == -2) {
             const char* e = getenv("OSP_GEMM_W8"); w8 = e ? atoi(e) : -1;
-            w8_min = 160;
+            { const char* m = getenv("OSP_GEMM_W8_MIN"); w8_min = m ? atoi(m) : 160; }
         }
         const int64_t t256 = cdiv(M, 256) * cdiv(N, 256) * batch;
         // measured (tools/gemm_w8_probe.py, profiles/r02_gemm_w8_probe.txt): +23..30 % where the reduction is long (K >= 2560: the
