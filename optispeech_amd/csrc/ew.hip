@@ -13,6 +13,8 @@
 //   osp_transpose_last2  (B, R, C) -> (B, C, R)         mel (B, n_feats, T) -> frames (generator/__init__.py:122)
 //   osp_length_masks     keep[b, t] = t < len[b] as f32 and its complement as bool  (utils/model.py:12-16 sequence_mask)
 //   osp_sum_scaled       out[0] = scale * sum(x)        (.mean() of the per-utterance loss terms)
+//   osp_posenc_fwd / osp_posenc_dalpha   y = x + alpha * pe over the batch and d alpha = sum dy * pe  (_transformer/embedding.py:91-124)
+//   osp_permute_0213     (A, B, C, D) -> (A, C, B, D)   the head split / merge of the unfused attention path (attention.py:75-101)
 //   osp_dot_multi / osp_scale_vec   loss = sum_i c_i * term_i[0] and its backward (generator/__init__.py:175-181, disc/__init__.py:105-111)
 #include "osp_common.h"
 
@@ -229,6 +231,98 @@ extern "C" int osp_scale_vec(const float* g, const float* coeff_host, int64_t co
     a.n = (int)count;
     for (int i = 0; i < a.n; ++i) a.c[i] = coeff_host[i];
     hipLaunchKernelGGL(scale_vec_kernel, dim3(1), dim3(64), 0, stream, g, a, out);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------- scaled positional encoding
+// ScaledPositionalEncoding.forward (_transformer/embedding.py:120-124): y[b, i] = x[b, i] + alpha[0] * pe[i], i over the T * C
+// entries of the table's first T rows; alpha is a learnt DEVICE scalar (no host read).  The gradient w.r.t. x is dy itself; the
+// gradient w.r.t. alpha is sum_{b, i} dy[b, i] * pe[i]: stage 1 here writes one partial per workgroup (fixed grid, fixed order inside
+// a workgroup -> bit-reproducible), stage 2 is osp_sum_scaled over the partials.
+__global__ void posenc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ alpha,
+                                  float* __restrict__ y, int64_t total, int64_t n, int vec) {
+    const float a = alpha[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {                                                   // n % 4 == 0: a float4 stays inside one utterance
+        const int64_t t4 = total >> 2;
+        for (; i < t4; i += stride) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            const float4 pv = *reinterpret_cast<const float4*>(pe + ((i << 2) % n));
+            reinterpret_cast<float4*>(y)[i] = make_float4(fmaf(a, pv.x, xv.x), fmaf(a, pv.y, xv.y), fmaf(a, pv.z, xv.z), fmaf(a, pv.w, xv.w));
+        }
+        return;
+    }
+    for (; i < total; i += stride) y[i] = fmaf(a, pe[i % n], x[i]);
+}
+
+extern "C" int osp_posenc_fwd(const float* x, const float* pe, const float* alpha, float* y, int64_t B, int64_t n, hipStream_t stream) {
+    OSP_CHECK_ARG(x && pe && alpha && y && B > 0 && n > 0, "bad args");
+    const int64_t total = B * n;
+    const int vec = (n % 4 == 0) && al16(x) && al16(y) && al16(pe);
+    hipLaunchKernelGGL(posenc_fwd_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(256), 0, stream, x, pe, alpha, y, total, n, vec);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+__global__ __launch_bounds__(256) void posenc_dalpha_kernel(const float* __restrict__ dy, const float* __restrict__ pe,
+                                                            float* __restrict__ partials, int64_t total, int64_t n, int vec) {
+    __shared__ float red[256];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    if (vec) {
+        const int64_t t4 = total >> 2;
+        for (; i < t4; i += stride) {
+            const float4 g = reinterpret_cast<const float4*>(dy)[i];
+            const float4 pv = *reinterpret_cast<const float4*>(pe + ((i << 2) % n));
+            s += g.x * pv.x + g.y * pv.y + g.z * pv.z + g.w * pv.w;
+        }
+    } else {
+        for (; i < total; i += stride) s += dy[i] * pe[i % n];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// partials: nparts floats, one per workgroup (the caller sums them: osp_sum_scaled)
+extern "C" int osp_posenc_dalpha(const float* dy, const float* pe, int64_t B, int64_t n, float* partials, int64_t nparts,
+                                 hipStream_t stream) {
+    OSP_CHECK_ARG(dy && pe && partials && B > 0 && n > 0 && nparts > 0 && nparts <= 4096, "bad args");
+    const int64_t total = B * n;
+    const int vec = (n % 4 == 0) && al16(dy) && al16(pe);
+    hipLaunchKernelGGL(posenc_dalpha_kernel, dim3((unsigned)nparts), dim3(256), 0, stream, dy, pe, partials, total, n, vec);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- (A, B, C, D) -> (A, C, B, D)
+// y[a, c, b, :] = x[a, b, c, :] for contiguous f32 tensors with D % 4 == 0: rows of D floats move as 16-byte chunks, consecutive
+// lanes walk a destination row and then the next one (stores fully coalesced, loads coalesced per row of D).
+__global__ void permute_0213_kernel(const float4* __restrict__ x, float4* __restrict__ y, int64_t total4, int Bd, int Cd, int D4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total4; o += stride) {
+        const int d = (int)(o % D4);
+        int64_t r = o / D4;                                      // destination row index (a, c, b)
+        const int b = (int)(r % Bd); r /= Bd;
+        const int c = (int)(r % Cd); const int64_t a = r / Cd;
+        y[o] = x[((a * Bd + b) * Cd + c) * D4 + d];
+    }
+}
+
+extern "C" int osp_permute_0213(const float* x, float* y, int64_t A, int64_t B, int64_t C, int64_t D, hipStream_t stream) {
+    OSP_CHECK_ARG(x && y && A > 0 && B > 0 && C > 0 && D > 0 && D % 4 == 0, "D must be a positive multiple of 4");
+    OSP_CHECK_ARG(al16(x) && al16(y) && B < (1ll << 31) && C < (1ll << 31) && D < (1ll << 31), "operands must be 16-byte aligned");
+    const int64_t total4 = A * B * C * (D / 4);
+    hipLaunchKernelGGL(permute_0213_kernel, dim3(ew_grid(total4)), dim3(256), 0, stream, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<float4*>(y), total4, (int)B, (int)C, (int)(D / 4));
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

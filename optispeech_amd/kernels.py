@@ -972,6 +972,36 @@ def length_masks(lengths, T):
     return pad, keep
 
 
+def posenc_fwd(x, pe, alpha):
+    """x (B, T, C) + alpha[0] * pe (T, C) over the batch (_transformer/embedding.py:120-124); alpha: device scalar."""
+    _f32(x, pe, alpha)
+    B, T, C = x.shape
+    assert x.is_contiguous() and pe.is_contiguous() and tuple(pe.shape) == (T, C) and alpha.numel() == 1
+    y = torch.empty_like(x)
+    call("osp_posenc_fwd", x, pe, alpha, y, B, T * C)
+    return y
+
+
+def posenc_dalpha(dy, pe, nparts=128):
+    """sum_{b, t, c} dy[b, t, c] * pe[t, c] as a 0-dim tensor: one partial per workgroup, then osp_sum_scaled (fixed order)."""
+    _f32(dy, pe)
+    B, T, C = dy.shape
+    assert dy.is_contiguous() and pe.is_contiguous() and tuple(pe.shape) == (T, C)
+    parts = torch.empty((nparts,), device=dy.device, dtype=torch.float32)
+    call("osp_posenc_dalpha", dy, pe, B, T * C, parts, nparts)
+    return sum_scaled(parts, 1.0)
+
+
+def permute_0213(x):
+    """(A, B, C, D) contiguous f32 -> (A, C, B, D) contiguous: x.transpose(1, 2).contiguous() in one launch of ours."""
+    _f32(x)
+    A, B_, C, D = x.shape
+    assert x.is_contiguous() and D % 4 == 0
+    y = torch.empty((A, C, B_, D), device=x.device, dtype=torch.float32)
+    call("osp_permute_0213", x, y, A, B_, C, D)
+    return y
+
+
 def sum_scaled(x, scale):
     """scale * sum(x) as a 0-dim f32 tensor (small vectors: one workgroup, deterministic order)."""
     _f32(x)

@@ -24,6 +24,7 @@ def padding_mask(lengths, T):
     pad, keep = K.length_masks(lengths.contiguous(), int(T))
     try:
         pad._osp_rowmask = ((-1 if pad.is_inference() else pad._version, torch.cuda.is_current_stream_capturing()), keep)
+        pad._osp_lengths = (-1 if pad.is_inference() else pad._version, lengths)      # the Transformer backbone's valid-key counts
     except (AttributeError, RuntimeError):
         pass
     return pad

@@ -6,7 +6,7 @@ Same class names and state-dict keys (``transformer.embed.0.alpha``, ``transform
 feed_forward.w_*, norm1, norm2}``, ``transformer.after_norm``); pre-LN, 2 heads, conv1d-k1 feed-forward, scaled positional
 encoding -- the configuration of configs/model/generator/{encoder,decoder}/transformer.yaml.  Arithmetic: LayerNorm /
 linear layers / attention GEMMs and the masked softmax run in the HIP kernels (ops.layer_norm, ops.conv_linear,
-ops.AttentionFn); residual adds, the positional table and the Philox dropout masks are element-wise torch glue.
+ops.AttentionFn); dropout (+ residual) on osp_dropout_add, the scaled positional encoding on osp_posenc_fwd.
 """
 import math
 
@@ -47,35 +47,45 @@ class _Conv1dK1(RefSchemaModule):
         return ops.conv_linear(x, self.weight, self.bias, self.weight.shape[0], 1, 0, act)
 
 
-def _dropout(x, p, training, stream_id):
-    if not training or p <= 0.0:
-        return x
-    B, T, C = x.shape
-    return x * ops.dropout_mask((B * T, C), p, rng.seed(), stream_id, x.device).view(B, T, C)
+def _dropout(x, p, training, stream_id, res=None):
+    """res + F.dropout(x): one launch of the counter-based dropout kernel (osp_dropout_add), the same kernel on the gradient in the
+    backward.  (Through round 5 every site materialised a keep mask -- three fills, a LayerNorm launch and an ATen multiply per site,
+    26 sites per forward -- with the same Philox counters: the values are bit-identical.)"""
+    return ops.dropout_add(x, p, training, stream_id, res=res)
 
 
 class ScaledPositionalEncoding(nn.Module):
-    """_transformer/embedding.py:91-124: x + alpha * pe, then dropout."""
+    """_transformer/embedding.py:91-124: x + alpha * pe, then dropout.  The table is a non-persistent buffer (it moves with the module
+    and never enters a state dict, like the reference's ``self.pe``); on the GPU the sum is one launch that reads alpha on the
+    device (ops.ScaledPosEncFn), so a call tape can hold the whole forward."""
 
     def __init__(self, d_model, dropout_rate, max_len=5000):
         super().__init__()
         self.d_model, self.dropout_rate = d_model, dropout_rate
         self.alpha = nn.Parameter(torch.tensor(1.0))
-        self._pe = None
+        self.register_buffer("_pe", self._table(max_len), persistent=False)
         self._stream = rng.new_stream()
 
+    def _table(self, rows):
+        pos = torch.arange(0, rows, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / self.d_model))
+        pe = torch.zeros(rows, self.d_model)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe
+
     def pe(self, T, device):
-        if self._pe is None or self._pe.shape[0] < T or self._pe.device != device:
-            pos = torch.arange(0, max(T, 1024), dtype=torch.float32).unsqueeze(1)
-            div = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / self.d_model))
-            pe = torch.zeros(pos.shape[0], self.d_model)
-            pe[:, 0::2] = torch.sin(pos * div)
-            pe[:, 1::2] = torch.cos(pos * div)
-            self._pe = pe.to(device)
+        if self._pe.shape[0] < T or self._pe.device != device:        # extend_pe (embedding.py:58-77)
+            self._pe = self._table(max(T, self._pe.shape[0])).to(device)
         return self._pe[:T]
 
     def forward(self, x):
-        return _dropout(x + self.alpha * self.pe(x.shape[1], x.device), self.dropout_rate, self.training, self._stream)
+        pe = self.pe(x.shape[1], x.device)
+        if x.is_cuda and x.dtype == torch.float32:
+            y = ops.ScaledPosEncFn.apply(x, self.alpha, pe)
+        else:
+            y = x + self.alpha * pe
+        return _dropout(y, self.dropout_rate, self.training, self._stream)
 
 
 class MultiHeadedAttention(nn.Module):
@@ -120,8 +130,8 @@ class EncoderLayer(nn.Module):
         self._s1, self._s2 = rng.new_stream(), rng.new_stream()
 
     def forward(self, x, klen):
-        x = x + _dropout(self.self_attn(self.norm1(x), klen), self.dropout_rate, self.training, self._s1)
-        return x + _dropout(self.feed_forward(self.norm2(x)), self.dropout_rate, self.training, self._s2)
+        x = _dropout(self.self_attn(self.norm1(x), klen), self.dropout_rate, self.training, self._s1, res=x)
+        return _dropout(self.feed_forward(self.norm2(x)), self.dropout_rate, self.training, self._s2, res=x)
 
 
 class Encoder(nn.Module):
@@ -160,5 +170,11 @@ class Transformer(nn.Module):
             self.transformer.embed[-1].alpha.fill_(init_alpha)
 
     def forward(self, x, padding_mask):
-        klen = (~padding_mask).sum(1).to(torch.int64)            # mask = ~padding_mask (prefix-valid, as sequence_mask builds it)
+        # mask = ~padding_mask (prefix-valid, as sequence_mask builds it): the valid-key counts are the lengths the mask was built
+        # from when the generator built it (generator.padding_mask leaves them on the tensor), a row sum otherwise
+        tag = getattr(padding_mask, "_osp_lengths", None)
+        if tag is not None and tag[0] == (-1 if padding_mask.is_inference() else padding_mask._version) and tag[1].is_cuda == x.is_cuda:
+            klen = tag[1]
+        else:
+            klen = (~padding_mask).sum(1).to(torch.int64)
         return self.transformer(x, klen)

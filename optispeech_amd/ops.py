@@ -822,7 +822,10 @@ class AttentionFn(torch.autograd.Function):
                 ctx.fused = True
                 ctx.bias_shape = None if sbias is None else sbias.shape
             return o
-        heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)      # noqa: E731
+        if q.is_cuda and dk % 4 == 0:                            # head split / merge as launches of ours (a call tape can hold them)
+            heads = lambda t: K.permute_0213(t.contiguous().view(B, T, H, dk)).view(Z, T, dk)     # noqa: E731
+        else:
+            heads = lambda t: t.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)      # noqa: E731
         qh, kh, vh = heads(q), heads(k), heads(v)
         scale = 1.0 / float(dk) ** 0.5
         S = K.conv_gemm(qh, kh, T, cin=dk, w_strides=(dk, 0, 1), batch=Z, batch_strides=(T * dk, T * dk, T * T, 0))
@@ -834,6 +837,8 @@ class AttentionFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[:3]) or (sbias is not None and ctx.needs_input_grad[8]):
             ctx.save_for_backward(qh, kh, vh, P, Pd)
             ctx.cfg = (B, T, H, dk, scale, drop_p, seed, stream_id)
+        if O.is_cuda and dk % 4 == 0:
+            return K.permute_0213(O.view(B, H, T, dk)).view(B, T, C)
         return O.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, C)
 
     @staticmethod
@@ -850,7 +855,8 @@ class AttentionFn(torch.autograd.Function):
         qh, kh, vh, P, Pd = ctx.saved_tensors
         B, T, H, dk, scale, drop_p, seed, stream_id = ctx.cfg
         Z = B * H
-        dO = dout.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous().view(Z, T, dk)
+        gpu = dout.is_cuda and dk % 4 == 0
+        dO = (K.permute_0213(dout.contiguous().view(B, T, H, dk)) if gpu else dout.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous()).view(Z, T, dk)
         dPd = K.conv_gemm(dO, vh, T, cin=dk, w_strides=(dk, 0, 1), batch=Z, batch_strides=(T * dk, T * dk, T * T, 0))
         dV = torch.zeros((Z, T, dk), device=dout.device, dtype=torch.float32)
         K.conv_wgrad(Pd, dO, dV, None, batch=Z)                          # dV[t2, d] = sum_t1 Pd[t1, t2] dO[t1, d]
@@ -858,8 +864,32 @@ class AttentionFn(torch.autograd.Function):
         dQ = K.conv_gemm(dS, kh, dk, cin=T, w_strides=(1, 0, dk), batch=Z, batch_strides=(T * T, T * dk, T * dk, 0))
         dKh = torch.zeros((Z, T, dk), device=dout.device, dtype=torch.float32)
         K.conv_wgrad(dS, qh, dKh, None, batch=Z)                         # dK[t2, d] = sum_t1 dS[t1, t2] q[t1, d]
-        back = lambda t: t.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, H * dk)              # noqa: E731
+        if gpu:
+            back = lambda t: K.permute_0213(t.view(B, H, T, dk)).view(B, T, H * dk)                 # noqa: E731
+        else:
+            back = lambda t: t.view(B, H, T, dk).permute(0, 2, 1, 3).reshape(B, T, H * dk)          # noqa: E731
         return back(dQ), back(dKh), back(dV), None, None, None, None, None, (dS if ctx.has_bias else None)
+
+
+@_grad_aware
+class ScaledPosEncFn(torch.autograd.Function):
+    """x + alpha * pe[:T] over the batch (ScaledPositionalEncoding, _transformer/embedding.py:120-124) with alpha read on the device.
+    dx = dy; d alpha = sum dy * pe (two small launches, fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, pe):
+        x = x.contiguous()
+        if ctx.needs_input_grad[1]:
+            ctx.save_for_backward(pe)
+        return K.posenc_fwd(x, pe, alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dalpha = None
+        if ctx.needs_input_grad[1]:
+            (pe,) = ctx.saved_tensors
+            dalpha = K.posenc_dalpha(dy.contiguous(), pe)
+        return (dy if ctx.needs_input_grad[0] else None), dalpha, None
 
 
 class BatchedNTFn(torch.autograd.Function):

@@ -121,8 +121,11 @@ def _train(tapes, steps=4, pipeline=True, segments=False):
         precision.set_precision("f32")
 
 
-def test_taped_segments_on_changing_ragged_batches_equal_eager():
-    """A taped generator segment replayed on ANOTHER ragged batch of the same padded shape (what real training does every step; the
+@pytest.mark.parametrize("backbone", ["convnext", "transformer"])
+def test_taped_segments_on_changing_ragged_batches_equal_eager(backbone):
+    """(transformer: the Transformer-backbone acoustic model is a recordable region since the scaled positional encoding, the head
+    split / merge and the dropout sites are launches of ours -- ops.ScaledPosEncFn, osp_permute_0213, osp_dropout_add.)
+    A taped generator segment replayed on ANOTHER ragged batch of the same padded shape (what real training does every step; the
     benchmark re-uses one batch and cannot see it).  Round 5 found the backward tape reading the recording step's token ids and
     lengths (they were not declared inputs of the backward region): 2.5e-2 wrong acoustic-model gradients.  Steps: batch 0
     (records), 1, 1, 0 without an optimizer update; gradients of both networks, taped vs eager, to the tolerance of two eager
@@ -137,7 +140,8 @@ def test_taped_segments_on_changing_ragged_batches_equal_eager():
         tape.ENABLED = tapes
         c = S.SMALL
         cfg = ModelConfig(dim=c.dim, enc_inter=c.enc_inter, dec_inter=c.dec_inter, dur=c.dur + (0.0,), pitch=c.pitch + (0.0,),
-                          energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers).no_dropout()
+                          energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers,
+                          backbone=backbone).no_dropout()
         torch.manual_seed(7); rng.manual_seed(7, 0)
         m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
         m.tape_segments = True

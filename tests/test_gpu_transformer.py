@@ -281,3 +281,54 @@ def test_attention_function_with_score_term_fused_vs_unfused():
     finally:
         ops._FUSED_ATTN_TRAIN = keep
         precision.set_precision("f32")
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 37, 64), (2, 130, 256), (1, 5, 6)])
+def test_scaled_posenc_forward_backward_vs_torch(B, T, C):
+    """ops.ScaledPosEncFn (osp_posenc_fwd / osp_posenc_dalpha) vs `x + alpha * pe` and its autograd (embedding.py:120-124); C = 6
+    takes the scalar path of both kernels.  dx is dy itself; d alpha to f32 summation noise, twice the same bits."""
+    from optispeech_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + T)
+    x = torch.randn(B, T, C, device=DEV, generator=g)
+    pe = torch.randn(T, C, device=DEV, generator=g)
+    G = torch.randn(B, T, C, device=DEV, generator=g)
+    outs = []
+    for fn in (lambda x_, a_: ops.ScaledPosEncFn.apply(x_, a_, pe), lambda x_, a_: x_ + a_ * pe):
+        xx = x.clone().requires_grad_(True)
+        al = torch.tensor(0.7, device=DEV, requires_grad=True)
+        y = fn(xx, al)
+        (y * G).sum().backward()
+        outs.append((y.detach(), xx.grad, al.grad))
+    (y, dx, da), (yr, dxr, dar) = outs
+    assert da.shape == dar.shape
+    assert (y - yr).abs().max().item() <= 1e-6 * max(1.0, yr.abs().max().item())
+    assert torch.equal(dx, dxr)
+    assert abs(da.item() - dar.item()) <= 1e-4 * max(1.0, abs(dar.item()))
+    xx = x.clone().requires_grad_(True)
+    al = torch.tensor(0.7, device=DEV, requires_grad=True)
+    (ops.ScaledPosEncFn.apply(xx, al, pe) * G).sum().backward()
+    assert torch.equal(al.grad, da)                              # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 3, 16), (32, 128, 2, 128), (1, 1, 5, 4)])
+def test_permute_0213_vs_torch(shape):
+    """osp_permute_0213 == x.transpose(1, 2).contiguous() (the head split / merge of attention.py:59-66,99-101), both directions"""
+    from optispeech_amd import kernels as K
+    x = torch.randn(*shape, device=DEV)
+    y = K.permute_0213(x)
+    assert torch.equal(y, x.transpose(1, 2).contiguous())
+    assert torch.equal(K.permute_0213(y), x)
+
+
+def test_transformer_dropout_sites_use_the_documented_philox_counters():
+    """_dropout (osp_dropout_add) == x * keep-mask of the same (seed, stream) + residual, bit for bit: the mask a LayerNorm launch
+    with drop_p materialises (ops.dropout_mask) uses counter = element index / 4 as well."""
+    from optispeech_amd import ops, rng
+    from optispeech_amd.model.transformer import _dropout
+    rng.manual_seed(11, 0)
+    x = torch.randn(4, 50, 64, device=DEV)
+    res = torch.randn(4, 50, 64, device=DEV)
+    y = _dropout(x, 0.2, True, 5, res=res)
+    mask = ops.dropout_mask((200, 64), 0.2, rng.seed(), 5, DEV).view(4, 50, 64)
+    assert torch.equal(y, res + x * mask)
+    assert 0.1 < (mask == 0).float().mean().item() < 0.3

@@ -122,6 +122,10 @@ REPLACES = {
     "osp_ew_relu_mask": "autograd of nn.ReLU after nn.Conv1d: modules/core.py:66-71",
     "osp_transpose_last2": "mel.transpose(1, 2) of OptiSpeechGenerator.forward: generator/__init__.py:122",
     "osp_length_masks": "sequence_mask + padding masks: utils/model.py:12-16, generator/__init__.py:96-103",
+    "osp_posenc_fwd": "ScaledPositionalEncoding.forward `x + alpha * pe`: generator/modules/_transformer/embedding.py:120-124",
+    "osp_posenc_dalpha": "autograd of the same w.r.t. alpha (stage 1: one partial per workgroup; stage 2 = osp_sum_scaled)",
+    "osp_permute_0213": "the head split / merge `.view(B, T, h, d_k).transpose(1, 2)` (+ .contiguous()) of MultiHeadedAttention: "
+                        "generator/modules/_transformer/attention.py:59-66,99-101",
     "osp_sum_scaled": "torch.mean over the per-utterance loss terms: generator/loss.py:190-193, alignments.py:236-238",
     "osp_dot_multi": "weighted loss sums: generator/__init__.py:175-181, vocoder/wavenext/disc/__init__.py:105-111",
     "osp_scale_vec": "autograd of the weighted loss sums",

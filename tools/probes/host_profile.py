@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Host (enqueue) cost of the training step on a tiny batch (the GPU is never the bound) + cProfile of 20 steps.
-Env: the schedule knobs of the library (OSP_TAPE_SEGMENTS, OSP_TAPES, ...), PROFILE=0 to skip cProfile."""
+Env: BACKBONE=transformer for configs[3]; the schedule knobs of the library (OSP_TAPE_SEGMENTS, OSP_TAPES, ...), PROFILE=0 to skip cProfile."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from optispeech_amd import precision, rng, _lib
 from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
 precision.set_precision("bf16")
 torch.manual_seed(0); rng.manual_seed(0, 0)
-cfg = ModelConfig()
+cfg = ModelConfig(backbone=os.environ["BACKBONE"]) if os.environ.get("BACKBONE") else ModelConfig()
 m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to("cuda").train()
 m.pipeline_steps = True
 batch = synthetic_batch(2, 16, 72, cfg, seed=1, device="cuda")

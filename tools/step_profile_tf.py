@@ -11,6 +11,7 @@ cfg = ModelConfig(backbone="transformer")
 m = make_optispeech(cfg, batch_size=32, pretraining_steps=0).to("cuda").train()
 batch = synthetic_batch(32, 128, 800, cfg, seed=1234, device="cuda")
 m.optimizers()
+m.pipeline_steps = os.environ.get("PIPELINE", "1") == "1"
 n = int(os.environ.get("STEPS", "10"))
 import time
 for i in range(3):
