@@ -315,7 +315,7 @@ def synthesise_rtf(model, dev, n_sent=64, seed=7, timer=None, cpu=True, cpu_sent
     o, oe = res[True], res[False]
     same = bool(torch.equal(torch.as_tensor(o.wav), torch.as_tensor(oe.wav)))
     audio_s = float(o.wav_lengths.sum()) / model.sample_rate
-    return {"decode": "hipGraph-captured (upsampler + decoder graph, vocoder graph; eager text encoder / predictors / one length sync)",
+    return {"decode": "hipGraph-captured (text encoder + predictors graph, one length sync, upsampler + decoder graph, vocoder graph)",
             "eager": {"rtf": oe.rtf, "latency_ms": oe.latency}, "graph_output_equals_eager": same,
             "rtf": o.rtf, "am_rtf": o.am_rtf, "v_rtf": o.v_rtf, "latency_ms": o.latency, "sentences": n_sent,
             "padded_audio_s": o.wav.shape[-1] / model.sample_rate, "total_audio_s": audio_s,

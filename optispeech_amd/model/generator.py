@@ -75,6 +75,10 @@ class OptiSpeechGenerator(nn.Module):
         #: synthesise(): replay the shape-static part (upsampler, decoder, vocoder) from captured hipGraphs
         self.graph_decode = __import__("os").environ.get("OSP_GRAPH_DECODE", "0") == "1"
         self._decode_graphs = {}
+        #: with graph_decode: the shape-static part BEFORE the length sync (text encoder, predictors, length sums) replays from a
+        #: captured hipGraph as well (OSP_GRAPH_ENCODE=0: eager launches there, the round-4 schedule)
+        self.graph_encode = __import__("os").environ.get("OSP_GRAPH_ENCODE", "1") == "1"
+        self._encode_graphs = {}
 
     # ------------------------------------------------------------------------------------------ training forward
     def forward(self, x, x_lengths, mel, mel_lengths, pitches, energies, sids, lids):
@@ -206,13 +210,17 @@ class OptiSpeechGenerator(nn.Module):
         am_t0 = perf_counter()
         x_lengths = x_lengths.to(dev).contiguous()
         Tt = x.shape[1]
+        if self.graph_decode and self.graph_encode and x.is_cuda:          # the captured encode builds its own mask / precision scope
+            return self._synthesise_body(x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0, None)
         input_padding_mask = padding_mask(x_lengths, Tt)
         with precision.index_path():        # durations are integers: their inputs stay exact-f32 in every mode
             return self._synthesise_body(x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0,
                                          input_padding_mask)
 
-    def _synthesise_body(self, x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0,
-                         input_padding_mask):
+    def _encode(self, x, x_lengths, input_padding_mask, sids, lids, d_factor, p_factor, e_factor, durations_override):
+        """generator/__init__.py:229-258: text encoder, speaker / language embeddings, the three predictors and the frame counts.
+        No host reads; called inside ``precision.index_path()`` (the durations' inputs stay exact-f32 in every mode)."""
+        dev = x.device
         h, _ = self.text_embedding(x)                                       # :229
         h = self.encoder(h, input_padding_mask)                             # :232
         if (self.num_speakers > 1) and sids is None:
@@ -230,8 +238,67 @@ class OptiSpeechGenerator(nn.Module):
         h, pitch = self.pitch_predictor.infer(h, input_padding_mask, p_factor)              # :252
         h, energy = self.energy_predictor.infer(h, input_padding_mask, e_factor)            # :254
         y_lengths = durations.sum(dim=1)                                                    # :258
-        y_max_length = int(y_lengths.max())                                                 # data-dependent shape: 1 sync
-        if int(durations.sum()) == 0:                                                       # alignments.py:152-157
+        return h, durations, pitch, energy, y_lengths
+
+    def _graphed_encode(self, x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev):
+        """_encode replayed from a hipGraph captured per (B, T_text, which optional inputs exist, the three factors, precision): the
+        ~60 small launches before the length sync cost their GPU time instead of an interpreter round trip each.  Returns _encode's
+        tensors (graph-owned buffers, valid until the next replay of the same graph) and (max frame count, total frame count) from ONE
+        host read."""
+        key = (tuple(x.shape), sids is not None, lids is not None, float(d_factor), float(p_factor), float(e_factor),
+               durations_override is not None, precision.get_precision())
+        ent = self._encode_graphs.get(key)
+        Tt = x.shape[1]
+        if ent is None:
+            if len(self._encode_graphs) >= 8:
+                self._encode_graphs.pop(next(iter(self._encode_graphs)))
+            st = {"x": x.clone(), "xl": x_lengths.clone(), "sids": None if sids is None else sids.to(dev).clone(),
+                  "lids": None if lids is None else lids.to(dev).clone(),
+                  "do": None if durations_override is None else durations_override.to(dev).clone()}
+
+            def enc():
+                mask = padding_mask(st["xl"], Tt)
+                with precision.index_path():
+                    h, d, p, e, yl = self._encode(st["x"], st["xl"], mask, st["sids"], st["lids"], d_factor, p_factor, e_factor, st["do"])
+                return h, d, p, e, yl, torch.stack([yl.max(), d.sum()])
+
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):                                  # warm-up: allocator pools, weight packs, kernel attributes
+                    enc()
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g_enc = torch.cuda.CUDAGraph()
+            from ..graphs import no_gc_during_capture
+            with no_gc_during_capture(), torch.cuda.graph(g_enc, capture_error_mode="thread_local"):
+                st["out"] = enc()
+            ent = self._encode_graphs[key] = (st, g_enc)
+        st, g_enc = ent
+        st["x"].copy_(x); st["xl"].copy_(x_lengths)
+        if sids is not None:
+            st["sids"].copy_(sids)
+        if lids is not None:
+            st["lids"].copy_(lids)
+        if durations_override is not None:
+            st["do"].copy_(durations_override)
+        g_enc.replay()
+        h, d, p, e, yl, stats = st["out"]
+        y_max, total = stats.tolist()                                   # the one length sync
+        return h, d, p, e, yl, int(y_max), int(total)
+
+    def _synthesise_body(self, x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev, am_t0,
+                         input_padding_mask):
+        if input_padding_mask is None:
+            h, durations, pitch, energy, y_lengths, y_max_length, total = self._graphed_encode(
+                x, x_lengths, sids, lids, d_factor, p_factor, e_factor, durations_override, dev)
+        else:
+            h, durations, pitch, energy, y_lengths = self._encode(x, x_lengths, input_padding_mask, sids, lids, d_factor, p_factor,
+                                                                  e_factor, durations_override)
+            y_max_length = int(y_lengths.max())                                             # data-dependent shape: 1 sync
+            total = int(durations.sum())
+        if total == 0:                                                                      # alignments.py:152-157
             durations = torch.ones_like(durations)
             y_lengths = durations.sum(dim=1)
             y_max_length = int(y_lengths.max())
