@@ -631,9 +631,13 @@ def main():
         precision.set_precision(a.precision)
         parity_fig = {"ms_per_step": p_dt * 1e3, "mel_frames_per_s": world * Bl * T_MEL / p_dt, "steps": 10, "precision": "mixed",
                       "ratio_to_headline": p_dt / (dt / a.steps),
-                      "note": "precision 'mixed': generator forward / backward and the spectral losses on the exact-f32 kernels "
-                              "(wav_hat / mel <= 1e-3 vs the reference goldens, tests/test_gpu_mixed.py), only the MPD / MRD "
-                              "discriminator stacks on the bf16 kernels"}
+                      "f32_split": bool(precision._split["v"]),
+                      "note": "precision 'mixed': generator forward / backward and the spectral losses on f32 tensors with f32 "
+                              "accumulation -- the index-critical forward on the exact-f32 kernels (durations / alignment indices "
+                              "bit-identical to the f32 mode), the other generator GEMMs on osp_conv_gemm_f32_split (f32 operands as "
+                              "(hi, lo) bf16 pairs, three bf16 MFMAs per product, <= 1.1e-5 per product; OSP_F32_SPLIT=0: exact-f32 "
+                              "kernels throughout); wav_hat / mel <= 1e-3 vs the reference goldens (tests/test_gpu_mixed.py, "
+                              "tests/test_gpu_fullsize_golden.py); only the MPD / MRD discriminator stacks on the bf16 kernels"}
     ms_per_step = dt / a.steps * 1e3
     value = world * Bl * T_MEL / (dt / a.steps)
     # what the host needs to ENQUEUE a step when the device never pushes back: the same step on a 2-utterance batch (GPU work

@@ -24,7 +24,24 @@ static __device__ __attribute__((aligned(256))) unsigned osp_zero_page[64];     
 // F32 (round 4, gemm_f32_glds.hip): the operands are f32 and the products exact -- v_mfma_f32_32x32x2_f32.  Staging does not change
 // at all: a 128-byte row is 32 floats instead of 64 bf16, and the caller passes every global stride / extent in 2-byte units (doubled)
 // so that the address arithmetic below is the same; only the fragment reads and the MFMAs of a k-step differ.
-template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false, bool F32 = false>
+// SPLIT (with F32; round 5, gemm_f32_split.hip): f32 operands staged exactly as in F32 mode, but every fragment element is split in
+// registers into two bf16 numbers, x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest; x - hi is exact in f32,
+// |r| <= 2^-18 |x|), and a product is three bf16 MFMAs accumulated in f32: lo_a hi_b + hi_a lo_b + hi_a hi_b.  What is dropped --
+// lo_a lo_b and the two r terms -- is <= 3 x 2^-18 = 1.1e-5 of |a b| per product (random sign: ~4e-6 rms), against 6e-8 for the exact
+// pipe and 4e-3 for plain bf16 operands.  The bf16 matrix pipe is 16x the f32 one, so three of its MFMAs cost a fifth of the exact
+// product; the conversions (VALU) run beside them.  Used for the generator's GEMMs in the "mixed" parity mode (never on the
+// index-critical path, whose discrete outputs must come from the same kernels as the f32 mode's).
+__device__ __forceinline__ void glds_split_f32x8(const float4 v0, const float4 v1, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
+
+template <int BM_, int NST, int BN_ = TBN, int NW = 4, bool EARLY = false, bool F32 = false, bool SPLIT = false>
 __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsigned short* smem, const TileCtx tc) {
     const GemmB pp = gemm_select_phase(pin, tc.z);
     constexpr int WN_ = NW == 8 ? 4 : 2, WM_ = NW / WN_;                                         // waves along N / M
@@ -141,6 +158,54 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
         if (ld >= 0) issue_begin();
         auto kstep = [&](auto ksidx) {
             constexpr int ks = decltype(ksidx)::value;
+            if constexpr (F32 && SPLIT) {
+                // a 128-byte staged row is 32 floats = TWO 16-deep bf16 k-steps (h = 0, 1).  Lane (row l31, half lh) owns k = 16 h + 8 lh .. + 7
+                // = the 16-byte slots 4 h + 2 lh and 4 h + 2 lh + 1 of its row (the operand layout of v_mfma_f32_32x32x16_bf16).
+                // Everything happens in k-step 0 of the loop: ALL fragment reads of the slab first (no LDS-DMA request is in flight then --
+                // the compiler puts a vmcnt(0) in front of every LDS read that follows a request), then the whole next slab is requested,
+                // then conversions and MFMAs run while those loads are in flight: one exposed memory latency per slab.  (Requests dealt
+                // over four k-steps in front of the reads -- the first version -- exposed up to four.)
+                static_assert(TM_ <= 2, "f32 tiles: 32 or 64 rows per wave");
+                if constexpr (ks == 0) {
+                    float4 av[2][TM_][2], bv[2][TN_][2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int i = 0; i < TM_; ++i) {
+                            const int row = wm0 + 32 * i + l31, sw = (row >> 1) & 7;
+                            av[h][i][0] = *reinterpret_cast<const float4*>(as + row * TBK + (((4 * h + 2 * lh) ^ sw) << 3));
+                            av[h][i][1] = *reinterpret_cast<const float4*>(as + row * TBK + (((4 * h + 2 * lh + 1) ^ sw) << 3));
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN_; ++j) {
+                            const int row = wn0 + 32 * j + l31, sw = (row >> 1) & 7;
+                            bv[h][j][0] = *reinterpret_cast<const float4*>(bs + row * TBK + (((4 * h + 2 * lh) ^ sw) << 3));
+                            bv[h][j][1] = *reinterpret_cast<const float4*>(bs + row * TBK + (((4 * h + 2 * lh + 1) ^ sw) << 3));
+                        }
+                    }
+                    if (ld >= 0) {
+                        issue_quarter(ld, std::integral_constant<int, 0>{}); issue_quarter(ld, std::integral_constant<int, 1>{});
+                        issue_quarter(ld, std::integral_constant<int, 2>{}); issue_quarter(ld, std::integral_constant<int, 3>{});
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bf16x8 ah[TM_], al[TM_], bh[TN_], bl[TN_];
+#pragma unroll
+                        for (int i = 0; i < TM_; ++i) glds_split_f32x8(av[h][i][0], av[h][i][1], ah[i], al[i]);
+#pragma unroll
+                        for (int j = 0; j < TN_; ++j) glds_split_f32x8(bv[h][j][0], bv[h][j][1], bh[j], bl[j]);
+#pragma unroll
+                        for (int i = 0; i < TMA; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN_; ++j) {
+                                acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc0[i][j], 0, 0, 0);
+                                acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc0[i][j], 0, 0, 0);
+                                acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+                            }
+                    }
+                }
+                return;
+            }
             if constexpr (F32) {
                 // the two 16-byte slots of this k-step hold 4 floats each = two MFMAs of K = 2.  Lane half lh reads the 8-byte half lh
                 // of a slot, (k, k + 1) with k = 4 slot + 2 lh: the first MFMA contracts k = {4 slot, 4 slot + 2} (its k index IS the

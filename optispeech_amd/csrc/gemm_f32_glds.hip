@@ -22,8 +22,11 @@ __global__ __launch_bounds__(256) void conv_gemm_f32_glds_s64_kernel(const GemmB
     conv_gemm_bf16_glds_body<64, 2, 64, 4, false, true>(pp, glds_smem, grid_tile_ctx());
 }
 
+// the split-bf16 instantiations of the same three tile shapes live in gemm_f32_split.hip (a translation unit of their own: compile time)
+int osp_launch_f32_split(const GemmB& p, int shape, dim3 grid, int lds, hipStream_t stream);
+
 // returns 1 when the launch was taken, 0 when the caller should use its own kernel, < 0 on a launch error
-int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
+static int try_gemm_f32_glds_impl(int split, const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
                           const float* a_rowscale, const float* B, int64_t sBn, int64_t sBtap, int64_t sBk, int64_t N, float* C,
                           int64_t ldc, int64_t epi, const float* bias, const float* gamma, const float* res, int64_t ldr,
                           const float* rowmask, const float* rowscale, float* aux_out, const float* aux_in, int64_t ld_aux,
@@ -66,11 +69,55 @@ int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_glds_s64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSS);
         attr = 1;
     }
-    osp_note_symbol("conv_gemm_f32_glds_kernel");
+    osp_note_symbol(split ? "conv_gemm_f32_split_kernel" : "conv_gemm_f32_glds_kernel");
     osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);
     osp_note_bytes(4.0 * batch * ((double)M * Cin + (double)N * taps * Cin + (double)M * N));
+    if (split) {
+        const int shape = small ? 2 : wide ? 0 : 1;
+        const dim3 grid((unsigned)cdiv(N, shape == 0 ? 128 : 64), (unsigned)cdiv(M, shape == 2 ? 64 : 128), (unsigned)batch);
+        return osp_launch_f32_split(p, shape, grid, shape == 0 ? GLDS_LDS : shape == 1 ? LDS64 : LDSS, stream);
+    }
     if (small) hipLaunchKernelGGL(conv_gemm_f32_glds_s64_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)batch), dim3(256), LDSS, stream, p);
     else if (wide) hipLaunchKernelGGL(conv_gemm_f32_glds_kernel, dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch), dim3(256), GLDS_LDS, stream, p);
     else hipLaunchKernelGGL(conv_gemm_f32_glds_n64_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 128), (unsigned)batch), dim3(256), LDS64, stream, p);
     return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+
+int osp_try_gemm_f32_glds(const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
+                          const float* a_rowscale, const float* B, int64_t sBn, int64_t sBtap, int64_t sBk, int64_t N, float* C,
+                          int64_t ldc, int64_t epi, const float* bias, const float* gamma, const float* res, int64_t ldr,
+                          const float* rowmask, const float* rowscale, float* aux_out, const float* aux_in, int64_t ld_aux,
+                          int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate, hipStream_t stream) {
+    return try_gemm_f32_glds_impl(0, A, lda, M, T, Cin, taps, pad, a_rowscale, B, sBn, sBtap, sBk, N, C, ldc, epi, bias, gamma, res, ldr, rowmask,
+                                  rowscale, aux_out, aux_in, ld_aux, batch, sAb, sBb, sCb, sXb, accumulate, stream);
+}
+
+extern "C" int osp_conv_gemm_f32(const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
+                                 const float* a_rowscale, const float* B, int64_t sBn, int64_t sBtap, int64_t sBk, int64_t N, float* C,
+                                 int64_t ldc, int64_t epi, const float* bias, const float* gamma, const float* res, int64_t ldr,
+                                 const float* rowmask, const float* rowscale, float* aux_out, const float* aux_in, int64_t ld_aux,
+                                 int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate, hipStream_t stream);
+
+// osp_conv_gemm_f32 with f32 operands in HBM and SPLIT-bf16 products (gemm_bf16_glds.h, SPLIT): every operand element enters the matrix
+// pipe as hi + lo (two bf16 numbers, 16 significand bits), three bf16 MFMAs per product, f32 accumulate -- <= 1.1e-5 of |a b| per product
+// where the exact pipe gives 6e-8 and plain bf16 operands 4e-3.  For GEMMs whose result feeds continuous quantities only (the "mixed"
+// parity mode's generator outside the index-critical path).  Same arguments, same epilogues; shapes the direct-to-LDS kernel does not take
+// run as osp_conv_gemm_f32 (exact).
+extern "C" int osp_conv_gemm_f32_split(const float* A, int64_t lda, int64_t M, int64_t T, int64_t Cin, int64_t taps, int64_t pad,
+                                       const float* a_rowscale, const float* B, int64_t sBn, int64_t sBtap, int64_t sBk, int64_t N, float* C,
+                                       int64_t ldc, int64_t epi, const float* bias, const float* gamma, const float* res, int64_t ldr,
+                                       const float* rowmask, const float* rowscale, float* aux_out, const float* aux_in, int64_t ld_aux,
+                                       int64_t batch, int64_t sAb, int64_t sBb, int64_t sCb, int64_t sXb, int64_t accumulate, hipStream_t stream) {
+    OSP_CHECK_ARG(A && B && C, "null operand");
+    OSP_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && taps > 0 && T > 0 && batch > 0, "bad shape");
+    OSP_CHECK_ARG(M % T == 0, "M must be a whole number of utterances of T frames");
+    OSP_CHECK_ARG(epi >= 0 && epi <= BEPI_MASK, "unknown epilogue");
+    OSP_CHECK_ARG(epi != BEPI_SCALE_RES_MASK || res, "epilogue needs res");
+    OSP_CHECK_ARG((epi != BEPI_GELU_BWD && epi != BEPI_RELU_BWD && epi != BEPI_AXMY) || aux_in, "epilogue needs aux_in");
+    const int r = try_gemm_f32_glds_impl(1, A, lda, M, T, Cin, taps, pad, a_rowscale, B, sBn, sBtap, sBk, N, C, ldc, epi, bias, gamma, res, ldr, rowmask,
+                                         rowscale, aux_out, aux_in, ld_aux, batch, sAb, sBb, sCb, sXb, accumulate, stream);
+    if (r < 0) { osp_set_error("osp_conv_gemm_f32_split: launch failed"); return OSP_ERR_HIP; }
+    if (r > 0) return OSP_OK;
+    return osp_conv_gemm_f32(A, lda, M, T, Cin, taps, pad, a_rowscale, B, sBn, sBtap, sBk, N, C, ldc, epi, bias, gamma, res, ldr, rowmask, rowscale,
+                             aux_out, aux_in, ld_aux, batch, sAb, sBb, sCb, sXb, accumulate, stream);
 }

@@ -282,7 +282,14 @@ __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __
 // lane (A: dY[frame lh][channel l31], B: X[frame lh][channel l31]) -- no transposition anywhere.  64 x 64 tiles, four waves of
 // 32 x 32, 64-frame slabs, two stages (66 KB: two workgroups per CU).  The row factor `arow` (padding mask / DropPath) is staged
 // beside the slab and multiplied into the A operand; the bias gradient is a VALU sum of the same operand.
-template <bool AROW>
+// SPLIT (late round 5; osp_conv_wgrad_f32_split_ws, the "mixed" parity mode): the same staging and the same LDS reads, but the products
+// run on the bf16 matrix pipe -- every operand element as a (hi, lo) pair of bf16 numbers, hi = bf16(x), lo = bf16(x - hi), and
+// lo_a hi_b + hi_a lo_b + hi_a hi_b per 16-frame block (three v_mfma_f32_32x32x16_bf16 where the exact form issues eight
+// v_mfma_f32_32x32x2_f32 of twice the length each): <= 1.1e-5 of |a b| per product, f32 accumulation.  The k index of the bf16 MFMA is
+// (lane half, element e) and may be ANY enumeration of the block's 16 frames as long as both operands use the same one: frame
+// 2 e + lh -- exactly the eight floats lane half lh reads over two groups of four frame pairs below.  The bias gradient stays the
+// exact f32 sum of the A operand.
+template <bool AROW, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, float* __restrict__ ws) {
     constexpr int T = 64, SK = 64, NI = SK / 16;            // pairs of DMA instructions per wave and slab
     constexpr int STAGE = 2 * SK * T + SK;                   // floats of one stage: dY slab, X slab, row factors
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, floa
         const unsigned ya = lds_addr(ys + lh * T + wm0 + l31), xa = lds_addr(ys + SK * T + lh * T + wn0 + l31);
         const unsigned ra = lds_addr(ys + 2 * SK * T + lh);
         float a[2][4], b[2][4], r[2][4];
+        bf16x8 sah, sal, sbh, sbl;                           // SPLIT: the (hi, lo) operands of a 16-frame block, filled over two groups
 #pragma unroll
         for (int q = 0; q < 4; ++q) { r[0][q] = 1.f; r[1][q] = 1.f; }
         auto group = [&](auto gidx) {
@@ -369,11 +377,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, floa
             }
             if constexpr (G + 1 < SK / 8) wait4(a[cur], b[cur], r[cur], std::integral_constant<int, RD>{});
             else wait4(a[cur], b[cur], r[cur], std::integral_constant<int, 0>{});
+            if constexpr (SPLIT) {
+                constexpr int E0 = 4 * (G & 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float av = AROW ? a[cur][q] * r[cur][q] : a[cur][q];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[cur][q], acc, 0, 0, 0);
-                if (bias_wave) bsum += av;
+                for (int q = 0; q < 4; ++q) {
+                    const float av = AROW ? a[cur][q] * r[cur][q] : a[cur][q];
+                    if (bias_wave) bsum += av;
+                    const __bf16 ha = (__bf16)av;
+                    sah[E0 + q] = ha; sal[E0 + q] = (__bf16)(av - (float)ha);
+                    const float bv = b[cur][q];
+                    const __bf16 hb = (__bf16)bv;
+                    sbh[E0 + q] = hb; sbl[E0 + q] = (__bf16)(bv - (float)hb);
+                }
+                if constexpr ((G & 1) == 1) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sal, sbh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sah, sbl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sah, sbh, acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float av = AROW ? a[cur][q] * r[cur][q] : a[cur][q];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[cur][q], acc, 0, 0, 0);
+                    if (bias_wave) bsum += av;
+                }
             }
         };
         rd4(ya, xa, ra, std::integral_constant<int, 0>{}, a[0], b[0], r[0]);
@@ -500,7 +527,7 @@ extern "C" int osp_conv_wgrad_f32(const float* dY, int64_t ldy, const float* X, 
 // conditions hold -- no atomics, bit-reproducible -- and osp_conv_wgrad_f32 (f32 atomics) otherwise.
 //   dW[n, j, c] += oscale[n] * sum_m arow[m] * dY[m, n] * X[m + j - pad, c],  db[n] += oscale[n] * sum_m arow[m] * dY[m, n]
 // Reference op: autograd of nn.Conv1d / nn.Linear (generator/modules/convnext.py:39-41, variance_predictor.py, alignments.py:55-64).
-extern "C" int osp_conv_wgrad_f32_ws(const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T, int64_t N,
+static int conv_wgrad_f32_ws_impl(int split, const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T, int64_t N,
                                      int64_t Cin, int64_t taps, int64_t pad, const float* arow, const float* oscale, float* dW,
                                      int64_t ldw, float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
                                      float* ws, int64_t ws_bytes, hipStream_t stream) {
@@ -511,6 +538,8 @@ extern "C" int osp_conv_wgrad_f32_ws(const float* dY, int64_t ldy, const float* 
     if (on < 0) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ring_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 64 * 64 + 64) * 4);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ring_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 64 * 64 + 64) * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ring_f32_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 64 * 64 + 64) * 4);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ring_f32_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 64 * 64 + 64) * 4);
         const char* e = getenv("OSP_WGRAD_RING_F32_TARGET"); tgt = e ? atoi(e) : 512;
         e = getenv("OSP_WGRAD_RING_F32"); on = (e && atoi(e) == 0) ? 0 : 1;
     }
@@ -542,12 +571,15 @@ extern "C" int osp_conv_wgrad_f32_ws(const float* dY, int64_t ldy, const float* 
     p.fd_trows = make_fastdiv((unsigned)T); p.fd_wrows = make_fastdiv((unsigned)T);
     p.arow = arow; p.oscale = oscale; p.dW = dW; p.ldw = ldw; p.db = db; p.chunk = (int)ch; p.splits = (int)sp;
     p.sYb = sYb; p.sXb = sXb; p.sWb = sWb; p.sDb = sDb; p.y_bytes = (unsigned)yb; p.x_bytes = (unsigned)xb;
-    osp_note_symbol("conv_wgrad_ring_f32_kernel");
+    osp_note_symbol(split ? "conv_wgrad_ring_f32_split_kernel" : "conv_wgrad_ring_f32_kernel");
     osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);
     osp_note_bytes(4.0 * batch * ((double)M * N + (double)M * Cin + (double)N * taps * Cin));
     const dim3 g((unsigned)(tl * sp));
     constexpr int LDS = 2 * (2 * 64 * 64 + 64) * 4;
-    if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true>), g, dim3(256), LDS, stream, p, ws);
+    if (split) {
+        if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true, true>), g, dim3(256), LDS, stream, p, ws);
+        else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false, true>), g, dim3(256), LDS, stream, p, ws);
+    } else if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true>), g, dim3(256), LDS, stream, p, ws);
     else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false>), g, dim3(256), LDS, stream, p, ws);
     if (sp > 1) {
         const int64_t blk = wgr_block_elems(N, taps, Cin);
@@ -558,4 +590,21 @@ extern "C" int osp_conv_wgrad_f32_ws(const float* dY, int64_t ldy, const float* 
     }
     OSP_LAUNCH_CHECK();
     return OSP_OK;
+}
+
+extern "C" int osp_conv_wgrad_f32_ws(const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T, int64_t N,
+                                     int64_t Cin, int64_t taps, int64_t pad, const float* arow, const float* oscale, float* dW,
+                                     int64_t ldw, float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                     float* ws, int64_t ws_bytes, hipStream_t stream) {
+    return conv_wgrad_f32_ws_impl(0, dY, ldy, X, ldx, M, T, N, Cin, taps, pad, arow, oscale, dW, ldw, db, batch, sYb, sXb, sWb, sDb, ws, ws_bytes, stream);
+}
+
+// The same weight gradient with SPLIT-bf16 products (kernel comment above): f32 operands in HBM, (hi, lo) bf16 pairs in registers, three
+// bf16 MFMAs per 16-frame block, f32 accumulation and the same split workspace / ordered reduction -- bit-reproducible.  For the
+// "mixed" parity mode's generator (precision.f32_split); problems the ring kernel declines run as osp_conv_wgrad_f32 (exact).
+extern "C" int osp_conv_wgrad_f32_split_ws(const float* dY, int64_t ldy, const float* X, int64_t ldx, int64_t M, int64_t T, int64_t N,
+                                     int64_t Cin, int64_t taps, int64_t pad, const float* arow, const float* oscale, float* dW,
+                                     int64_t ldw, float* db, int64_t batch, int64_t sYb, int64_t sXb, int64_t sWb, int64_t sDb,
+                                     float* ws, int64_t ws_bytes, hipStream_t stream) {
+    return conv_wgrad_f32_ws_impl(1, dY, ldy, X, ldx, M, T, N, Cin, taps, pad, arow, oscale, dW, ldw, db, batch, sYb, sXb, sWb, sDb, ws, ws_bytes, stream);
 }

@@ -105,7 +105,9 @@ def conv_gemm(a, w, n_out, *, T=None, taps=1, pad=0, cin=None, w_strides=None, o
         if t is not None:
             ld_aux = t.stride(-2)
     ldr = res.stride(-2) if res is not None else 0
-    call("osp_conv_gemm_f32", a, lda, M, T, cin, taps, pad, a_rowscale, w, w_strides[0], w_strides[1], w_strides[2],
+    # "mixed" parity mode outside the index-critical path: f32 operands, split-bf16 products (precision.f32_split)
+    call("osp_conv_gemm_f32_split" if _precision.f32_split() else "osp_conv_gemm_f32",
+         a, lda, M, T, cin, taps, pad, a_rowscale, w, w_strides[0], w_strides[1], w_strides[2],
          n_out, out, ldc, epi, bias, gamma, res, ldr, rowmask, rowscale, aux_out, aux_in, ld_aux, batch,
          batch_strides[0], batch_strides[1], batch_strides[2], batch_strides[3], bool(accumulate))
     return out
@@ -243,7 +245,7 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
         return
     # exact f32: the ring kernel with a split workspace where it applies (csrc/wgrad_ring.hip: no atomics), else the tile-per-tap kernel
     ws = wgrad_workspace(N, taps, cin, batch, dy.device)
-    call("osp_conv_wgrad_f32_ws", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
+    call("osp_conv_wgrad_f32_split_ws" if _precision.f32_split() else "osp_conv_wgrad_f32_ws", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
          taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0, ws, ws.numel())
 
 

@@ -4,10 +4,14 @@
 "bf16"  : bf16 MFMA operands with f32 accumulate for the discriminator stacks and the generator GEMMs -- BASELINE.json
           config[1] names bf16 as the training precision (the reference trains 16-mixed).
 "mixed" : the PARITY mode at bench speed.  The generator (everything that produces mel / wav_hat, its backward, the spectral
-          reconstruction losses) runs exactly as in "f32"; only the MPD / MRD discriminator conv stacks -- 90 % of the step's
-          flops, and no part of the synthesised waveform -- run on the bf16 kernels.  wav_hat, mel, durations and the
-          acoustic-model losses therefore carry the f32 mode's error (<= 1e-3 of north_star, measured ~1e-5), at a step time
-          within 2x of "bf16" (bench.py reports it as ``parity_mode_step``).
+          reconstruction losses) keeps f32 tensors and f32 accumulation; only the MPD / MRD discriminator conv stacks -- 90 % of the
+          step's flops, and no part of the synthesised waveform -- run on the bf16 kernels.  Since late round 5 the generator's GEMMs
+          OUTSIDE the index-critical path (below) take ``osp_conv_gemm_f32_split``: f32 operands, every element entering the matrix
+          pipe as a (hi, lo) pair of bf16 numbers, three bf16 MFMAs per product (<= 1.1e-5 of |a b| per product; the exact pipe
+          6e-8, plain bf16 operands 4e-3) -- the index-critical forward stays on the exact-f32 kernels, so durations / alignment
+          indices are the f32 mode's bit for bit.  wav_hat and mel stay inside north_star's 1e-3 (tests/test_gpu_mixed.py,
+          tests/test_gpu_fullsize_golden.py assert it against the reference goldens); bench.py reports the step as
+          ``parity_mode_step``.  OSP_F32_SPLIT=0: every generator GEMM on the exact-f32 kernels, as "f32".
 """
 _mode = {"v": "f32"}
 _mixed = {"v": False}
@@ -77,19 +81,40 @@ def set_index_path_f32(on: bool):
 _entered = {"v": False}
 
 
+#: inside index_path() in ANY mode (the "mixed" mode's split-bf16 GEMMs must not run there)
+_in_index = {"v": False}
+_split = {"v": _os.environ.get("OSP_F32_SPLIT", "1") != "0"}
+
+
+def set_f32_split(on: bool):
+    _split["v"] = bool(on)
+
+
+def f32_split() -> bool:
+    """True where an f32 GEMM may take the split-bf16 kernel: "mixed" mode, generator side, outside the index-critical path."""
+    return _split["v"] and _mixed["v"] and _mode["v"] == "f32" and not _in_index["v"]
+
+
 @_contextlib.contextmanager
 def index_path():
-    if _mode["v"] == "bf16" and _index_f32["v"]:
-        _mode["v"], _entered["v"] = "f32", True
-        try:
+    was = _in_index["v"]
+    _in_index["v"] = True
+    try:
+        if _mode["v"] == "bf16" and _index_f32["v"]:
+            _mode["v"], _entered["v"] = "f32", True
+            try:
+                yield
+            finally:
+                _mode["v"], _entered["v"] = "bf16", False
+        else:
             yield
-        finally:
-            _mode["v"], _entered["v"] = "bf16", False
-    else:
-        yield
+    finally:
+        _in_index["v"] = was
 
 
 def leave_index_path():
-    """Inside ``index_path()``: switch back to bf16 for the rest of the block (the context's exit is then a no-op)."""
+    """Inside ``index_path()``: switch back to the configured precision for the rest of the block (the context's exit is then a
+    no-op for the mode)."""
+    _in_index["v"] = False
     if _entered["v"]:
         _mode["v"] = "bf16"

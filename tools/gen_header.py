@@ -11,6 +11,8 @@ CSRC = os.path.join(ROOT, "optispeech_amd", "csrc")
 REPLACES = {
     "osp_conv_gemm_f32": "nn.Linear / nn.Conv1d forward + dgrad: generator/modules/convnext.py:39-41, modules/core.py:66-71,95, "
                          "generator/alignments.py:55-64, vocoder/wavenext/__init__.py:43-44,83; torch.matmul in alignments.py:173",
+    "osp_conv_gemm_f32_split": "same call sites as osp_conv_gemm_f32 (f32 operands in HBM), products as three bf16 MFMAs over (hi, lo) "
+                               "operand pairs: the 'mixed' parity mode's generator GEMMs outside the index-critical path",
     "osp_conv_wgrad_f32": "autograd weight/bias gradients of the same nn.Linear / nn.Conv1d call sites",
     "osp_conv_gemm_bf16": "same call sites as osp_conv_gemm_f32 and the weight-normed Conv2d (k,1) stacks of DiscriminatorP "
                           "(vocoder/wavenext/disc/_discriminators.py:51-60,80-90), bf16 operands / f32 accumulate",
@@ -19,6 +21,8 @@ REPLACES = {
                               "(autograd of nn.Conv1d / nn.Linear: generator/modules/convnext.py:39-41)",
     "osp_conv_wgrad_f32_ws": "exact-f32 weight gradients (the f32 / mixed parity modes) with a split workspace: no f32 atomics "
                              "(autograd of nn.Conv1d / nn.Linear: generator/modules/convnext.py:39-41, generator/alignments.py:55-64)",
+    "osp_conv_wgrad_f32_split_ws": "the same weight gradients (f32 operands in HBM) with products as three bf16 MFMAs over (hi, lo) operand "
+                                   "pairs: the 'mixed' parity mode's generator",
     "osp_conv2d_wgrad_bf16_ws": "autograd weight gradients of the DiscriminatorP / DiscriminatorR Conv2d stacks "
                                 "(vocoder/wavenext/disc/_discriminators.py:51-60,154-163) with a split workspace instead of atomics",
     "osp_dwconv7_ln_fwd": "ConvNeXtBlock.forward dwconv + LayerNorm: generator/modules/convnext.py:36-38",
