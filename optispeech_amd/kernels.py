@@ -245,7 +245,7 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
         return
     # exact f32: the ring kernel with a split workspace where it applies (csrc/wgrad_ring.hip: no atomics), else the tile-per-tap kernel
     ws = wgrad_workspace(N, taps, cin, batch, dy.device)
-    call("osp_conv_wgrad_f32_split_ws" if _precision.f32_split() else "osp_conv_wgrad_f32_ws", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
+    call("osp_conv_wgrad_f32_split_ws" if _precision.f32_split("wgrad") else "osp_conv_wgrad_f32_ws", dy, dy.stride(-2), x, x.stride(-2), M, T, N, cin, taps, pad, arow, oscale, dw,
          taps * cin, db, batch, sy, sx, N * taps * cin if batch > 1 else 0, N if batch > 1 else 0, ws, ws.numel())
 
 

@@ -90,9 +90,23 @@ def set_f32_split(on: bool):
     _split["v"] = bool(on)
 
 
-def f32_split() -> bool:
-    """True where an f32 GEMM may take the split-bf16 kernel: "mixed" mode, generator side, outside the index-critical path."""
-    return _split["v"] and _mixed["v"] and _mode["v"] == "f32" and not _in_index["v"]
+_split_wgrad = {"v": _os.environ.get("OSP_F32_SPLIT_WGRAD", "1") != "0"}
+_split_bwd = {"v": _os.environ.get("OSP_F32_SPLIT_BWD", "1") != "0"}
+
+
+def f32_split(kind: str = "gemm") -> bool:
+    """True where an f32 GEMM (kind "gemm": forward and input gradients) or weight gradient ("wgrad") may take the split-bf16
+    kernel: "mixed" mode, generator side, outside the index-critical path.  OSP_F32_SPLIT_WGRAD=0 keeps the weight gradients,
+    OSP_F32_SPLIT_BWD=0 everything inside an autograd backward pass, on the exact-f32 kernels."""
+    if not (_split["v"] and _mixed["v"] and _mode["v"] == "f32" and not _in_index["v"]):
+        return False
+    if kind == "wgrad" and not _split_wgrad["v"]:
+        return False
+    if not _split_bwd["v"]:
+        import torch
+        if torch._C._current_graph_task_id() >= 0:
+            return False
+    return True
 
 
 @_contextlib.contextmanager

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from optispeech_amd import precision, rng, tape
 from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
-precision.set_precision("bf16")
+precision.set_precision(os.environ.get("PRECISION", "bf16"))          # PRECISION=mixed: the parity mode
 torch.manual_seed(1234); rng.manual_seed(1234, 0)
 cfg = ModelConfig()
 m = make_optispeech(cfg, batch_size=32, pretraining_steps=0).to("cuda").train()
