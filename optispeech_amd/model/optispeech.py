@@ -180,16 +180,18 @@ class OptiSpeech(nn.Module):
         """base_lightning_module.py:24-45; the ground-truth segment gather happens on the device."""
         dev = self.device
         t = lambda v: v.to(dev, non_blocking=True) if v is not None else None      # noqa: E731
-        if (self.graph_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
-                and batch.get("lids") is None and self.train_args.gradient_accumulate_batches is None):
-            gen_outputs = self._graphed_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
-        elif (self.tape_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
-                and batch.get("lids") is None and rng.device_seed_active() and _tape.available()):
-            gen_outputs = self._taped_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
-        else:
-            gen_outputs = self.generator(x=t(batch["x"]), x_lengths=t(batch["x_lengths"]), mel=t(batch["mel"]),
-                                         mel_lengths=t(batch["mel_lengths"]), pitches=t(batch["pitches"]),
-                                         energies=t(batch["energies"]), sids=t(batch.get("sids")), lids=t(batch.get("lids")))
+        from .. import precision as _prec
+        with (_prec.parity_forward() if self.training else contextlib.nullcontext()):
+            if (self.graph_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
+                    and batch.get("lids") is None and self.train_args.gradient_accumulate_batches is None):
+                gen_outputs = self._graphed_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
+            elif (self.tape_segments and dev.type == "cuda" and self.training and torch.is_grad_enabled() and batch.get("sids") is None
+                    and batch.get("lids") is None and rng.device_seed_active() and _tape.available()):
+                gen_outputs = self._taped_generator(tuple(t(batch[k]) for k in ("x", "x_lengths", "mel", "mel_lengths", "pitches", "energies")))
+            else:
+                gen_outputs = self.generator(x=t(batch["x"]), x_lengths=t(batch["x_lengths"]), mel=t(batch["mel"]),
+                                             mel_lengths=t(batch["mel_lengths"]), pitches=t(batch["pitches"]),
+                                             energies=t(batch["energies"]), sids=t(batch.get("sids")), lids=t(batch.get("lids")))
         wav = batch["wav"]
         if isinstance(wav, np.ndarray):
             wav = torch.from_numpy(wav)

@@ -15,6 +15,7 @@
 """
 _mode = {"v": "f32"}
 _mixed = {"v": False}
+_in_fwd = {"v": False}
 
 
 def set_precision(mode: str):
@@ -24,6 +25,8 @@ def set_precision(mode: str):
 
 
 def get_precision() -> str:
+    if _in_fwd["v"]:
+        return "bf16"                       # inside parity_forward(): the CONFIGURED mode (tape / graph keys are built from it)
     return "mixed" if (_mixed["v"] and _mode["v"] == "f32") else _mode["v"]
 
 
@@ -98,7 +101,7 @@ def f32_split(kind: str = "gemm") -> bool:
     """True where an f32 GEMM (kind "gemm": forward and input gradients) or weight gradient ("wgrad") may take the split-bf16
     kernel: "mixed" mode, generator side, outside the index-critical path.  OSP_F32_SPLIT_WGRAD=0 keeps the weight gradients,
     OSP_F32_SPLIT_BWD=0 everything inside an autograd backward pass, on the exact-f32 kernels."""
-    if not (_split["v"] and _mixed["v"] and _mode["v"] == "f32" and not _in_index["v"]):
+    if not (_split["v"] and (_mixed["v"] or _in_fwd["v"]) and _mode["v"] == "f32" and not _in_index["v"]):
         return False
     if kind == "wgrad" and not _split_wgrad["v"]:
         return False
@@ -132,3 +135,31 @@ def leave_index_path():
     _in_index["v"] = False
     if _entered["v"]:
         _mode["v"] = "bf16"
+
+
+# ---- parity-grade FORWARD inside the bf16 mode (opt-in: OSP_FWD_PARITY=1 / set_forward_parity)
+# The generator's forward of a training step runs beside the previous step's discriminator phase with ~1.5 ms to spare
+# (profiles/r05_phase_events_final.txt), so it can afford the parity mode's kernels: inside this scope the bf16 mode behaves as
+# "mixed" does for the generator -- f32 tensors, the index-critical part on the exact kernels, every other GEMM on split-bf16
+# products -- while every backward pass (run outside the scope) and the discriminator stacks stay on the bf16 kernels.  What the
+# step OUTPUTS (mel-side predictions, wav_hat, the acoustic losses) then carries the parity mode's error (~1e-5) instead of the bf16
+# operands' (~6e-3); gradients are the bf16 mode's.  ConvNeXtBlockFn / the conv Functions decide their backward precision at
+# backward time and take f32 saved activations in bf16 mode -- the combination the index-critical encoder blocks have always run.
+_fwd_parity = {"v": _os.environ.get("OSP_FWD_PARITY", "0") == "1"}
+
+
+def set_forward_parity(on: bool):
+    _fwd_parity["v"] = bool(on)
+
+
+@_contextlib.contextmanager
+def parity_forward():
+    if _fwd_parity["v"] and _mode["v"] == "bf16" and not _mixed["v"] and not _in_fwd["v"]:
+        _mode["v"], _in_fwd["v"] = "f32", True
+        try:
+            yield
+        finally:
+            _mode["v"], _in_fwd["v"] = "bf16", False
+    else:
+        yield
+

@@ -181,3 +181,50 @@ def test_mixed_mode_training_steps_run_on_the_production_schedule(mixed):
     v = m.discriminator.multiperioddisc.discriminators[0].convs[3].weight_v
     pack = getattr(v, "_osp_wn_pack", None)
     assert pack is not None and pack[1][0] is not None and pack[1][0].dtype == torch.bfloat16
+
+
+def test_bf16_mode_with_parity_forward_vs_reference_golden(golden):
+    """``precision.set_forward_parity(True)`` (OSP_FWD_PARITY=1) in the bf16 mode: the generator's training forward runs the parity mode's
+    kernels (index path exact f32, the other GEMMs split-bf16 products), every backward pass and the discriminator stacks stay bf16.
+    Outputs carry the parity mode's bounds -- indices EXACT, wav_hat < 1e-3 (north_star), acoustic losses 1e-4 --, gradients the bf16
+    mode's (acoustic-model / vocoder gradient norms 3e-2 / 1.2e-1 as in tests/test_gpu_bf16.py and test_gpu_fullsize_golden.py)."""
+    from optispeech_amd import precision
+    from tests.test_gpu_training import _small_model, _ref_grads
+    precision.set_precision("bf16")
+    precision.set_forward_parity(True)
+    try:
+        g = golden("gen_small_gan")
+        m = _small_model(g)
+        batch = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+        batch.update(sids=None, lids=None)
+        m.discriminator.lambda_mel = 0.0
+        logs = {}
+        for p in m.discriminator.parameters():
+            p.requires_grad_(False)
+        loss_g, (wav, wav_hat) = m.training_step_g(batch, True, logs)
+        assert precision.is_bf16() and precision.get_precision() == "bf16"          # the scope is closed again
+        aux = m._last_gen_outputs["_aux"]
+        assert np.array_equal(m._last_gen_outputs["start_idx"].cpu().numpy(), g["start_idx"])
+        assert np.array_equal(aux["durations"].cpu().numpy(), g["durations"])
+        werr = relerr(wav_hat, g["wav_hat"])
+        assert werr < 1e-3, werr
+        got, want = logs["gen_adv_loss/train_mr_stft_loss"].item(), float(g["genlog_mr_stft_loss"])
+        assert abs(got - want) <= 2e-4 * abs(want), (got, want)
+        assert abs(loss_g.item() - float(g["loss_g"])) <= 2e-2 * abs(float(g["loss_g"]))
+        loss_g.backward()
+        gg = _ref_grads(m.generator)
+        worst_am = worst_voc = 0.0
+        for k, n in zip(g["grad_g_names"].tolist(), g["grad_g_norms"].tolist()):
+            if n < 1e-6:
+                continue
+            e = abs(gg[k].double().norm().item() - n) / n
+            if k.startswith("vocoder."):
+                worst_voc = max(worst_voc, e)
+                assert e <= 1.2e-1, (k, gg[k].double().norm().item(), n)
+            else:
+                worst_am = max(worst_am, e)
+                assert e <= 3e-2, (k, gg[k].double().norm().item(), n)
+        print(f"bf16 + parity forward: wav_hat err {werr:.2e}, gradient-norm deviations acoustic {worst_am:.2e} vocoder {worst_voc:.2e}")
+    finally:
+        precision.set_forward_parity(False)
+        precision.set_precision("f32")
