@@ -107,7 +107,8 @@ def f32_split(kind: str = "gemm") -> bool:
         return False
     if not _split_bwd["v"]:
         import torch
-        if torch._C._current_graph_task_id() >= 0:
+        in_backward = getattr(torch._C, "_current_graph_task_id", None)      # >= 0 while an autograd backward pass runs
+        if in_backward is not None and in_backward() >= 0:
             return False
     return True
 
