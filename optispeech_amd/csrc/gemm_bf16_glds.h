@@ -142,8 +142,31 @@ __device__ __forceinline__ void conv_gemm_bf16_glds_body(const GemmB& pin, unsig
     // shadow of that iteration's remaining MFMAs -- computed at the top of the iteration they delayed its first loads and
     // first MFMA (8-wave kernel: 128 -> 139 us per launch when this order was introduced).
     auto issue_begin = [&]() {};
-    auto issue_end = [&]() { ++is_j; if (is_j == taps) { is_j = 0; is_cb += TBK; } if (is_cb < Cin) set_tap(is_j, is_cb); };
+    // SPLIT kernels, taps == 1 (a plain GEMM -- every pointwise conv / linear of the generator): the rows of a slab are the rows of the
+    // previous one 128 bytes further on, so the source pointers ADVANCE instead of being recomputed (a row on the zero page stays
+    // there).  The split kernels are VALU-issue-bound (profiles/r05_split_pmc.txt) and the generic form costs ~10 VALU instructions per
+    // staged row and slab -- as much as the (hi, lo) conversions of a 64 x 64 tile.
+    int a_adv[SPLIT ? RA : 1], b_adv[SPLIT ? RB : 1];
+    auto issue_end = [&]() {
+        if constexpr (SPLIT) {
+            if (taps == 1) {
+                is_cb += TBK;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) a_src[i] += a_adv[i];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) b_src[i] += b_adv[i];
+                return;
+            }
+        }
+        ++is_j; if (is_j == taps) { is_j = 0; is_cb += TBK; } if (is_cb < Cin) set_tap(is_j, is_cb);
+    };
     set_tap(0, 0);
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) a_adv[i] = a_src[i] != zero ? TBK : 0;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) b_adv[i] = b_src[i] != zero ? TBK : 0;
+    }
     auto issue = [&](int buf) {
         issue_begin();
         issue_quarter(buf, std::integral_constant<int, 0>{}); issue_quarter(buf, std::integral_constant<int, 1>{});
