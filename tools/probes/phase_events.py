@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from optispeech_amd import precision, rng
 from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
-precision.set_precision("bf16")
+precision.set_precision(os.environ.get("PRECISION", "bf16"))
 torch.manual_seed(0); rng.manual_seed(0, 0)
 cfg = ModelConfig()
 NB = int(os.environ.get("NB", "32"))
