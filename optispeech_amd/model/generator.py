@@ -162,7 +162,7 @@ class OptiSpeechGenerator(nn.Module):
     def _graphed_decode(self, h, durations, x_lengths, y_lengths, y_max, am_t0, dev):
         """Upsampler + decoder, then the vocoder, replayed from hipGraphs captured per (B, T_text, y_max, precision).  Returns
         (wav, acoustic-model ms, vocoder ms) with the reference's two timing points."""
-        key = (tuple(h.shape), int(y_max), precision.get_precision())
+        key = (tuple(h.shape), int(y_max), precision.signature())
         ent = self._decode_graphs.get(key)
         if ent is None:
             if len(self._decode_graphs) >= 8:
@@ -246,7 +246,7 @@ class OptiSpeechGenerator(nn.Module):
         tensors (graph-owned buffers, valid until the next replay of the same graph) and (max frame count, total frame count) from ONE
         host read."""
         key = (tuple(x.shape), sids is not None, lids is not None, float(d_factor), float(p_factor), float(e_factor),
-               durations_override is not None, precision.get_precision())
+               durations_override is not None, precision.signature())
         ent = self._encode_graphs.get(key)
         Tt = x.shape[1]
         if ent is None:

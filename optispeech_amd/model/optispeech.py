@@ -219,12 +219,12 @@ class OptiSpeech(nn.Module):
             self._tape_voc = _tape.Segment(lambda seg: (gen.vocoder(seg, f0=None),), "vocoder")
         x, mel = tensors[0], tensors[2]
         r01 = gen.draw_segment_rand(x.shape[0], x.device)
-        key = (tuple((tuple(v.shape), v.dtype) for v in tensors), precision.get_precision(), id(self.optimizers()[0].arena))
+        key = (tuple((tuple(v.shape), v.dtype) for v in tensors), precision.signature(), id(self.optimizers()[0].arena))
         am = self._tape_am if os.environ.get("OSP_TAPE_AM", "1") != "0" else (lambda k, *a: self._tape_am.fn(*a))
         vo = self._tape_voc if os.environ.get("OSP_TAPE_VOC", "1") != "0" else (lambda k, *a: self._tape_voc.fn(*a))
         loss, align, dur, pit, ene, segment, start_idx, durations, p_avg, e_avg = am(key, *tensors, r01)
         seg_size = int(segment.shape[1])
-        vkey = (tuple(segment.shape), precision.get_precision(), id(self.optimizers()[0].arena))
+        vkey = (tuple(segment.shape), precision.signature(), id(self.optimizers()[0].arena))
         from ..model.generator import _VOC_STREAM
         if _VOC_STREAM:
             wav_hat = ops.run_on_side_stream("vocoder", lambda: vo(vkey, segment)[0], [segment])
@@ -250,7 +250,7 @@ class OptiSpeech(nn.Module):
         """generator.forward through the two graphed segments (captured on the first call with this batch signature)."""
         from .. import ops, precision
         from ..graphs import GeneratorSegments
-        key = (tuple((tuple(v.shape), str(v.dtype)) for v in tensors), precision.get_precision(), self.generator.segment_rand01 is not None)
+        key = (tuple((tuple(v.shape), str(v.dtype)) for v in tensors), precision.signature(), self.generator.segment_rand01 is not None)
         segs = self._gen_segments.get(key)
         if segs is None:
             if len(self._gen_segments) >= 4:

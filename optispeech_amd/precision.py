@@ -34,6 +34,12 @@ def is_bf16() -> bool:
     return _mode["v"] == "bf16"
 
 
+def signature():
+    """What a recorded call tape / captured hipGraph of generator code depends on besides shapes: the configured mode AND the
+    switches that choose kernels inside it.  Keys built from this never replay a region recorded under other switches."""
+    return (get_precision(), _split["v"], _split_wgrad["v"], _split_bwd["v"], _fwd_parity["v"], _index_f32["v"])
+
+
 # ---- index-critical path
 # The monotonic alignment search, the durations it yields and the duration predictor's integer output at inference are
 # DISCRETE functions of the encoder output / the attention log-probabilities: bf16 operand rounding upstream moves a few

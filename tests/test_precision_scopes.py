@@ -85,3 +85,19 @@ def test_parity_forward_scope_is_bf16_only_opt_in_and_restores():
         P.set_precision(mode)
         with P.parity_forward():
             assert not P._in_fwd["v"] and P.get_precision() == mode
+
+
+def test_signature_names_every_kernel_choosing_switch():
+    P.set_precision("mixed")
+    base = P.signature()
+    assert base[0] == "mixed"
+    for setter in (lambda: P.set_f32_split(not P._split["v"]), lambda: P._split_wgrad.__setitem__("v", not P._split_wgrad["v"]),
+                   lambda: P._split_bwd.__setitem__("v", not P._split_bwd["v"]), lambda: P.set_forward_parity(not P._fwd_parity["v"])):
+        setter()
+        assert P.signature() != base                      # a tape / graph key built from it cannot be replayed under other switches
+        setter()
+        assert P.signature() == base
+    P.set_precision("bf16")
+    P.set_forward_parity(True)
+    with P.parity_forward():
+        assert P.signature()[0] == "bf16"                 # the configured mode, also inside the scope
