@@ -138,6 +138,31 @@ def _param_pack_f32(p, w, n_out, taps, cin, w_strides):
     return _param_pack(p, w, n_out, taps, cin, w_strides, f32=True)
 
 
+def _region_first_use(p, key):
+    """True exactly once per (recorded region, pack).  While a call tape is RECORDING, the first use of an epoch-cached weight pack in
+    the region counts as a cache miss, whatever the cache says: a region recorded when the pack happened to be fresh --
+    the second differently-shaped micro-batch of a gradient-accumulation epoch, a region whose packs another region refreshed --
+    would otherwise put no refresh launch on its tape and, replayed as the FIRST user of a later epoch, read the previous epoch's
+    weights.  With the rule every tape carries the refresh of every pack it reads; in the steady state (one optimizer step per
+    training step) that is exactly the launch an epoch's first use makes anyway."""
+    from . import tape
+    seen = tape.region_packs()
+    if seen is None:
+        return False
+    k = (id(p), key)
+    if k in seen:
+        return False
+    seen.add(k)
+    return True
+
+
+def _region_mark(p, key):
+    from . import tape
+    seen = tape.region_packs()
+    if seen is not None:
+        seen.add((id(p), key))
+
+
 _PACK_REG = {}          # (id(param), view key) -> (weakref(param), view key): every pack ever asked for through _param_pack
 
 
@@ -154,7 +179,8 @@ def _param_pack(p, w, n_out, taps, cin, w_strides, f32=False):
         _PACK_REG[rk] = (weakref.ref(p), key)
     stamp = (values.param_epoch(), p._version, p.data_ptr())
     cache = getattr(p, "_osp_packs", None)
-    if cache is not None and cache[0] == stamp:
+    force = _region_first_use(p, ("view",) + key)            # recording a tape: this region's tape must carry the refresh
+    if cache is not None and cache[0] == stamp and not force:
         wp = cache[1].get(key)
         if wp is not None:
             return wp
@@ -187,8 +213,9 @@ def _param_pack(p, w, n_out, taps, cin, w_strides, f32=False):
         if c2 is None or c2[0] != st:
             c2 = (st, {})
             q._osp_packs = c2
-        if k2 in c2[1]:
+        if k2 in c2[1] and not force:                            # (force: every registered pack of the arena, fresh or not)
             continue
+        _region_mark(q, ("view",) + k2)
         off, n2, t2, c_in, strd = k2[:5]
         as_f32 = len(k2) > 5
         out = _persistent(q, "_osp_pack_bufs", k2, (n2, t2, c_in), torch.float32 if as_f32 else torch.bfloat16)
@@ -739,9 +766,9 @@ def param_bf16(p, transposed=False):
     if cache is None or cache[0] != stamp:
         cache = (stamp, {})
         p._osp_bf16 = cache
-    if transposed not in cache[1]:
+    if transposed not in cache[1] or _tape_recording():      # (recording: param_bf16_many decides, once per region and pack)
         param_bf16_many([(p, transposed, None)])
-    return cache[1][transposed]
+    return p._osp_bf16[1][transposed]
 
 
 def param_bf16_many(requests):
@@ -758,10 +785,11 @@ def param_bf16_many(requests):
             cache = (stamp, {})
             p._osp_bf16 = cache
         key = transposed if kscale is None else ("t_scaled", kscale.data_ptr(), kscale._version)
-        if key in cache[1]:
-            continue
-        N, Kd = p.shape
         bkey = key if kscale is None else ("t_scaled", kscale.data_ptr())
+        if key in cache[1] and not _region_first_use(p, ("bf16", bkey)):
+            continue
+        _region_mark(p, ("bf16", bkey))
+        N, Kd = p.shape
         if transposed or kscale is not None:                     # out[k_dim = N index ... ] : (Kd rows, N reduction) = W^T
             out = _persistent(p, "_osp_bf16_bufs", bkey, (Kd, N), torch.bfloat16)
             rows.append([p.data_ptr(), 0 if kscale is None else kscale.data_ptr(), out.data_ptr(), Kd, 1, N, 1, 0, Kd, 0])
@@ -784,7 +812,7 @@ def param_bf16_scaled_t(p, kscale):
     stamp = (values.param_epoch(), p._version, p.data_ptr())
     cache = getattr(p, "_osp_bf16", None)
     key = ("t_scaled", kscale.data_ptr(), kscale._version)
-    if cache is not None and cache[0] == stamp and key in cache[1]:
+    if cache is not None and cache[0] == stamp and key in cache[1] and not _tape_recording():
         return cache[1][key]
     param_bf16_many([(p, True, kscale)])
     return p._osp_bf16[1][key]
@@ -823,14 +851,33 @@ def conv_gemm_bf16(a, w, n_out, *, M, Trows, Tin, cin, taps=1, a_step=1, a_tapst
 
 
 _WGRAD_WS_CAP = 32 << 20
+_WGRAD_WS = {}          # (device index, launch-stream key) -> persistent uint8 scratch, grown to the largest request (<= _WGRAD_WS_CAP)
 
 
 def wgrad_workspace(n, taps, cin, batch, device):
     """Scratch for the frame splits of one weight-gradient launch (csrc/wgrad_ring.hip): up to 64 partial copies of dW (+ db),
-    32 MB at most; the library takes as many splits as fit.  From torch's caching allocator, i.e. owned by the current stream
-    (inside a recorded region: by the tape)."""
+    32 MB at most; the library takes as many splits as fit.  ONE persistent buffer per LAUNCH stream: the partial-sum
+    kernel and its reduction are queued back to back on that stream, so stream order is all the protection the scratch needs, and
+    nothing is allocated per launch -- a deferred launch (ops.side_wgrad) or a call tape holds a pointer into a buffer that is never
+    freed instead of pinning 32 MB each.  The launch stream is the side stream of the calling stream while ops.side_wgrad is
+    recording (ops._flush_wgrad sends a calling stream's launches to exactly one side stream), else the stream the call goes to."""
+    from . import _lib
     blk = (n * taps * cin + n + 3) // 4 * 16 * batch
-    return torch.empty((min(_WGRAD_WS_CAP, 64 * blk),), device=device, dtype=torch.uint8)
+    need = min(_WGRAD_WS_CAP, 64 * blk)
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
+        # a buffer made during a capture would live in the graph's private pool: not cached (one per launch, owned by the graph, as before)
+        return torch.empty((need,), device=device, dtype=torch.uint8)
+    raw = _lib._STREAM_OVERRIDE[0] or _lib._raw_stream(idx)
+    key = (idx, ("side", raw) if _lib._RECORD[0] is not None else raw)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        # grown, never shrunk; the old buffer may still be in use by launches queued (or taped) earlier: kept alive, not freed
+        if ws is not None:
+            _WGRAD_WS.setdefault("retired", []).append(ws)
+        ws = _WGRAD_WS[key] = torch.empty((_WGRAD_WS_CAP if ws is not None else need,), device=device, dtype=torch.uint8)
+    return ws[:need]
 
 
 def conv_wgrad_bf16(dy, x, dw, db=None, *, M, Trows, Tin, n, cin, taps=1, pad=0, x_step=1, arow=None, oscale=None,
@@ -1054,8 +1101,9 @@ def param_f32_t(p, kscale=None):
     stamp = (values.param_epoch(), p._version, p.data_ptr(), None if kscale is None else (kscale.data_ptr(), kscale._version))
     key = "_osp_f32_t" if kscale is None else "_osp_f32_t_scaled"
     cache = getattr(p, key, None)
-    if cache is None or cache[0] != stamp:
+    if cache is None or cache[0] != stamp or _region_first_use(p, key):
         N, Kd = p.shape
+        _region_mark(p, key)
         out = _persistent(p, "_osp_f32_t_bufs", key, (Kd, N), torch.float32)
         row = [[p.data_ptr(), 0 if kscale is None else kscale.data_ptr(), out.data_ptr(), Kd, 1, N, 1, 0, Kd, 1]]
         _keep(p, kscale, out)
@@ -1072,8 +1120,9 @@ def param_bf16_kperm16(p):
     from . import values
     stamp = (values.param_epoch(), p._version, p.data_ptr())
     cache = getattr(p, "_osp_bf16_kperm16", None)
-    if cache is None or cache[0] != stamp:
+    if cache is None or cache[0] != stamp or _region_first_use(p, "kperm16"):
         N, Kd = p.shape
+        _region_mark(p, "kperm16")
         assert Kd % 16 == 0
         w = _persistent(p, "_osp_bf16_bufs", "kperm16", (N, Kd), torch.bfloat16)       # refreshed in place: one launch, no torch op
         call("osp_pack_bf16_kperm16", p.detach(), w, N, Kd)

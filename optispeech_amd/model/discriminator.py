@@ -145,6 +145,33 @@ def _replay_scores(d, B):
 
 
 class _Multi(nn.Module):
+    def _plist(self):
+        """Flat parameter list, taken once (walking the module tree for `self.parameters()` four times a step was 0.3 ms of host
+        time) and checked against the live tensors' ids on every use (a list cached forever goes stale when parameters
+        are replaced -- remove_weight_norm, an overwriting _apply -- and `real_needs_grad` would then read dead tensors).  The
+        check is over the cached (module, name) slots, not a tree walk."""
+        hit = self.__dict__.get("_param_slots")
+        if hit is not None:
+            slots, plist = hit
+            if all(m._parameters.get(n) is q for (m, n), q in zip(slots, plist)) and self.__dict__.get("_param_count") == sum(len(m._parameters) for m in self.__dict__["_param_mods"]):
+                return plist
+        slots, plist, mods = [], [], []
+        for m in self.modules():
+            mods.append(m)
+            for n, q in m._parameters.items():
+                if q is not None:
+                    slots.append((m, n)); plist.append(q)
+        object.__setattr__(self, "_param_slots", (slots, plist))
+        object.__setattr__(self, "_param_mods", mods)
+        object.__setattr__(self, "_param_count", sum(len(m._parameters) for m in mods))
+        return plist
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("_param_slots", "_param_mods", "_param_count"):         # a cache, not state: never copied by deepcopy / pickle
+            st.pop(k, None)
+        return st
+
     def forward_real(self, y):
         """Real-wave branch only -> (scores, feature maps) per sub-discriminator, under the caller's grad mode.  Inside
         one training step the discriminator weights and the real waves are the same in the generator phase and in the
@@ -168,11 +195,7 @@ class _Multi(nn.Module):
                 gs.append(g); fgs.append(fg)
             return rs, gs, frs, fgs
         # (a flat list, taken once: walking the module tree for `self.parameters()` four times a step was 0.3 ms of host time)
-        plist = self.__dict__.get("_param_list")
-        if plist is None:
-            plist = list(self.parameters())
-            object.__setattr__(self, "_param_list", plist)
-        real_needs_grad = any(p.requires_grad for p in plist)
+        real_needs_grad = any(p.requires_grad for p in self._plist())
         B = y.shape[0]
         # weight-norm packs of every conv of this family in one launch (cached per optimiser epoch: the generator phase, its
         # real / generated halves and the discriminator phase of a step share them)

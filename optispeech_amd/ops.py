@@ -151,8 +151,10 @@ def wgrad_side_streams():
 
 
 class side_wgrad:
-    """``with side_wgrad(t0, t1, ...):`` -- the enclosed C-ABI launches (weight-gradient kernels; only kernels.* calls that allocate
-    nothing may run inside) are RECORDED, and every OSP_WGRAD_FLUSH-th region the recorded launches go to the side stream of the
+    """``with side_wgrad(t0, t1, ...):`` -- the enclosed C-ABI launches (weight-gradient kernels) are RECORDED: a kernels.* call
+    inside may only allocate tensors that it passes to a recorded launch (the bf16 operand copies of kernels._bf16_rows: the argument
+    tuple keeps them alive until the end-of-backward join; the split workspace is NOT such a tensor, it is one persistent buffer per
+    launch stream, kernels.wgrad_workspace), never one it drops before the launch runs, and every OSP_WGRAD_FLUSH-th region the recorded launches go to the side stream of the
     current stream in one hand-over (one event record + one stream wait, torch's current stream is never switched).  Measured on
     one box, 40 steps each, twice: inline 21.84 / 20.75 ms per step, flush every region 20.22 / 20.42, every 2nd 20.92 / 20.88,
     every 4th 20.56 / 20.59, every 8th 20.41 / 20.57 -- the earlier start of the side-stream work is worth more than the host time

@@ -25,9 +25,17 @@ def set_precision(mode: str):
 
 
 def get_precision() -> str:
-    if _in_fwd["v"]:
-        return "bf16"                       # inside parity_forward(): the CONFIGURED mode (tape / graph keys are built from it)
+    """The EFFECTIVE mode: what kernels and dtypes code running right now must choose (inside parity_forward() that is "f32",
+    consistent with is_bf16())."""
     return "mixed" if (_mixed["v"] and _mode["v"] == "f32") else _mode["v"]
+
+
+def configured_precision() -> str:
+    """The mode the user configured, whatever region is executing (inside parity_forward() of the bf16 mode: "bf16"): what keys of
+    tapes and graphs are built from (signature())."""
+    if _in_fwd["v"]:
+        return "bf16"
+    return get_precision()
 
 
 def is_bf16() -> bool:
@@ -37,7 +45,7 @@ def is_bf16() -> bool:
 def signature():
     """What a recorded call tape / captured hipGraph of generator code depends on besides shapes: the configured mode AND the
     switches that choose kernels inside it.  Keys built from this never replay a region recorded under other switches."""
-    return (get_precision(), _split["v"], _split_wgrad["v"], _split_bwd["v"], _fwd_parity["v"], _index_f32["v"])
+    return (configured_precision(), _split["v"], _split_wgrad["v"], _split_bwd["v"], _fwd_parity["v"], _index_f32["v"])
 
 
 # ---- index-critical path

@@ -32,6 +32,9 @@ from torch.utils._python_dispatch import TorchDispatchMode
 from . import _lib
 
 ENABLED = os.environ.get("OSP_TAPES", "1") != "0"
+#: a taped Segment records a key at its N-th sighting (2: the first step with a batch signature runs eagerly, the second records,
+#: later ones replay); OSP_TAPE_SEGMENT_AFTER=1 records at first sight (round 5's behaviour)
+SEGMENT_RECORD_AFTER = int(os.environ.get("OSP_TAPE_SEGMENT_AFTER", "2"))
 EAGER = object()                    # cache marker: this key could not be recorded, run the region eagerly
 _STATS = {"recorded": 0, "replayed": 0, "poisoned": 0, "calls_replayed": 0}
 _WARNED = set()
@@ -62,6 +65,16 @@ def recording():
 
 def stats():
     return dict(_STATS)
+
+
+_REGION_PACKS = [None]
+
+
+def region_packs():
+    """While a Recorder is active: the set of (parameter, pack) pairs the region being recorded has refreshed so far (kernels.py
+    treats the first use of an epoch-cached weight pack inside a recorded region as a miss, so that every tape carries the refresh
+    of every pack it reads); None outside a recording."""
+    return _REGION_PACKS[0]
 
 
 # ---------------------------------------------------------------------------------------------------- ATen interception
@@ -325,9 +338,12 @@ class Recorder:
     """``with Recorder(inputs) as rec: outs = fn(*inputs)`` then ``rec.finish(outs)`` -> Region, or None when the recording was
     poisoned (the execution itself was complete and valid either way: a recording run IS a normal run)."""
 
-    def __init__(self, inputs, label=""):
+    def __init__(self, inputs, label="", packs=None):
         self.inputs = list(inputs)
         self.label = label
+        #: weight packs this region may take as fresh without a refresh of its own: those refreshed by the region whose replay
+        #: always precedes this one's in the same optimizer epoch (a Segment's backward inherits its forward's)
+        self.packs = set(packs) if packs is not None else set()
         self.poisoned = None
         self.rerouted = 0
         self.cap = None
@@ -347,12 +363,14 @@ class Recorder:
         f.tape_begin(bases, sizes, _lib._STREAM_OVERRIDE[0] or _lib._raw_stream(_lib._cur_device()))
         for t in self.inputs:                                    # inputs stay alive only through the caller; nothing to keep
             pass
+        _REGION_PACKS[0] = self.packs
         self._guard = _AtenGuard(self)
         self._guard.__enter__()
         return self
 
     def __exit__(self, et, ev, tb):
         f = fast()
+        _REGION_PACKS[0] = None
         self._guard.__exit__(et, ev, tb)
         if et is not None:
             f.tape_abort()
@@ -422,12 +440,23 @@ class Segment:
     def __init__(self, fn, label):
         self.fn, self.label = fn, label
         self.cache = {}
+        self.seen = {}
         self.anchor = None
 
     def __call__(self, key, *inputs):
         if (not available() or recording() or not torch.is_grad_enabled() or not inputs[0].is_cuda
                 or torch.cuda.is_current_stream_capturing() or self.cache.get(key) is EAGER):
             return self.fn(*inputs)
+        if key not in self.cache and SEGMENT_RECORD_AFTER > 1:
+            # a segment's key is built from the batch's SHAPES and a recorded segment owns a full set of activations: record a key only
+            # once it has come back (ragged real batches would otherwise re-record almost every step, never replay, and pin
+            # up to 8 activation sets); `seen` holds keys only, bounded
+            n = self.seen.pop(key, 0) + 1
+            if n < SEGMENT_RECORD_AFTER:
+                if len(self.seen) >= 256:
+                    self.seen.pop(next(iter(self.seen)))
+                self.seen[key] = n
+                return self.fn(*inputs)
         if self.anchor is None or self.anchor.device != inputs[0].device:
             self.anchor = torch.zeros(1, device=inputs[0].device, requires_grad=True)     # gives the node's outputs a grad_fn
         return _SegmentFn.apply(self, key, self.anchor, *inputs)
@@ -458,6 +487,7 @@ class _SegmentFn(torch.autograd.Function):
             diff = tuple(i for i, o in enumerate(inner) if isinstance(o, torch.Tensor) and o.requires_grad)
             region = rec.finish(tuple(o.detach() if isinstance(o, torch.Tensor) else o for o in inner))
             ctx.inner = (inner, region)
+            ctx.fwd_packs = rec.packs
             ctx.diff = diff
             outs = tuple(o.detach() if isinstance(o, torch.Tensor) else o for o in inner)
         nd = [o for i, o in enumerate(outs) if isinstance(o, torch.Tensor) and i not in ctx.diff]
@@ -490,7 +520,7 @@ class _SegmentFn(torch.autograd.Function):
         from . import ops as _ops
         outer = _ops.nested_backward_begin()                       # the segment joins its own weight-gradient side streams: on the tape
         try:
-            with Recorder(gin + list(ctx.fwd_inputs), seg.label + " backward") as rec:
+            with Recorder(gin + list(ctx.fwd_inputs), seg.label + " backward", packs=ctx.fwd_packs) as rec:
                 torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         finally:
             _ops.nested_backward_end(outer)

@@ -169,6 +169,71 @@ def test_taped_segments_on_changing_ragged_batches_equal_eager(backbone):
         assert ((da - db).norm() / da.norm()).item() < 1e-5, (i, "discriminator")
 
 
+@pytest.mark.parametrize("mode", ["mixed", "bf16"])
+def test_taped_segments_across_differently_shaped_micro_batches_see_fresh_weights(mode):
+    """gradient_accumulate_batches = 2 with two padded shapes A, B.  In one optimizer epoch micro-batch A records
+    its tapes (first user of the epoch: its tape carries the weight-pack refresh) and micro-batch B records ITS tapes when every
+    pack is already fresh -- before the fix B's tapes held no refresh launch, and an epoch that begins with B (order B, A) replayed
+    them on the previous epoch's weights: silently stale forward and input gradients.  The "optimizer" here moves the weights by a
+    visible amount (1 % of each tensor's scale) so that a stale pack cannot hide inside the tolerance.  Order: (A, B) eager,
+    (A, B) records, (B, A) and (B, A) replay; accumulated gradients of every epoch, taped vs eager."""
+    from oracle import schema as S
+    from optispeech_amd import precision, rng, tape, values
+    from optispeech_amd.config import ModelConfig, make_optispeech, synthetic_batch
+    precision.set_precision(mode)
+    keep = tape.ENABLED
+
+    def run(tapes):
+        tape.ENABLED = tapes
+        c = S.SMALL
+        cfg = ModelConfig(dim=c.dim, enc_inter=c.enc_inter, dec_inter=c.dec_inter, dur=c.dur + (0.0,), pitch=c.pitch + (0.0,),
+                          energy=c.energy + (0.0,), voc_dim=c.voc_dim, voc_inter=c.voc_inter, voc_layers=c.voc_layers).no_dropout()
+        torch.manual_seed(7); rng.manual_seed(7, 0)
+        m = make_optispeech(cfg, batch_size=2, pretraining_steps=0).to(DEV).train()
+        m.train_args.gradient_accumulate_batches = 2
+        m.tape_segments = True
+        m.pipeline_steps = False
+        got, epoch = {}, [0]
+
+        def fake_step(name, oo):
+            def step(*a, **k):
+                got[name] = oo.arena.grad.detach().clone()
+                noise = torch.randn(oo.arena.numel, generator=torch.Generator().manual_seed(100 * epoch[0] + len(name))).to(DEV)
+                oo.arena.data.add_(noise * 0.01 * oo.arena.data.abs().mean())
+                values.bump_param_epoch()
+            return step
+        for name, o in zip(("g", "dd"), m.optimizers()):
+            o.step = fake_step(name, o)
+        shapes = {"A": (24, 96), "B": (20, 80)}
+        out, idx = [], 0
+        for pair in ("AB", "AB", "BA", "BA"):
+            for which in pair:
+                tt, tm = shapes[which]
+                b = synthetic_batch(2, tt, tm, cfg, seed=60 + idx, ragged=True, device=DEV)
+                m.generator.segment_rand01 = torch.tensor([0.25, 0.6], device=DEV)
+                m.training_step(b, idx)
+                idx += 1
+            m.join()
+            torch.cuda.synchronize()
+            epoch[0] += 1
+            out.append((got["g"].clone(), got["dd"].clone()))
+        return out
+
+    try:
+        s0 = tape.stats()
+        a = run(False)
+        b = run(True)
+        s1 = tape.stats()
+    finally:
+        tape.ENABLED = keep
+        precision.set_precision("f32")
+    assert s1["replayed"] - s0["replayed"] >= 8 and s1["poisoned"] == s0["poisoned"], (s0, s1)
+    tol = 1e-5 if mode == "mixed" else 2e-3
+    for i, ((ga, da), (gb, db)) in enumerate(zip(a, b)):
+        assert ((ga - gb).norm() / ga.norm()).item() < tol, (i, "generator", ((ga - gb).norm() / ga.norm()).item())
+        assert ((da - db).norm() / da.norm()).item() < tol, (i, "discriminator", ((da - db).norm() / da.norm()).item())
+
+
 def test_two_forwards_before_either_backward_keep_their_activations():
     """a taped forward's outputs are the tape's buffers.  Two forwards of one stack with the same key before
     either backward (what OSP_SHARE_REAL=1 does: forward_real(wav), then d(wav_hat.detach())) must not share them -- the second

@@ -70,13 +70,14 @@ def test_parity_forward_scope_is_bf16_only_opt_in_and_restores():
     P.set_forward_parity(True)
     with P.parity_forward():
         assert not P.is_bf16() and P.f32_split()           # the generator's forward sees the parity mode's kernels ...
-        assert P.get_precision() == "bf16"                 # ... while tape / graph keys still name the configured mode
+        assert P.get_precision() == "f32"                  # ... and the EFFECTIVE mode agrees with is_bf16() ...
+        assert P.configured_precision() == "bf16" and P.signature()[0] == "bf16"     # ... while tape / graph keys name the configured mode
         with P.index_path():
             assert not P.f32_split()
         with P.parity_forward():                           # nesting is a no-op
             assert P.f32_split()
         assert P.f32_split()
-    assert P.is_bf16() and not P.f32_split() and P.get_precision() == "bf16"
+    assert P.is_bf16() and not P.f32_split() and P.get_precision() == "bf16" == P.configured_precision()
     with pytest.raises(RuntimeError):
         with P.parity_forward():
             raise RuntimeError("forward failed")
