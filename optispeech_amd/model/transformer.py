@@ -174,9 +174,11 @@ class Transformer(nn.Module):
         # from when the generator built it (generator.padding_mask leaves them on the tensor), a row sum otherwise
         tag = getattr(padding_mask, "_osp_lengths", None)
         if tag is not None and tag[0] == (-1 if padding_mask.is_inference() else padding_mask._version) and tag[1].is_cuda == x.is_cuda:
-            # (never more keys than the tensor has: lengths from an inconsistent batch, or a mask built for a longer T and sliced,
-            # would send osp_attn_softmax past the T2 keys -- a row sum could not exceed T, the raw lengths can)
-            klen = tag[1].clamp(max=x.shape[1])
+            # (raw lengths may exceed T -- an inconsistent batch, a mask built for a longer T and sliced -- where a row sum could
+            # not: every attention kernel clamps, kl = min(T, klen[b]) (csrc/attention.hip:20,134, attention_train.hip:190,303,407;
+            # tests/test_gpu_attention*.py::..._lengths_beyond_T), so no launch is spent on a clamp here: an ATen op would also
+            # poison the taped acoustic-model region)
+            klen = tag[1]
         else:
             klen = (~padding_mask).sum(1).to(torch.int64)
         return self.transformer(x, klen)

@@ -127,6 +127,33 @@ def test_fused_attention_forward_matches_the_unfused_path(B, T, H, dk):
     assert rel < 5e-3, rel
 
 
+def test_attention_kernels_clamp_lengths_beyond_T():
+    """the Transformer backbone hands the RAW lengths tensor to the attention kernels (model/transformer.py), and a
+    raw length may exceed the T of the tensor (an inconsistent batch, a mask built for a longer T and sliced) where a mask's row sum
+    could not.  Every kernel clamps -- kl = min(T, klen[b]) -- so lengths beyond T behave exactly as lengths == T: bit-identical
+    results, nothing read or written past the T keys (a canary row behind every operand stays untouched)."""
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    B, T, H, dk = 2, 70, 2, 64
+    C, Z = H * dk, B * H
+    q, k, v, dout = (torch.randn(B, T, C, generator=g).to(DEV) for _ in range(4))
+    at_T = torch.tensor([T, 33], device=DEV)
+    beyond = torch.tensor([T + 900, 33], device=DEV)
+    assert torch.equal(K.attn_fused_fwd(q, k, v, at_T, H), K.attn_fused_fwd(q, k, v, beyond, H))
+    o0, l0 = K.attn_train_fwd(q, k, v, at_T, H, 0.2, 99, 3)
+    o1, l1 = K.attn_train_fwd(q, k, v, beyond, H, 0.2, 99, 3)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    for a, b in zip(K.attn_train_bwd(q, k, v, o0, l0, dout, at_T, H, 0.2, 99, 3), K.attn_train_bwd(q, k, v, o0, l0, dout, beyond, H, 0.2, 99, 3)):
+        assert torch.equal(a, b)
+    S = torch.randn(Z + 1, T, T, generator=g).to(DEV)                  # one canary (T x T) block behind the scores
+    canary = S[Z].clone()
+    S0, S1 = S.clone(), S.clone()
+    P0, Pd0 = K.attn_softmax_fwd(S0[:Z], at_T, B, H, T, T, 0.125, 0.2, 5, 1)
+    P1, Pd1 = K.attn_softmax_fwd(S1[:Z], beyond, B, H, T, T, 0.125, 0.2, 5, 1)
+    assert torch.equal(P0, P1) and torch.equal(Pd0, Pd1)
+    assert torch.equal(S1[Z], canary)
+
+
 def test_attention_function_takes_the_fused_kernel_without_grad():
     from optispeech_amd import ops, precision
     precision.set_precision("bf16")
