@@ -425,6 +425,11 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
     dim3 grid((unsigned)cdiv(N, bn), (unsigned)cdiv(M, bm), (unsigned)batch);
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("OSP_GEMM_GLDS"); use_glds = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && Cin == 64 && N == 64 && bm == 128 && bn == 64 && taps > 1 &&
+        osp_launch_conv2d_panel(p, batch_in, stream)) {           // conv2d_panel.hip: the 64 <- 64 DiscriminatorR layers and their dgrads
+        OSP_LAUNCH_CHECK();
+        return OSP_OK;
+    }
     if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 64 && N > 8) {
         static int attr64 = 0;
         if (!attr64) {

@@ -341,3 +341,4 @@ extern __shared__ __attribute__((aligned(1024))) unsigned short glds_smem[];
 
 // host launchers of the kernels that live in other translation units
 int osp_launch_glds8(const GemmB& p, dim3 grid, bool early, hipStream_t stream);              // gemm_bf16_w8.hip
+int osp_launch_conv2d_panel(const GemmB& p, int64_t batch_in, hipStream_t stream);            // conv2d_panel.hip (1: taken, 0: declined)

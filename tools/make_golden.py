@@ -190,7 +190,7 @@ def to_t(batch):
     return {k: torch.from_numpy(v) for k, v in batch.items()}
 
 
-def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors=True, disc=None, dweights=None, gen=None):
+def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors=True, disc=None, dweights=None, gen=None, grad_probe=0):
     torch.manual_seed(0)
     if gen is None:
         gen = build_generator(c).train()                 # train mode, all dropout rates 0
@@ -288,6 +288,10 @@ def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors
             gnorm.append(p.grad.double().norm().item())
             if full_tensors and p.numel() <= 70000:
                 res["grad_g/" + k] = p.grad.numpy()
+            elif grad_probe:                             # strided probe of <= grad_probe elements (tools/make_golden_b32.py)
+                flat = p.grad.detach().reshape(-1)
+                res["grad_g/" + k] = flat[:: max(1, flat.numel() // grad_probe)][:grad_probe].numpy().copy()
+                res["gabs_g/" + k] = np.float64(flat.abs().max().item())
     res["grad_g_names"] = np.array(gnames)
     res["grad_g_norms"] = np.array(gnorm)
     res["grad_g_none"] = np.array(gnone)
@@ -304,7 +308,11 @@ def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors
         for k, p in disc.named_parameters():
             dn.append(k)
             dv.append(p.grad.double().norm().item())
-            if p.numel() <= 4096:
+            if grad_probe:
+                flat = p.grad.detach().reshape(-1)
+                res["grad_d/" + k] = flat[:: max(1, flat.numel() // grad_probe)][:grad_probe].numpy().copy()
+                res["gabs_d/" + k] = np.float64(flat.abs().max().item())
+            elif p.numel() <= 4096:
                 res["grad_d/" + k] = p.grad.numpy()
         res["grad_d_names"] = np.array(dn)
         res["grad_d_norms"] = np.array(dv)

@@ -5,7 +5,8 @@
 
   * ``full_b32_gan``   BASELINE configs[1]: B = 32, T_text <= 128, T_mel <= 800, ConvNeXt generator + the GAN step (G phase with the
                        frozen discriminators, D phase), dropout rates 0, fixed segment starts.  Stored: integer paths (durations,
-                       start indices: exact), the loss scalars, L2 / sum checksums of the big tensors, every gradient NORM.
+                       start indices: exact), the loss scalars, L2 / sum checksums of the big tensors, every gradient NORM and, per parameter, a strided
+                       probe of <= 64 gradient elements (round 6).
   * ``full_b64_synth`` BASELINE configs[4]: 64 sentences, T_text in 64..128, the duration head biased to ~6 frames / phoneme
                        (random-init weights predict ~1 frame): int64 durations, wav lengths, per-sentence
                        waveform checksums.
@@ -38,6 +39,28 @@ def _cks(a):
     return np.array([a.sum(), np.sqrt((a * a).sum())])
 
 
+PROBE = 64            # gradient elements kept per parameter
+
+
+def _grad_probes(g, res):
+    """Per parameter a strided probe of <= 64 gradient ELEMENTS (a norm cannot see a sign flip or a permutation
+    inside a tensor): flat[:: max(1, numel // 64)][:64], concatenated in the order of grad_{g,d}_names, f32, plus each tensor's
+    max |gradient| (the scale an element-wise error is read against)."""
+    for fam in ("g", "d"):
+        names = g["grad_%s_names" % fam].tolist()
+        vals, lens, amax = [], [], []
+        for k in names:
+            key = "grad_%s/%s" % (fam, k)
+            if key not in g.files:
+                lens.append(0); amax.append(0.0)
+                continue
+            pr = np.asarray(g[key], dtype=np.float32).reshape(-1)      # already the strided probe (run_generator_case(grad_probe=PROBE))
+            vals.append(pr); lens.append(pr.size); amax.append(float(g["gabs_%s/%s" % (fam, k)]))
+        res["grad_%s_probe" % fam] = np.concatenate(vals) if vals else np.zeros(0, np.float32)
+        res["grad_%s_probe_len" % fam] = np.array(lens, dtype=np.int64)
+        res["grad_%s_absmax" % fam] = np.array(amax, dtype=np.float64)
+
+
 def gan_case(name="full_b32_gan", B=32, seed=7788):
     t0 = time.time()
     disc, _ = MG.build_disc(seed + 11)
@@ -45,7 +68,7 @@ def gan_case(name="full_b32_gan", B=32, seed=7788):
     os.makedirs(tmp, exist_ok=True)
     keep_out, MG.OUT = MG.OUT, tmp
     try:
-        MG.run_generator_case(name, S.Cfg(), B, (96, 128), (600, 800), seed, with_disc=True, full_tensors=False, disc=disc)
+        MG.run_generator_case(name, S.Cfg(), B, (96, 128), (600, 800), seed, with_disc=True, full_tensors=False, disc=disc, grad_probe=PROBE)
     finally:
         MG.OUT = keep_out
     g = np.load(os.path.join(tmp, name + ".npz"), allow_pickle=False)
@@ -57,12 +80,13 @@ def gan_case(name="full_b32_gan", B=32, seed=7788):
                 res[k] = v
             res["cks_" + k] = _cks(v)                      # checksum of every regenerated input
             continue
-        if k.startswith("grad_d/") or k.startswith("grad_g/"):
-            continue                                       # norms only at this size
+        if k.startswith(("grad_d/", "grad_g/", "gabs_d/", "gabs_g/")):
+            continue                                       # norms + the strided probes (_grad_probes) at this size
         if k == "wav":
             res["wav_cks"] = _cks(v)
             continue
         res[k] = v
+    _grad_probes(g, res)
     res["disc_seed"] = np.int64(seed + 11)
     res["batch_args"] = np.array([B, 96, 128, 600, 800, seed + 1], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
@@ -103,7 +127,7 @@ def transformer_gan_case(name="full_b32_transformer_gan", B=32, seed=6655):
     os.makedirs(tmp, exist_ok=True)
     keep_out, MG.OUT = MG.OUT, tmp
     try:
-        MG.run_generator_case(name, c, B, (96, 128), (600, 800), seed, with_disc=True, full_tensors=False, disc=disc, gen=gen)
+        MG.run_generator_case(name, c, B, (96, 128), (600, 800), seed, with_disc=True, full_tensors=False, disc=disc, gen=gen, grad_probe=PROBE)
     finally:
         MG.OUT = keep_out
     g = np.load(os.path.join(tmp, name + ".npz"), allow_pickle=False)
@@ -115,12 +139,13 @@ def transformer_gan_case(name="full_b32_transformer_gan", B=32, seed=6655):
                 res[k] = v
             res["cks_" + k] = _cks(v)
             continue
-        if k.startswith("grad_d/") or k.startswith("grad_g/"):
+        if k.startswith(("grad_d/", "grad_g/", "gabs_d/", "gabs_g/")):
             continue
         if k == "wav":
             res["wav_cks"] = _cks(v)
             continue
         res[k] = v
+    _grad_probes(g, res)
     sd = gen.state_dict()
     res["state_names"] = np.array(list(sd.keys()))
     res["state_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
