@@ -31,8 +31,91 @@ __host__ __device__ __forceinline__ int64_t wgr_block_elems(int64_t N, int64_t t
     return ((N * taps * Cin + N + 3) / 4) * 4;
 }
 
+// ---- fused split reduction (round 6): the LAST workgroup to deliver a partial of an output tile adds the tile's splits up.
+// Every workgroup publishes its partial (plain stores, agent-scope release fence), then bumps the tile's arrival counter; the one
+// that reads splits - 1 resets the counter for the next launch, takes an acquire fence and sums the `splits` partial tiles in INDEX
+// order into dW (`+=`, oscale) -- the arithmetic of wgrad_split_reduce_kernel element by element, so the result is bit-identical
+// to the two-kernel form and independent of which workgroup happens to arrive last.  One launch per weight gradient instead of
+// two (53-63 launches of 6 us per training step).  Counters: one u32 per output tile, zero between launches, in a small buffer
+// the library keeps per launch stream (launches of a stream are ordered, so they can share it).
+template <int T>
+__device__ __forceinline__ void wgr_last_arriver_reduce(const WgradB& p, const float* __restrict__ ws, unsigned* __restrict__ cnt, int* lds_flag,
+                                                        int tile_id, int bz, int n0, int j, int c0, bool do_bias) {
+    const int tid = threadIdx.x;
+    __threadfence();                                         // release: this workgroup's partial tile is visible device-wide
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = atomicAdd(cnt + tile_id, 1u);
+        const int last = old == (unsigned)(p.splits - 1);
+        if (last) cnt[tile_id] = 0u;                         // every split has arrived: clean for the next launch on this stream
+        lds_flag[0] = last;
+    }
+    __syncthreads();
+    if (!lds_flag[0]) return;
+    __threadfence();                                         // acquire: the other splits' partial tiles
+    const int64_t blk = wgr_block_elems(p.N, p.taps, p.Cin);
+    const float* base = ws + (int64_t)bz * p.splits * blk;
+    float* dW = p.dW + (int64_t)bz * p.sWb;
+    constexpr int Q = T / 4;                                 // float4 per tile row
+    for (int e = tid; e < T * Q; e += 256) {
+        const int row = e / Q, c = c0 + (e - row * Q) * 4, n = n0 + row;
+        if (c >= p.Cin) continue;
+        const float* src = base + ((int64_t)n * p.taps + j) * p.Cin + c;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sp = 0;
+        for (; sp + 8 <= p.splits; sp += 8) {                // eight loads in flight, added in index order
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(src + (int64_t)(sp + q) * blk);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
+        }
+        for (; sp < p.splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sp * blk);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const float sc = p.oscale ? p.oscale[n] : 1.f;
+        float4* d = reinterpret_cast<float4*>(dW + (int64_t)n * p.ldw + (int64_t)j * p.Cin + c);
+        float4 o = *d;
+        o.x += sc * s.x; o.y += sc * s.y; o.z += sc * s.z; o.w += sc * s.w;
+        *d = o;
+    }
+    if (do_bias && tid < T) {
+        const int n = n0 + tid;
+        const float* src = base + (int64_t)p.N * p.taps * p.Cin + n;
+        float sacc = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp) sacc += src[(int64_t)sp * blk];
+        p.db[(int64_t)bz * p.sDb + n] += (p.oscale ? p.oscale[n] : 1.f) * sacc;
+    }
+}
+
+#include <mutex>
+#include <unordered_map>
+#define WGR_MAX_TILES 4096
+// arrival counters of the launch stream (nullptr: none could be made -- inside a capture, say -- the caller launches the reduce kernel)
+static unsigned* wgr_counters(hipStream_t stream) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, unsigned*> pool;
+    static int on = -1;
+    // OFF by default -- measured: the agent-scope release / acquire fences (an L2 write-back + invalidate per workgroup on this
+    // multi-XCD part) cost far more than the launch they save: 14.8 -> 19.6 ms per training step, the 128-tile ring kernel at 2 % of
+    // peak.  OSP_WGRAD_FUSED_REDUCE=1 takes it; tests/test_gpu_wgrad_ring.py keeps it bit-identical.
+    if (on < 0) { const char* e = getenv("OSP_WGRAD_FUSED_REDUCE"); on = (e && atoi(e) != 0) ? 1 : 0; }
+    if (!on) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find(stream);
+    if (it != pool.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    unsigned* q = nullptr;
+    if (hipMalloc(&q, WGR_MAX_TILES * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(q, 0, WGR_MAX_TILES * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(q); return nullptr; }
+    pool[stream] = q;
+    return q;
+}
+
 template <int T, int NST>
-__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradB p, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradB p, float* __restrict__ ws, unsigned* __restrict__ cnt) {
     constexpr int SK = 64;                                   // frames per slab
     constexpr int S = T / 8, RPI = 64 / S, NI = SK / RPI / 4, TI = T / 64;   // slots/row, rows/instruction, pairs/wave/slab
     constexpr int NL = 2 * NI;                               // DMA instructions per wave and slab
@@ -197,6 +280,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradB p, float* _
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bb[n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh] = accb[i][r];
         }
+        if (cnt) wgr_last_arriver_reduce<T>(p, ws, cnt, reinterpret_cast<int*>(smem), (bz * ntiles + n0 / T) * inner + within, bz, n0, j, c0, do_bias);
         return;
     }
     // one split: this workgroup owns its tile of dW.  All 16 loads of an accumulator block are requested before the first add
@@ -290,7 +374,7 @@ __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __
 // 2 e + lh -- exactly the eight floats lane half lh reads over two groups of four frame pairs below.  The bias gradient stays the
 // exact f32 sum of the A operand.
 template <bool AROW, bool SPLIT = false>
-__global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, float* __restrict__ ws, unsigned* __restrict__ cnt) {
     constexpr int T = 64, SK = 64, NI = SK / 16;            // pairs of DMA instructions per wave and slab
     constexpr int STAGE = 2 * SK * T + SK;                   // floats of one stage: dY slab, X slab, row factors
     float* smem = reinterpret_cast<float*>(wgr_smem);
@@ -433,6 +517,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_f32_kernel(WgradB p, floa
             }
         }
         if (do_bias && wn0 == 0 && lh == 0) wb[(int64_t)p.N * p.taps * p.Cin + n0 + wm0 + l31] = bsum;
+        if (cnt) wgr_last_arriver_reduce<64>(p, ws, cnt, reinterpret_cast<int*>(smem), (bz * ntiles + n0 / 64) * inner + within, bz, n0, j, c0, do_bias);
         return;
     }
     float* dW = p.dW + (int64_t)bz * p.sWb;
@@ -499,18 +584,19 @@ int osp_launch_wgrad_ring(WgradB& p, int64_t batch, float* ws, int64_t ws_bytes,
     if (sp > 1 && (reinterpret_cast<uintptr_t>(ws) & 15) != 0) return 0;
     p.chunk = (int)ch; p.splits = (int)sp; p.y_bytes = (unsigned)yb; p.x_bytes = (unsigned)xb;
     const dim3 g((unsigned)(tl * sp));
+    unsigned* cnt = (sp > 1 && tl <= WGR_MAX_TILES) ? wgr_counters(stream) : nullptr;
     if (T_ == 128) {
         osp_note_symbol("conv_wgrad_ring_kernel<128>");
-        if (nst128 == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 2>), g, dim3(256), 2 * 2 * 64 * 128 * 2, stream, p, ws);
-        else if (nst128 == 3) hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 3>), g, dim3(256), 3 * 2 * 64 * 128 * 2, stream, p, ws);
-        else hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 4>), g, dim3(256), 4 * 2 * 64 * 128 * 2, stream, p, ws);
+        if (nst128 == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 2>), g, dim3(256), 2 * 2 * 64 * 128 * 2, stream, p, ws, cnt);
+        else if (nst128 == 3) hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 3>), g, dim3(256), 3 * 2 * 64 * 128 * 2, stream, p, ws, cnt);
+        else hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 4>), g, dim3(256), 4 * 2 * 64 * 128 * 2, stream, p, ws, cnt);
     } else {
         osp_note_symbol("conv_wgrad_ring_kernel<64>");
-        if (nst64 == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<64, 2>), g, dim3(256), 2 * 2 * 64 * 64 * 2, stream, p, ws);
-        else if (nst64 == 3) hipLaunchKernelGGL((conv_wgrad_ring_kernel<64, 3>), g, dim3(256), 3 * 2 * 64 * 64 * 2, stream, p, ws);
-        else hipLaunchKernelGGL((conv_wgrad_ring_kernel<64, 4>), g, dim3(256), 4 * 2 * 64 * 64 * 2, stream, p, ws);
+        if (nst64 == 2) hipLaunchKernelGGL((conv_wgrad_ring_kernel<64, 2>), g, dim3(256), 2 * 2 * 64 * 64 * 2, stream, p, ws, cnt);
+        else if (nst64 == 3) hipLaunchKernelGGL((conv_wgrad_ring_kernel<64, 3>), g, dim3(256), 3 * 2 * 64 * 64 * 2, stream, p, ws, cnt);
+        else hipLaunchKernelGGL((conv_wgrad_ring_kernel<64, 4>), g, dim3(256), 4 * 2 * 64 * 64 * 2, stream, p, ws, cnt);
     }
-    if (sp > 1) {
+    if (sp > 1 && !cnt) {
         const int64_t E = N * taps * Cin, K = taps * Cin, tot = p.db ? E + N : E;
         hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3((unsigned)cdiv(tot, 1024), (unsigned)batch), dim3(256), 0, stream, ws, (int)sp,
                            (long long)blk, (long long)E, (int)K, make_fastdiv((unsigned)(K / 4)), p.oscale, p.dW, (long long)p.ldw, p.db,
@@ -575,13 +661,14 @@ static int conv_wgrad_f32_ws_impl(int split, const float* dY, int64_t ldy, const
     osp_note_flops(2.0 * M * taps * (double)Cin * N * batch);
     osp_note_bytes(4.0 * batch * ((double)M * N + (double)M * Cin + (double)N * taps * Cin));
     const dim3 g((unsigned)(tl * sp));
+    unsigned* cnt = (sp > 1 && tl <= WGR_MAX_TILES) ? wgr_counters(stream) : nullptr;
     constexpr int LDS = 2 * (2 * 64 * 64 + 64) * 4;
     if (split) {
-        if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true, true>), g, dim3(256), LDS, stream, p, ws);
-        else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false, true>), g, dim3(256), LDS, stream, p, ws);
-    } else if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true>), g, dim3(256), LDS, stream, p, ws);
-    else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false>), g, dim3(256), LDS, stream, p, ws);
-    if (sp > 1) {
+        if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true, true>), g, dim3(256), LDS, stream, p, ws, cnt);
+        else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false, true>), g, dim3(256), LDS, stream, p, ws, cnt);
+    } else if (arow) hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<true>), g, dim3(256), LDS, stream, p, ws, cnt);
+    else hipLaunchKernelGGL((conv_wgrad_ring_f32_kernel<false>), g, dim3(256), LDS, stream, p, ws, cnt);
+    if (sp > 1 && !cnt) {
         const int64_t blk = wgr_block_elems(N, taps, Cin);
         const int64_t E = N * taps * Cin, K = taps * Cin, tot = db ? E + N : E;
         hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3((unsigned)cdiv(tot, 1024), (unsigned)batch), dim3(256), 0, stream, ws, (int)sp,

@@ -140,3 +140,50 @@ def test_conv_wgrad_f32_ring_vs_f64(M, N, C, taps, T, arow, batch):
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "no atomics: two runs must agree bit for bit"
     assert ((dw.double() - w0.double()) - want_w).abs().max().item() <= 2e-5 * want_w.abs().max().item() + 1e-6
     assert ((db.double() - b0.double()) - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item() + 1e-6
+
+
+def _fused_reduce_cases(dev="cuda"):
+    """(dW, db) of a few split weight gradients -- bf16 ring (64- and 128-tiles, 2-D taps, batch of 2) and exact-f32 ring -- as CPU tensors."""
+    from optispeech_amd import kernels as K
+    out = []
+    for (M, N, C, taps, T, batch) in [(4096, 1024, 256, 1, 4096, 1), (2048, 384, 1152, 1, 2048, 2), (1024, 128, 192, 3, 128, 1), (3072, 64, 64, 5, 256, 1)]:
+        x, dy = _bf(batch, M, C, seed=40 + taps), _bf(batch, M, N, seed=41 + taps)
+        osc = torch.rand(N, generator=torch.Generator().manual_seed(6)) + 0.5
+        g = torch.Generator().manual_seed(9)
+        dw, db = torch.randn(batch, N, taps, C, generator=g).to(dev), torch.randn(batch, N, generator=g).to(dev)
+        K.conv_wgrad_bf16(dy.to(dev), x.to(dev), dw, db, M=M, Trows=T, Tin=T, n=N, cin=C, taps=taps, pad=taps // 2, oscale=osc.to(dev), batch=batch,
+                          strides=(M * N, M * C, N * taps * C, N) if batch > 1 else (0, 0, 0, 0))
+        out += [dw.cpu(), db.cpu()]
+    for (M, N, C, taps, T) in [(4096, 256, 256, 1, 4096), (2048, 64, 128, 3, 512)]:
+        x, dy = _bf(M, C, seed=50).float().to(dev), _bf(M, N, seed=51).float().to(dev)
+        arow = (torch.rand(M, generator=torch.Generator().manual_seed(8)) > 0.2).float().to(dev)
+        dw, db = torch.zeros(N, taps, C, device=dev), torch.zeros(N, device=dev)
+        ws = K.wgrad_workspace(N, taps, C, 1, dev)
+        K.call("osp_conv_wgrad_f32_ws", dy, N, x, C, M, T, N, C, taps, taps // 2, arow, None, dw, taps * C, db, 1, 0, 0, 0, 0, ws, ws.numel())
+        out += [dw.cpu(), db.cpu()]
+    torch.cuda.synchronize()
+    return out
+
+
+def test_fused_split_reduction_equals_the_reduce_kernel_bitwise():
+    """Round 6 (opt-in, OSP_WGRAD_FUSED_REDUCE=1: measured slower, csrc/wgrad_ring.hip): the last workgroup to deliver a partial of an
+    output tile adds the tile's splits up (wgr_last_arriver_reduce) instead of a second launch (wgrad_split_reduce_kernel, the
+    default).  Same partials, same index order, same `dW += oscale * sum`: the two forms must agree BIT FOR BIT, and the fused form
+    with itself whichever workgroup arrives last."""
+    import os
+    import subprocess
+    import sys
+    ref = _fused_reduce_cases()                                  # this process: the default two-kernel form
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_wgrad_ring import _fused_reduce_cases\n"
+            "torch.save(_fused_reduce_cases(), sys.argv[1])\n") % root
+    outs = []
+    for k in range(2):
+        out = "/tmp/osp_wgrad_fused_%d.pt" % k
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, OSP_WGRAD_FUSED_REDUCE="1"), timeout=900)
+        outs.append(torch.load(out))
+    assert all(torch.equal(x, y) for x, y in zip(*outs)), "fused reduction differs between two runs"
+    assert len(ref) == len(outs[0])
+    for i, (x, y) in enumerate(zip(outs[0], ref)):
+        assert torch.equal(x, y), (i, (x - y).abs().max().item())

@@ -271,12 +271,19 @@ def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors
     if with_disc:
         for p in disc.parameters():
             p.requires_grad_(False)
-        adv, logs = _forward_gen_nomel(disc, wav, out["wav_hat"])
+        adv, logs, mr_term = _forward_gen_nomel(disc, wav, out["wav_hat"], want_mr=True)
         loss_g = loss_g + adv
         res["gen_adv_loss"] = adv.detach().numpy()
         for k, v in logs.items():
             res["genlog_" + k] = np.float64(v)
     gen.zero_grad()
+    g_mr = None
+    if with_disc and grad_probe:
+        # the multi-resolution STFT term's own gradient (taken before the backward, graph retained): its log-magnitude part is
+        # ill-conditioned at a random-init state (1 / |X| at near-empty bins), so that the element-wise probes of the VOCODER are
+        # stored for the total gradient minus this term -- the adversarial + feature-matching gradient -- as well
+        vp = [(k, p) for k, p in gen.named_parameters() if k.startswith("vocoder.")]
+        g_mr = dict(zip([k for k, _ in vp], torch.autograd.grad(mr_term, [p for _, p in vp], retain_graph=True, allow_unused=True)))
     loss_g.backward()
     res["loss_g"] = loss_g.detach().numpy()
     gnames, gnorm, gnone = [], [], []
@@ -292,6 +299,10 @@ def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors
                 flat = p.grad.detach().reshape(-1)
                 res["grad_g/" + k] = flat[:: max(1, flat.numel() // grad_probe)][:grad_probe].numpy().copy()
                 res["gabs_g/" + k] = np.float64(flat.abs().max().item())
+                if g_mr is not None and g_mr.get(k) is not None:
+                    rest = (p.grad.detach() - g_mr[k]).reshape(-1)
+                    res["grad_gns/" + k] = rest[:: max(1, rest.numel() // grad_probe)][:grad_probe].numpy().copy()
+                    res["gabs_gns/" + k] = np.float64(rest.abs().max().item())
     res["grad_g_names"] = np.array(gnames)
     res["grad_g_norms"] = np.array(gnorm)
     res["grad_g_none"] = np.array(gnone)
@@ -322,7 +333,7 @@ def run_generator_case(name, c, B, tt_rng, tm_rng, seed, with_disc, full_tensors
     return gen, weights
 
 
-def _forward_gen_nomel(disc, wav, wav_hat):
+def _forward_gen_nomel(disc, wav, wav_hat, want_mr=False):
     """VocosDiscriminator.forward_gen with the (inert torchaudio) mel term skipped."""
     _, g_mp, fr_mp, fg_mp = disc.multiperioddisc(y=wav, y_hat=wav_hat)
     _, g_mr, fr_mr, fg_mr = disc.multiresddisc(y=wav, y_hat=wav_hat)
@@ -334,8 +345,9 @@ def _forward_gen_nomel(disc, wav, wav_hat):
     sc, mag = disc.mr_stft_loss(wav_hat, wav)
     mr = (sc + mag) * disc.lambda_mr_stft
     loss = l_mp + l_mr * disc.loss_coeffs.lambda_mrd + fm_mp + fm_mr * disc.loss_coeffs.lambda_mrd + mr
-    return loss, dict(loss_gen_mp=l_mp.item(), loss_gen_mrd=l_mr.item(), loss_fm_mp=fm_mp.item(),
-                      loss_fm_mrd=fm_mr.item(), mr_stft_loss=mr.item(), sc=sc.item(), mag=mag.item())
+    logs = dict(loss_gen_mp=l_mp.item(), loss_gen_mrd=l_mr.item(), loss_fm_mp=fm_mp.item(),
+                loss_fm_mrd=fm_mr.item(), mr_stft_loss=mr.item(), sc=sc.item(), mag=mag.item())
+    return (loss, logs, mr) if want_mr else (loss, logs)
 
 
 def build_disc(seed):

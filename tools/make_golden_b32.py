@@ -46,8 +46,8 @@ def _grad_probes(g, res):
     """Per parameter a strided probe of <= 64 gradient ELEMENTS (a norm cannot see a sign flip or a permutation
     inside a tensor): flat[:: max(1, numel // 64)][:64], concatenated in the order of grad_{g,d}_names, f32, plus each tensor's
     max |gradient| (the scale an element-wise error is read against)."""
-    for fam in ("g", "d"):
-        names = g["grad_%s_names" % fam].tolist()
+    for fam in ("g", "d", "gns"):                             # gns: generator gradient WITHOUT the MR-STFT term (vocoder parameters only)
+        names = g["grad_%s_names" % ("g" if fam == "gns" else fam)].tolist()
         vals, lens, amax = [], [], []
         for k in names:
             key = "grad_%s/%s" % (fam, k)
@@ -80,7 +80,7 @@ def gan_case(name="full_b32_gan", B=32, seed=7788):
                 res[k] = v
             res["cks_" + k] = _cks(v)                      # checksum of every regenerated input
             continue
-        if k.startswith(("grad_d/", "grad_g/", "gabs_d/", "gabs_g/")):
+        if k.startswith(("grad_d/", "grad_g/", "gabs_d/", "gabs_g/", "grad_gns/", "gabs_gns/")):
             continue                                       # norms + the strided probes (_grad_probes) at this size
         if k == "wav":
             res["wav_cks"] = _cks(v)
@@ -139,7 +139,7 @@ def transformer_gan_case(name="full_b32_transformer_gan", B=32, seed=6655):
                 res[k] = v
             res["cks_" + k] = _cks(v)
             continue
-        if k.startswith(("grad_d/", "grad_g/", "gabs_d/", "gabs_g/")):
+        if k.startswith(("grad_d/", "grad_g/", "gabs_d/", "gabs_g/", "grad_gns/", "gabs_gns/")):
             continue
         if k == "wav":
             res["wav_cks"] = _cks(v)
