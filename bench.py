@@ -157,7 +157,7 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="time the hipGraph replay of the step (OptiSpeech.graph_steps) as the headline instead of the eager multi-stream "
                          "step.  Off by default: on ROCm 7.2 a captured multi-stream graph executes its branches almost serially "
-                         "(29.9 vs 24.5 ms per step, tools/graph_probe.py), so the eager schedule is the faster one; the replay is "
+                         "(29.9 vs 24.5 ms per step, tools/graph_probe.py (git history)), so the eager schedule is the faster one; the replay is "
                          "still measured and reported as `graph_replay_step`")
     ap.add_argument("--graph-segments", action="store_true",
                     help="replay the acoustic model / vocoder forward and backward from captured hipGraph segments inside the eager "

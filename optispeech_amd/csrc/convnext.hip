@@ -159,7 +159,7 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
     };
 #define L(N, F) do { const int R_ = pick_runs(F); hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * (int64_t)R_, 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, (int)C, R_); } while (0)
     static int fr1 = -1;
-    if (fr1 < 0) { fr1 = 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
+    if (fr1 < 0) { fr1 = 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py (git history)): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
     if (nch == 1) { if (fr1 == 8) L(1, 8); else if (fr1 == 4) L(1, 4); else L(1, 16); } else if (nch == 2) L(2, 8); else if (nch == 3) L(3, 4); else L(4, 4);
 #undef L
     OSP_LAUNCH_CHECK();

@@ -458,7 +458,7 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         if (w8 != 0 && N >= 256 && t256 >= (w8 == 1 ? 128 : w8_min) && (w8 == 1 || taps * Cin >= 2304)) {
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
             static int early = -1;
-            if (early < 0) { early = 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py)
+            if (early < 0) { early = 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py (git history))
             return osp_launch_glds8(p, g8, early != 0, stream);
         }
         static int attr_done = 0;

@@ -214,7 +214,7 @@ __device__ __forceinline__ bool gemm_bf16_rows_ok(const GemmB& pp) {
     // kinds that read nothing of the output's shape: the row domain still wins on instruction count -- one ds_write_b32 per
     // accumulator, then 8 channels per lane (bias add, activation, pack, ONE 16-byte store, row geometry once per 8 values)
     // against ~12 VALU + a DPP swap + a 4-byte LDS store per value in the MFMA layout.  The 256x256 tile's epilogue was ~10 of
-    // the 21.7 us a one-slab launch takes (tools/epi_probe.py).
+    // the 21.7 us a one-slab launch takes (tools/epi_probe.py (git history)).
     if constexpr (EPI == BEPI_NONE || EPI == BEPI_RELU || EPI == BEPI_LRELU || EPI == BEPI_MASK) return true;
     if constexpr (EPI == BEPI_SCALE_RES_MASK)                  // ConvNeXt pwconv2: f32 residual rows in, optional z rows out
         return pp.res && aligned16(pp.res) && (pp.ldr & 7) == 0 && ((pp.sXb * 4) & 15) == 0 &&

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
 // (A producer / consumer variant of this kernel -- 8 waves, two per SIMD: four waves run phase 1 + GELU and hand the bf16 hidden tile
 // to four phase-2 waves through LDS, GELU deferred by a chunk so that it runs under MFMAs -- was built and measured in round 4:
 // correct on the first run, but the same 3.5 (C = 256) / 4.5 us (C = 384) per 128 hidden units as this kernel for a workgroup that
-// has its CU to itself (tools/probes/mlp_fixed_cost.py), against 2.0 / 3.0 us of MFMA time.  Two designs with opposite issue
+// has its CU to itself (tools/probes/mlp_fixed_cost.py (git history)), against 2.0 / 3.0 us of MFMA time.  Two designs with opposite issue
 // structure and the same chunk time: the limiter is not the instruction stream of a wave.  Removed from the library; its source is kept, unbuilt, in tools/probes/mlp_pc_kernel.hip.)
 
 // f32 (N, K) -> bf16 (N, K) with every group of 16 along K stored as [0-3, 8-11, 4-7, 12-15] (the phase-2 operand order above)

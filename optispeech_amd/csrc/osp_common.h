@@ -118,7 +118,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // erf-GELU for epilogues whose RESULT IS ROUNDED TO bf16 (the performance mode's I-wide intermediates): Abramowitz-Stegun 7.1.26,
 // |erf error| <= 1.5e-7 -- four orders below the bf16 unit round-off -- on one v_rcp_f32 and one v_exp_f32 plus 8 FMAs instead of the
 // ~50-instruction branchy library erff.  At the decoder shape (26 M GELUs per block and direction) the library call alone
-// was 37 of the 87 us of the pwconv1 launch (tools/convnext_pw_probe.py).  Phi(x) is formed without cancellation on the
+// was 37 of the 87 us of the pwconv1 launch (tools/convnext_pw_probe.py (git history)).  Phi(x) is formed without cancellation on the
 // negative side (Phi(x) = q / 2, x < 0; 1 - q / 2 otherwise; q = poly(t) exp(-x^2 / 2)); exp(-x^2 / 2) is shared with the pdf.
 __device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& e) {
     const float ax = fabsf(x) * 0.70710678118654752440f;

@@ -129,7 +129,7 @@ class GradReducer:
             # gloo on device tensors = the single-GPU test aid (OSP_DP_BACKEND=gloo).  The buffer is staged through the host HERE,
             # synchronously: gloo's own device path (private streams, worker threads) produced rare wrong slices (1e-3 of a
             # sub-discriminator's gradients, replicas still identical) when the two ranks shared one GPU, while the same step is
-            # reproducible to 1e-7 run to run in one process (tools/determinism_probe.py, also under contention).
+            # reproducible to 1e-7 run to run in one process (tools/determinism_probe.py (git history), also under contention).
             torch.cuda.synchronize()
             host = flat_grad.detach().to("cpu")
             with around_host_collective():

@@ -264,7 +264,7 @@ def conv_wgrad(dy, x, dw, db=None, *, T=None, taps=1, pad=0, arow=None, oscale=N
         if _WGRAD_CAST and batch == 1 and N % 64 == 0 and cin % 64 == 0 and _dense_rows(dy) and _dense_rows(x):
             # f32 activations: one bf16 copy of each operand (the row factor folded into dy's), then the ring kernel -- the register-staged
             # f32 loader of the tile-per-tap kernel rounds to bf16 at the same place (after the row factor), so the products are
-            # the same; 34 -> ~20 us per launch at the predictor shapes (tools/probes/wgrad_calls.py)
+            # the same; 34 -> ~20 us per launch at the predictor shapes (tools/probes/wgrad_calls.py (git history))
             conv_wgrad_bf16(_bf16_rows(dy, arow), _bf16_rows(x), dw, db, M=M, Trows=T, Tin=T, n=N, cin=cin, taps=taps, pad=pad, oscale=oscale)
             return
         call("osp_conv_wgrad_bf16", dy, 0, dy.stride(-2), x, 0, x.stride(-2), M, T, T, N, cin, taps, pad, 1, arow, oscale, dw,

@@ -9,7 +9,7 @@ real concurrency: shifting the assignment by one stream moved the step between 1
 
 This module makes the assignment explicit and deterministic: a pool of streams is created up front, in a fixed order, and each is
 bound to its hardware queue right away (one trivial launch); pool entry i sits on lane i mod 4.  A logical stream asks for a lane by
-name; ``OSP_LANES="name:lane,..."`` overrides the table (tools/lane_search.py uses that).  Names: voc, ctc, wg_main, wg_voc, wg_other,
+name; ``OSP_LANES="name:lane,..."`` overrides the table (tools/lane_search.py (git history) uses that).  Names: voc, ctc, wg_main, wg_voc, wg_other,
 p0..p4 (period discriminators 2, 3, 5, 7, 11), r0..r2 (resolution discriminators), spec, dphase.
 """
 import os

@@ -361,7 +361,7 @@ class OptiSpeech(nn.Module):
             (st.loss_g / st.scale).backward()
         st.loss_g = None
         self._g_done_event = torch.cuda.current_stream().record_event() if _D_AFTER_G else None
-        if _SYNC_AFTER_G:                                  # diagnostic (tools/race2.sh): drain the device between the phases
+        if _SYNC_AFTER_G:                                  # diagnostic (tools/race2.sh (git history)): drain the device between the phases
             torch.cuda.synchronize()
 
     def _stage_d(self, st, batch):

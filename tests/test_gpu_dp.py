@@ -210,7 +210,7 @@ def test_two_rank_training_step_equals_mean_of_single_rank_gradients(graph):
     """ONE attempt, strict.  Both ranks share ONE GPU here (RCCL needs a GPU per rank, the box has one).  Two PROCESSES computing
     on one MI355X of this pool at the same time is not a configuration the product runs in, and it makes FFT results come out
     different in a few percent of the repetitions -- rocFFT behind torch.stft as well as this package's STFT kernel, also in a
-    stand-alone HIP program with no torch in it, never in a process that has the GPU to itself (tools/probes/shared_gpu_all.sh,
+    stand-alone HIP program with no torch in it, never in a process that has the GPU to itself (tools/probes/shared_gpu_all.sh (git history),
     profiles/r03_shared_gpu_probe.txt).  So the two ranks take TURNS on the GPU (_yield_turn: a rank
     hands the GPU over, drained, whenever it blocks in a gloo collective): every kernel of either rank then runs with the GPU to
     itself, and the comparison is strict again -- a single attempt, no retry."""
