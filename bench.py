@@ -26,8 +26,8 @@ B, T_TEXT, T_MEL = 32, 128, 800
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r05_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/): TCC traffic / L2 hit
-PMC_MFMA = "r05_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM pass (tools/pmc_mfma.sh): matrix-pipe busy share per symbol
+PMC_SUMMARY = "r06_pmc_glds.json"         # committed summary of the separate rocprofv3 --pmc pass (profiles/): TCC traffic / L2 hit
+PMC_MFMA = "r06_pmc_mfma_busy.json"       # committed summary of the SQ / GRBM pass (tools/pmc_mfma.sh): matrix-pipe busy share per symbol
 
 
 def _pmc_file(name):
@@ -615,7 +615,7 @@ def main():
     calls1 = (_oslib.lib().ncalls, _tape0.stats().get("calls_replayed", 0))
     abi_calls = {"direct": (calls1[0] - calls0[0]) / a.steps, "replayed_from_tapes": (calls1[1] - calls0[1]) / a.steps,
                  "note": "C-ABI entry-point calls per timed step (almost all are one kernel launch; stream hand-overs and memsets are calls "
-                         "too); the rocprofv3 launch count of a step, ATen / runtime kernels included, is in profiles/r05_step_kernel_stats.csv (946: the split reductions and bf16 operand copies of the weight gradients are launches of their own)"}
+                         "too); the rocprofv3 launch count of a step, ATen / runtime kernels included, is in profiles/r06_step_kernel_stats.csv"}
     comm_exposed = None
     if world > 1:
         # per rank: how long the step's streams stood still in GradReducer.wait() (generator gradients before AdamW(G), discriminator
