@@ -33,8 +33,15 @@ __device__ unsigned long long* osp_panel_dbg = nullptr;
 #define PANEL_DBG_EVENTS 72
 #define PT_MARK() do { if constexpr (TIMING) { if (dbg && dbg_n < PANEL_DBG_EVENTS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) dbg[dbg_n] = t_; ++dbg_n; } } } while (0)
 
-template <int SW, bool TIMING = false>
-__global__ __launch_bounds__(256, 3) void conv2d_panel_n64_kernel(const GemmB pin) {
+// PIPE (second form, OSP_N64_PANEL=2): the loop software-pipelined inside each wave -- the fragments of tap t + 1 are read while tap t's
+// MFMAs issue (two fragment register sets, the tap loop unrolled by two), on a ring of FOUR weight stages so that a tap's weights were
+// published one barrier before the tap that prefetches them: LDS reads, MFMAs and the LDS-DMA wait of a wave overlap instead of
+// following each other (section 10.1's timeline: 0.9 k + 0.45 k + 0.37 k + 0.45 k clocks per tap, serial).  ~200 VGPRs and 68 KB of
+// LDS: two workgroups per CU.
+#define PANEL_LDS_PIPE ((PANEL_ROWS * TBK + 4 * 64 * TBK) * 2)
+
+template <int SW, bool TIMING = false, bool PIPE = false>
+__global__ __launch_bounds__(256, PIPE ? 2 : 3) void conv2d_panel_n64_kernel(const GemmB pin) {
     const TileCtx tc = grid_tile_ctx();
     const GemmB pp = gemm_select_phase(pin, tc.z);
     constexpr int BM = 128, PR = PANEL_ROWS, HALF = PR / 2, NPR = PR / 32;      // NPR: panel rows staged per thread
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_panel_n64_kernel(const GemmB pi
     const int m0 = mb_ * BM;
     if (m0 >= pp.M) return;                                     // (a fused-dgrad phase with fewer rows than the grid's maximum)
     unsigned short* Pn = glds_smem;                             // [PR][64]   physical rows
-    unsigned short* Bs = glds_smem + PR * TBK;                  // [2][64][64]
+    unsigned short* Bs = glds_smem + PR * TBK;                  // [2 | 4][64][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
     const int l31 = lane & 31, lh = lane >> 5, rsub = lane >> 3, pslot = lane & 7;
@@ -133,6 +140,77 @@ __global__ __launch_bounds__(256, 3) void conv2d_panel_n64_kernel(const GemmB pi
     // At the last tap of a kernel row the panel is free as soon as every wave holds its A fragments (one barrier behind the reads):
     // the next row's panel is requested there and lands under that tap's MFMAs.
     const int taps = pp.taps;
+    if constexpr (PIPE) {
+        // tap t reads its weights from stage t & 3; stage (t + 3) & 3 is requested during tap t (it held tap t - 1's weights, whose
+        // fragments every wave read during tap t - 2) and published by the barrier that ends tap t + 1.
+        bf16x8 A0[4][2], A1[4][2], B0[4], B1[4];
+        auto load_a = [&](bf16x8 (&a)[4][2], int kw_) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = p_base[i] + tsw * kw_;
+                const int q = SW == 2 ? (p >> 1) + (p & 1) * HALF : p;
+                const int row = q * TBK, sw_ = (q >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks][i] = *reinterpret_cast<const bf16x8*>(Pn + row + (((2 * ks + lh) ^ sw_) << 3));
+            }
+        };
+        auto load_b = [&](bf16x8 (&b)[4], int slot) {
+            const unsigned short* bs = Bs + slot * 64 * TBK;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const bf16x8*>(bs + b_frag + (((2 * ks + lh) ^ b_sw) << 3));
+        };
+        // loop state in plain scalars (a lambda capturing them by reference put them in scratch: VGPR conditions, exec-mask branches and a
+        // `vmcnt(0)` for every scratch read -- i.e. no LDS-DMA in flight across anything)
+        int kh = 0, kw = 0, t = 0;                               // (kh, kw) of tap t
+        int kh3 = 0, kw3 = 0;                                    // (kh, kw) of tap t + 3: the next weight stage to request
+#define PANEL_ADV(h, w) do { if (++(w) == KW) { (w) = 0; ++(h); } } while (0)
+        stage_panel(0);
+        stage_b(0, 0, 0);
+        PANEL_ADV(kh3, kw3);
+        if (taps > 1) stage_b(kh3, kw3, 1);
+        PANEL_ADV(kh3, kw3);
+        if (taps > 2) stage_b(kh3, kw3, 2);
+        PANEL_ADV(kh3, kw3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_a(A0, 0);
+        load_b(B0, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
+#define PANEL_TAP(ca, cb, na, nb)                                                                                               \
+        {                                                                                                                       \
+            const bool has_next = t + 1 < taps, last_kw = kw + 1 == KW;                                                         \
+            const bool new_panel = has_next && last_kw;                                                                         \
+            if (t + 3 < taps) stage_b(kh3, kw3, (t + 3) & 3);                                                                   \
+            PANEL_ADV(kh3, kw3);                                                                                                \
+            if (new_panel) {                                                                                                    \
+                /* this tap's A fragments were read one tap ago (KW >= 2) -- every wave passed a barrier since: the panel is free */ \
+                if (KW == 1) __syncthreads();                   /* (KW = 1: they were read just behind the last barrier) */     \
+                stage_panel(kh + 1);                                                                                            \
+            }                                                                                                                   \
+            if (has_next) load_b(nb, (t + 1) & 3);                                                                              \
+            if (has_next && !last_kw) load_a(na, kw + 1);                                                                       \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[ks][i], cb[ks], acc[i][0], 0, 0, 0);                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                  \
+            /* the stage requested THIS tap may stay in flight (two LDS-DMA instructions per wave); a panel must have landed */  \
+            if (new_panel || t + 3 >= taps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                               \
+            __syncthreads();                                                                                                    \
+            if (new_panel) { load_a(na, 0); __builtin_amdgcn_s_waitcnt(0xc07f); }   /* first tap of the next kernel row */      \
+            if (last_kw) { kw = 0; ++kh; } else ++kw;                                                                           \
+            ++t;                                                                                                                \
+        }
+        while (t < taps) {
+            PANEL_TAP(A0, B0, A1, B1)
+            if (t < taps) PANEL_TAP(A1, B1, A0, B0)
+        }
+#undef PANEL_TAP
+#undef PANEL_ADV
+        constexpr int SPp = 32 * 1 + 8;
+        gemm_bf16_epilogue<2, 1>(pp, acc, m0, 0, wm0, wn0, lane, 0, glds_smem + wave * 64 * SPp);
+        return;
+    }
     int kh = 0, kw = 0, buf = 0;
     PT_MARK();                                                  // 1: maps done
     stage_panel(0);
@@ -198,13 +276,15 @@ int osp_launch_conv2d_panel(const GemmB& p, int64_t batch_in, hipStream_t stream
     // traffic).  OSP_N64_PANEL=1 takes it (read per call: tests/test_gpu_conv2d_panel.py switches it on in-process).
     static int attrs = 0;
     const char* e = getenv("OSP_N64_PANEL");
-    const int on = (e && atoi(e) != 0) ? 1 : 0;
+    const int on = e ? atoi(e) : 0;                              // 1: the barrier-per-tap form, 2: the software-pipelined form (PIPE)
     if (on && !attrs) {
         attrs = 1;
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_panel_n64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_panel_n64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_panel_n64_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS);
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_panel_n64_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_panel_n64_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_PIPE);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_panel_n64_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_PIPE);
     }
     if (!on || batch_in != 1) return 0;
     if (!(p.N == 64 && p.Cin == 64 && p.a_bf16 && p.b_bf16 && p.sBk == 1 && !p.a_rowscale && (p.a_step == 1 || p.a_step == 2))) return 0;
@@ -241,6 +321,11 @@ int osp_launch_conv2d_panel(const GemmB& p, int64_t batch_in, hipStream_t stream
             const long long hdr[4] = {(long long)grid.y, (long long)np, (long long)p.a_step, (long long)p.taps};
             fwrite(hdr, sizeof(hdr), 1, f); fwrite(host.data(), 1, nbytes, f); fclose(f);
         }
+        return 1;
+    }
+    if (on == 2) {
+        if (p.a_step == 2) hipLaunchKernelGGL((conv2d_panel_n64_kernel<2, false, true>), grid, dim3(256), PANEL_LDS_PIPE, stream, p);
+        else hipLaunchKernelGGL((conv2d_panel_n64_kernel<1, false, true>), grid, dim3(256), PANEL_LDS_PIPE, stream, p);
         return 1;
     }
     if (p.a_step == 2) hipLaunchKernelGGL(conv2d_panel_n64_kernel<2>, grid, dim3(256), PANEL_LDS, stream, p);

@@ -19,12 +19,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True)
-def _panel_on():
-    """The panel kernel is opt-in (OSP_N64_PANEL=1; the launcher reads the variable per call)."""
+@pytest.fixture(autouse=True, params=["1", "2"], ids=["per-tap-barrier", "pipelined"])
+def _panel_on(request):
+    """The panel kernel is opt-in (OSP_N64_PANEL=1: a barrier per tap; 2: the software-pipelined loop on a four-stage weight ring; the
+    launcher reads the variable per call)."""
     import os
     keep = os.environ.get("OSP_N64_PANEL")
-    os.environ["OSP_N64_PANEL"] = "1"
+    os.environ["OSP_N64_PANEL"] = request.param
     yield
     if keep is None:
         os.environ.pop("OSP_N64_PANEL", None)
