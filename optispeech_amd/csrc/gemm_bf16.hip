@@ -14,6 +14,11 @@
 // Sources whose reduction index is NOT the contiguous one (dgrad weights, both wgrad operands) go through a
 // transposing loader: 8 strided rows x float4 per thread, packed to k-contiguous 16-byte LDS slots.
 #include "gemm_bf16_glds.h"
+// phased 8-wave kernel (gemm_bf16_w8p.hip); variant 1: priority flips around the MFMA clusters, 2: none
+int osp_launch_glds8p(const GemmB& p, dim3 grid, int variant, hipStream_t stream);
+#ifndef OSP_W8P_DEFAULT
+#define OSP_W8P_DEFAULT 0
+#endif
 
 // (the direct-to-LDS body: gemm_bf16_glds.h)
 
@@ -457,6 +462,9 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         // (K = 640, N = 512: the 256x256 prologue / epilogue is not amortised), neutral at half batch (too few tiles: not taken)
         if (w8 != 0 && N >= 256 && t256 >= (w8 == 1 ? 128 : w8_min) && (w8 == 1 || taps * Cin >= 2304)) {
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
+            // phased main loop (gemm_bf16_w8p.hip): OSP_GEMM_W8P = 0 lock-step kernel / 1 phased / 2 phased without priority flips
+            // (read per call: tests and probes switch it in-process)
+            { const char* e = getenv("OSP_GEMM_W8P"); const int ph = e ? atoi(e) : OSP_W8P_DEFAULT; if (ph) return osp_launch_glds8p(p, g8, ph, stream); }
             static int early = -1;
             if (early < 0) { early = 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py (git history))
             return osp_launch_glds8(p, g8, early != 0, stream);
