@@ -816,7 +816,9 @@ def main():
         # Every matrix-core symbol of the step, timed in the 3 serialised steps above and classified by the library's own
         # dispatcher (KernelTimer); the roofline object is the symbol with the LARGEST TOTAL TIME, the others are listed beside it.
         DESCR = {
-                 "conv_gemm_bf16_glds8e_kernel": "8 waves, 256x256 tiles, direct-to-LDS: DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
+                 "conv_gemm_bf16_glds8e_kernel": "8 waves, 256x256 tiles, direct-to-LDS, lock-step loop (OSP_GEMM_W8P=0): DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
+                 "conv_gemm_bf16_glds8q_kernel": "8 waves, 256x256 tiles, direct-to-LDS, two wave groups half a phase apart, rotating LDS-DMA unit schedule (round 6): DiscriminatorP 512->1024 / 1024->1024 forward + fused-phase dgrad",
+                 "conv_gemm_bf16_glds8p_kernel": "as glds8q with 64-bit operand pointers (operands >= 2 GiB)",
                  "conv_gemm_bf16_glds_kernel": "4 waves, 128x128 tiles, direct-to-LDS: the remaining MPD / MRD conv-GEMM forward + dgrad launches (N >= 128)",
                  "conv_gemm_bf16_glds_n64_kernel": "4 waves, 128x64 tiles, direct-to-LDS: the 64-channel DiscriminatorR layers",
                  "conv_wgrad_bf16_tr8_kernel": "8 waves, 256x256 weight-gradient tiles (transposed LDS reads): DiscriminatorP 512->1024 / 1024->1024",

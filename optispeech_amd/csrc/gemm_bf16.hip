@@ -17,7 +17,7 @@
 // phased 8-wave kernel (gemm_bf16_w8p.hip); variant 1: priority flips around the MFMA clusters, 2: none
 int osp_launch_glds8p(const GemmB& p, dim3 grid, int variant, hipStream_t stream);
 #ifndef OSP_W8P_DEFAULT
-#define OSP_W8P_DEFAULT 0
+#define OSP_W8P_DEFAULT 2
 #endif
 
 // (the direct-to-LDS body: gemm_bf16_glds.h)
@@ -449,21 +449,19 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
     }
     if (use_glds && fast && sBk == 1 && a_bf16 && b_bf16 && (Cin % TBK == 0) && bm == 128 && bn == 128) {
         // 8-wave 256x256 tiles when they still give every CU work: OSP_GEMM_W8 = 0 (never) / 1 (whenever >= 1 tile per 2 CUs) /
-        // unset: the measured crossover (tools/gemm_w8_probe.py)
-        static int w8 = -2;
-        static int64_t w8_min = 0;
-        if (w8 == -2) {
-            const char* e = getenv("OSP_GEMM_W8"); w8 = e ? atoi(e) : -1;
-            { const char* m = getenv("OSP_GEMM_W8_MIN"); w8_min = m ? atoi(m) : 160; }
-        }
+        // unset: the measured crossover (tools/gemm_w8_probe.py (git history); tools/probes/w8p_probe.py)
+        // (both read per call: tests and probes switch them in-process)
+        int w8 = -1; int64_t w8_min = 160;
+        { const char* e = getenv("OSP_GEMM_W8"); if (e) w8 = atoi(e); const char* m = getenv("OSP_GEMM_W8_MIN"); if (m) w8_min = atoi(m); }
         const int64_t t256 = cdiv(M, 256) * cdiv(N, 256) * batch;
-        // measured (tools/gemm_w8_probe.py, profiles/r02_gemm_w8_probe.txt): +23..30 % where the reduction is long (K >= 2560: the
+        // measured (round 2, profiles/r02_gemm_w8_probe_*.txt): +23..30 % where the reduction is long (K >= 2560: the
         // 512->1024 and 1024->1024 DiscriminatorP layers at M ~ 13k: 760 -> 950-990 TFLOP/s), -20 % on short-K / narrow layers
         // (K = 640, N = 512: the 256x256 prologue / epilogue is not amortised), neutral at half batch (too few tiles: not taken)
-        if (w8 != 0 && N >= 256 && t256 >= (w8 == 1 ? 128 : w8_min) && (w8 == 1 || taps * Cin >= 2304)) {
+        if (w8 != 0 && N >= 256 && t256 >= (w8 == 2 ? 1 : w8 == 1 ? 128 : w8_min) && (w8 >= 1 || taps * Cin >= 2304)) {    // OSP_GEMM_W8 = 2: any size (tests)
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
-            // phased main loop (gemm_bf16_w8p.hip): OSP_GEMM_W8P = 0 lock-step kernel / 1 phased / 2 phased without priority flips
-            // (read per call: tests and probes switch it in-process)
+            // phased main loops: OSP_GEMM_W8P = 0 lock-step kernel (gemm_bf16_w8.hip) / 1 phased (gemm_bf16_w8p.hip) / 2, the default:
+            // phased with the rotating unit schedule and 32-bit buffer addressing (gemm_bf16_w8q.hip; falls back to 1 for operands it
+            // cannot address).  Same results bit for bit (tests/test_gpu_gemm_w8p.py); 148.9 -> 138.2 -> 125.0 us at 204 tiles.
             { const char* e = getenv("OSP_GEMM_W8P"); const int ph = e ? atoi(e) : OSP_W8P_DEFAULT; if (ph) return osp_launch_glds8p(p, g8, ph, stream); }
             static int early = -1;
             if (early < 0) { early = 1; }      // +1..3 % in A/B runs (tools/gemm_quick.py (git history))

@@ -203,6 +203,7 @@ __device__ __forceinline__ void conv_gemm_bf16_glds8q_body(const GemmB& pin, uns
         wait_for_next(g + 3);
         W8Q_MID();
         quad(acc1, 0, X);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // phase 3's reads feed the NEXT phase's MFMAs: retire them inside their own phase (the two-phase re-request rule)
         W8Q_END();
         s1 = s2; s2 = tap_next(s2);
     };

@@ -23,25 +23,39 @@ def timeit(f, reps=REPS):
     return a.elapsed_time(b) / reps * 1e3
 
 
+BASE_W8 = os.environ.get("OSP_GEMM_W8")                    # variant -1 = the 4-wave 128 x 128 kernel (OSP_GEMM_W8=0): timed, not compared
+
+
+def set_variant(v):
+    if v < 0:
+        os.environ["OSP_GEMM_W8"] = "0"
+    elif BASE_W8 is None:
+        os.environ.pop("OSP_GEMM_W8", None)
+    else:
+        os.environ["OSP_GEMM_W8"] = BASE_W8
+    os.environ["OSP_GEMM_W8P"] = str(max(v, 0))
+
+
 def run_variants(label, fl, fn, ref=None):
     outs, ts = {}, {}
     for rnd in range(2):                                   # two interleaved rounds: the second one is reported (clock settled)
         for v in VARIANTS:
-            os.environ["OSP_GEMM_W8P"] = str(v)
+            set_variant(v)
             if rnd == 0:
                 outs[v] = fn().clone()
             ts[v] = timeit(fn)
-    base = outs[VARIANTS[0]]
+    cmp = [v for v in VARIANTS if v >= 0]
+    base = outs[cmp[0]]
     msg = []
     bad = 0
-    for v in VARIANTS[1:]:                                 # race screen: SCREEN more launches of every phased variant, each compared bitwise
-        os.environ["OSP_GEMM_W8P"] = str(v)
+    for v in cmp[1:]:                                      # race screen: SCREEN more launches of every phased variant, each compared bitwise
+        set_variant(v)
         for _ in range(SCREEN):
             bad += int(not torch.equal(fn(), base))
     if bad:
         msg.append(f"RACE SCREEN: {bad} differing launches")
     for v in VARIANTS:
-        same = torch.equal(outs[v], base)
+        same = v < 0 or torch.equal(outs[v], base)
         msg.append(f"v{v} {ts[v]:7.1f} us {fl / ts[v] / 1e6:5.0f} TF{'' if same else ' DIFFERS'}")
         if not same:
             d = (outs[v].float() - base.float()).abs()
@@ -51,11 +65,18 @@ def run_variants(label, fl, fn, ref=None):
         msg.append(f"err vs torch {err:.1e}")
         assert err < 2e-2, err
     print(f"{label}: " + " | ".join(msg), flush=True)
-    return bad == 0 and all(torch.equal(outs[v], base) for v in VARIANTS)
+    return bad == 0 and all(torch.equal(outs[v], base) for v in cmp)
 
 
+if os.environ.get("ONE"):                                   # one shape, N launches of the variant in OSP_GEMM_W8P: what tools/probes/w8p_pmc.sh profiles
+    U, T, cin, n = int(os.environ.get("U", "160")), 102, 1024, 1024
+    a = torch.randn(U * T, cin, device=dev).bfloat16(); w = (torch.randn(n, 5, cin, device=dev) * 0.03).bfloat16()
+    for _ in range(int(os.environ.get("N", "10"))):
+        K.conv_gemm_bf16(a, w, n, M=U * T, Trows=T, Tin=T, cin=cin, taps=5, a_step=1, a_off=-2, out_bf16=True)
+    torch.cuda.synchronize()
+    sys.exit(0)
 ok = True
-# 1. plain 5-tap convs at tile counts around one round of the chip (as tools/probes/w8_exp.py)
+# 1. plain 5-tap convs at tile counts around one round of the chip (the shapes of round 5's fill sweep, profiles/r05_w8_fill_sweep.txt)
 for (U, T, cin, n, st) in [(128, 102, 1024, 1024, 1), (160, 102, 1024, 1024, 1), (256, 102, 1024, 1024, 1), (128, 304, 512, 1024, 3),
                            (704, 19, 1024, 1024, 1), (64, 102, 1024, 1024, 1), (131, 97, 1024, 768, 1)]:
     Tout = (T + 4 - 5) // st + 1
@@ -74,7 +95,7 @@ for p in (2, 3, 5, 7, 11):
     Ws = [T0]
     for _ in range(4):
         Ws.append((Ws[-1] + 4 - 5) // 3 + 1)
-    for (cin, cout, li, s) in ((512, 1024, 3, 3), (1024, 1024, 4, 1)):
+    for (cin, cout, li, s) in ((128, 512, 2, 3), (512, 1024, 3, 3), (1024, 1024, 4, 1)):      # (128 -> 512: 8-wave only under OSP_GEMM_W8=1)
         W = Ws[li]
         Wo = (W + 4 - 5) // s + 1
         x = torch.randn(Ub, 1, W, cin, device=dev).bfloat16()
