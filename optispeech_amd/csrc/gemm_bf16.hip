@@ -451,13 +451,19 @@ static int gemm_launch(GemmB& p, int64_t batch_in, hipStream_t stream) {
         // 8-wave 256x256 tiles when they still give every CU work: OSP_GEMM_W8 = 0 (never) / 1 (whenever >= 1 tile per 2 CUs) /
         // unset: the measured crossover (tools/gemm_w8_probe.py (git history); tools/probes/w8p_probe.py)
         // (both read per call: tests and probes switch them in-process)
-        int w8 = -1; int64_t w8_min = 160;
-        { const char* e = getenv("OSP_GEMM_W8"); if (e) w8 = atoi(e); const char* m = getenv("OSP_GEMM_W8_MIN"); if (m) w8_min = atoi(m); }
+        // (round 6, with the phased kernel: >= 96 tiles and K >= 2048 -- the batch-32 1024 <- 1024 dgrad and the fused-phase 1024 -> 512
+        // dgrads -- measured 14.34-14.37 vs 14.51-14.58 ms / step on one box, 14.51-14.58 vs 14.33-14.53 on another: no robust gain, and
+        // those launches run at 40-60 % chip fill alone; fused-phase dgrads as balanced work lists (one 2-tap tile or two 1-tap tiles per
+        // workgroup, 255 workgroups): 94.7 -> 86.1 us alone -- the second epilogue of the paired tiles is the long pole -- and 0.1 ms
+        // SLOWER in the step; both dropped, profiles/r06_w8_threshold_ab.txt)
+        int w8 = -1; int64_t w8_min = 160, w8_kmin = 2304;
+        { const char* e = getenv("OSP_GEMM_W8"); if (e) w8 = atoi(e); const char* m = getenv("OSP_GEMM_W8_MIN"); if (m) w8_min = atoi(m);
+          const char* k = getenv("OSP_GEMM_W8_KMIN"); if (k) w8_kmin = atoi(k); }
         const int64_t t256 = cdiv(M, 256) * cdiv(N, 256) * batch;
         // measured (round 2, profiles/r02_gemm_w8_probe_*.txt): +23..30 % where the reduction is long (K >= 2560: the
         // 512->1024 and 1024->1024 DiscriminatorP layers at M ~ 13k: 760 -> 950-990 TFLOP/s), -20 % on short-K / narrow layers
         // (K = 640, N = 512: the 256x256 prologue / epilogue is not amortised), neutral at half batch (too few tiles: not taken)
-        if (w8 != 0 && N >= 256 && t256 >= (w8 == 2 ? 1 : w8 == 1 ? 128 : w8_min) && (w8 >= 1 || taps * Cin >= 2304)) {    // OSP_GEMM_W8 = 2: any size (tests)
+        if (w8 != 0 && N >= 256 && t256 >= (w8 == 2 ? 1 : w8 == 1 ? 128 : w8_min) && (w8 >= 1 || taps * Cin >= w8_kmin)) {    // OSP_GEMM_W8 = 2: any size (tests)
             const dim3 g8((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256), (unsigned)batch);
             // phased main loops: OSP_GEMM_W8P = 0 lock-step kernel (gemm_bf16_w8.hip) / 1 phased (gemm_bf16_w8p.hip) / 2, the default:
             // phased with the rotating unit schedule and 32-bit buffer addressing (gemm_bf16_w8q.hip; falls back to 1 for operands it
