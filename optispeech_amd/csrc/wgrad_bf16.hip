@@ -596,6 +596,10 @@ int osp_launch_wgrad_n1(const void* dY, int64_t y_bf16, int64_t ldy, const void*
                         const float* arow, const float* oscale, float* dW, float* db, hipStream_t stream);      // wgrad_n1.hip
 
 int osp_launch_wgrad_ring(WgradB& p, int64_t batch, float* ws, int64_t ws_bytes, hipStream_t stream);     // wgrad_ring.hip
+int osp_launch_wgrad_tr8q(const WgradB& p, dim3 grid, hipStream_t stream);                                // wgrad_bf16_tr8q.hip (1: taken)
+#ifndef OSP_WGRAD_W8Q_DEFAULT
+#define OSP_WGRAD_W8Q_DEFAULT 1
+#endif
 
 static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf16, int64_t ldy, const void* X, int64_t x_bf16, int64_t ldx,
                                    int64_t M, int64_t Trows, int64_t Tin, int64_t N, int64_t Cin, int64_t taps, int64_t pad,
@@ -695,6 +699,10 @@ static int conv_wgrad_bf16_impl(const int64_t* d2, const void* dY, int64_t y_bf1
             sp8 = cdiv(M, ch8);
             p.chunk = (int)ch8; p.splits = (int)sp8;
             const dim3 g8((unsigned)((N / 256) * taps * (Cin / 256) * sp8 * batch));
+            // phased main loop (wgrad_bf16_tr8q.hip; declines 2-D row maps / operands without a buffer descriptor): OSP_WGRAD_W8Q = 0
+            // keeps the lock-step kernel (read per call: tests and probes switch it in-process)
+            { const char* e = getenv("OSP_WGRAD_W8Q"); const int q = e ? atoi(e) : OSP_WGRAD_W8Q_DEFAULT;
+              if (q && buf && osp_launch_wgrad_tr8q(p, g8, stream)) { OSP_LAUNCH_CHECK(); return OSP_OK; } }
             osp_note_symbol("conv_wgrad_bf16_tr8_kernel");
             if (buf) hipLaunchKernelGGL((conv_wgrad_bf16_tr8_kernel<true>), g8, dim3(512), 131072, stream, p);
             else hipLaunchKernelGGL((conv_wgrad_bf16_tr8_kernel<false>), g8, dim3(512), 131072, stream, p);
