@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_glds8p_kernel(const GemmB 
 // (the same body without the priority flips, SETPRIO = false: measured equal, 130.0 vs 131.3 us at 204 tiles; not instantiated)
 
 int osp_launch_glds8q(const GemmB& p, dim3 grid, hipStream_t stream);          // 1: taken, 0: declined
+int osp_launch_glds8r(const GemmB& p, dim3 grid, hipStream_t stream);          // 1: taken, 0: declined
 
 int osp_launch_glds8p(const GemmB& p, dim3 grid, int variant, hipStream_t stream) {
     static int done = 0;
@@ -216,7 +217,8 @@ int osp_launch_glds8p(const GemmB& p, dim3 grid, int variant, hipStream_t stream
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_bf16_glds8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS8_LDS);
         done = 1;
     }
-    if (variant == 2 && osp_launch_glds8q(p, grid, stream)) return OSP_OK;      // gemm_bf16_w8q.hip (declines what it cannot address)
+    if (variant == 3 && osp_launch_glds8r(p, grid, stream)) return OSP_OK;      // gemm_bf16_w8r.hip: tap reuse (stride-1, 5-tap problems; declines the rest)
+    if (variant >= 2 && osp_launch_glds8q(p, grid, stream)) return OSP_OK;      // gemm_bf16_w8q.hip (declines what it cannot address)
     osp_note_symbol("conv_gemm_bf16_glds8p_kernel");
     hipLaunchKernelGGL(conv_gemm_bf16_glds8p_kernel, grid, dim3(512), GLDS8_LDS, stream, p);
     OSP_LAUNCH_CHECK();

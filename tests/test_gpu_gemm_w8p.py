@@ -29,12 +29,12 @@ def _bf16_mode_and_env():
 
 
 def _variants(fn, reps=6):
-    """fn() under the lock-step kernel (0) and both phased kernels (1, 2); returns the lock-step output after asserting that every
+    """fn() under the lock-step kernel (0) and the phased kernels (1, 2, 3 = tap reuse where it applies, else 2); returns the lock-step output after asserting that every
     launch of every variant equals it bitwise."""
     os.environ["OSP_GEMM_W8"] = "2"                 # take the 8-wave family whatever the problem size (short K, few tiles)
     os.environ["OSP_GEMM_W8P"] = "0"
     base = fn().clone()
-    for v in ("1", "2"):
+    for v in ("1", "2", "3"):
         os.environ["OSP_GEMM_W8P"] = v
         for r in range(reps):
             out = fn()
@@ -64,6 +64,34 @@ def test_conv_forward_bit_identical_and_vs_torch(U, T, cin, n, taps, stride):
     ref = F.conv1d(a.float().view(U, T, cin).transpose(1, 2), w.float().permute(0, 2, 1).contiguous(), bias, stride=stride, padding=pad)
     ref = F.leaky_relu(ref, 0.1).transpose(1, 2).reshape(M, n)
     assert (out.float() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("U,T,cin,n", [
+    (150, 17, 64, 256),          # the shortest utterances the panel takes (16 of them in a tile), ONE channel block
+    (77, 23, 128, 512),          # two channel blocks (one trip of the ten-tile loop, no tail), ragged M = 1771
+    (40, 131, 192, 256),         # three channel blocks (loop + tail), utterances longer than half a tile
+    (11, 1000, 320, 768),        # utterances longer than a tile: tiles that start in the middle of one
+])
+def test_tap_reuse_kernel_cases(U, T, cin, n):
+    """gemm_bf16_w8r.hip (variant 3): 5 taps, stride 1 -- forward (tap step +1) and the stride-1 dgrad (tap step -1), shapes that move the
+    utterance boundaries through the panel; bit-identical to the per-tap kernels."""
+    from optispeech_amd import kernels as K, disc_ops as D
+    torch.manual_seed(U + T + cin)
+    M = U * T
+    a = torch.randn(M, cin, device="cuda").bfloat16()
+    w = (torch.randn(n, 5, cin, device="cuda") * (1.0 / (5 * cin) ** 0.5)).bfloat16()
+    out = _variants(lambda: K.conv_gemm_bf16(a, w, n, M=M, Trows=T, Tin=T, cin=cin, taps=5, a_step=1, a_off=-2, out_bf16=False))
+    ref = F.conv1d(a.float().view(U, T, cin).transpose(1, 2), w.float().permute(0, 2, 1).contiguous(), padding=2).transpose(1, 2).reshape(M, n)
+    assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # the stride-1 dgrad of the same layer: dx (U, 1, T, cin) from dy (U, 1, T, n)
+    dy = torch.randn(U, 1, T, n, device="cuda").bfloat16()
+    w4 = w.view(n, 1, 5, cin)
+    wt = w4.permute(3, 1, 2, 0).contiguous()
+    dx = _variants(lambda: D.conv2d_dgrad(dy, wt, 1, T, 1, 5, 1, 1, 0, 2, out_bf16=False))
+    xf = torch.zeros(U, cin, 1, T, device="cuda", requires_grad=True)
+    g, = torch.autograd.grad(F.conv2d(xf, w4.float().permute(0, 3, 1, 2), padding=(0, 2)), xf, dy.float().permute(0, 3, 1, 2))
+    ref = g.permute(0, 2, 3, 1)
+    assert (dx - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("K_", [64, 128, 192, 256, 320, 448])
