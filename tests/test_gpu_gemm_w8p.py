@@ -94,6 +94,28 @@ def test_tap_reuse_kernel_cases(U, T, cin, n):
     assert (dx - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_conv_shapes(seed):
+    """Seeded random problems (utterance length, count, channels, taps 1-9, stride 1-3, ragged N): every 8-wave main loop gives the
+    lock-step kernel's bits, and those agree with torch."""
+    import random
+    from optispeech_amd import kernels as K
+    rnd = random.Random(1000 + seed)
+    taps = rnd.choice([1, 3, 5, 5, 7, 9]); stride = rnd.choice([1, 1, 2, 3]); pad = taps // 2
+    cin = 64 * rnd.randint(1, 6); n = 8 * rnd.randint(33, 130)
+    T = rnd.randint(max(17, taps), 400); Tout = (T + 2 * pad - taps) // stride + 1
+    U = max(1, rnd.randint(600, 9000) // Tout)
+    M = U * Tout
+    torch.manual_seed(seed)
+    a = torch.randn(U * T, cin, device="cuda").bfloat16()
+    w = (torch.randn(n, taps, cin, device="cuda") * (1.0 / (taps * cin) ** 0.5)).bfloat16()
+    bias = torch.randn(n, device="cuda")
+    out = _variants(lambda: K.conv_gemm_bf16(a, w, n, M=M, Trows=Tout, Tin=T, cin=cin, taps=taps, a_step=stride, a_off=-pad, out_bf16=False, bias=bias), reps=3)
+    ref = F.conv1d(a.float().view(U, T, cin).transpose(1, 2), w.float().permute(0, 2, 1).contiguous(), bias, stride=stride, padding=pad)
+    ref = ref.transpose(1, 2).reshape(M, n)
+    assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), (U, T, cin, n, taps, stride)
+
+
 @pytest.mark.parametrize("K_", [64, 128, 192, 256, 320, 448])
 def test_short_reductions_prologue_and_tail(K_):
     """nk = 1 .. 7 k-slabs: the prologue requests more units than exist, the tail waits count down (vmcnt(8) .. vmcnt(0))."""
