@@ -38,6 +38,7 @@
 struct MlpP {
     const unsigned short* h; const unsigned short* w1; const unsigned short* w2p;
     const float *b1, *b2, *gamma, *x, *rowmask, *rowscale; float* y; int M, I;
+    int nfull;                                                           // workgroups [0, nfull) take 128 rows each, the rest 64 (split mode)
 };
 
 template <int C> struct MlpSched {
@@ -67,6 +68,10 @@ template <int N> __device__ __forceinline__ void mlp_lds_wait(i32x4 (&f)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N) : "memory");
 }
 
+template <int N> __device__ __forceinline__ void mlp_lds_wait2(i32x4 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N) : "memory");
+}
+
 // gelu(x) = x Phi(x), Phi(x) - 1/2 ~ xc Q(xc^2) with xc = x clamped to |x| <= 4.2 (minimax fit of degree 8 in xc^2: |Phi error| <= 7.4e-6
 // inside, 1 - Phi(4.2) = 1.3e-5 outside; |gelu error| <= 5.3e-5 for |x| <= 7; the result is rounded to bf16, unit round-off 4e-3).
 // 12 plain VALU instructions per element -- scalar on purpose (`// osp-flags: -fno-slp-vectorize` above): beside MFMAs a v_pk_fma_f32
@@ -91,12 +96,12 @@ __device__ __forceinline__ float mlp_gelu(float x) {
 // comes back as one float4 per lane: x in and y out as 16-byte accesses.  All x rows of a pass are REQUESTED before the first is
 // used (the registers the pass's accumulator tiles just vacated hold them): as load / use / store per float4 the pass was a chain
 // of NIT memory latencies, ~20 us per workgroup for the four passes.
-template <int C, int NB>                                             // NB: float4s of x in flight per lane (registers)
+template <int C, int NB, int Q0 = 0, int Q1 = -1>                    // NB: float4s of x in flight per lane (registers); passes [Q0, Q1)
 __device__ __forceinline__ void mlp_epilogue(const MlpP& p, f32x16 (&out)[C / 32], float* patch, int m0, int lane) {
     constexpr int NT = C / 32, TP = (NT % 3 == 0) ? 3 : 2, CP = 32 * TP, Q4 = CP / 4, NIT = 32 * Q4 / 64;
     static_assert(NT % TP == 0 && (32 * Q4) % 64 == 0, "epilogue tiling");
     const int l31 = lane & 31, half = lane >> 5;
-    mlp_sfor<0, NT / TP>([&](auto qidx) {
+    mlp_sfor<Q0, (Q1 < 0 ? NT / TP : Q1)>([&](auto qidx) {
         constexpr int q = decltype(qidx)::value;
 #pragma unroll
         for (int tt = 0; tt < TP; ++tt) {
@@ -137,15 +142,26 @@ extern __shared__ __attribute__((aligned(1024))) unsigned short mlp_smem[];
 #define MLP_MAX_I 4096
 #define MLP_LDS (8 * 128 * 64 * 2 + MLP_MAX_I * 4)                      // ring + (hi, lo) bias table
 
-template <int C>
-__global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
+// SPLIT = false: the workgroup's 128 rows, a wave owns 32 rows and all 128 units of a chunk (the description above).
+// SPLIT = true (round 6): 64 rows.  Waves 2 r and 2 r + 1 share row tile r; wave 2 r + uh owns S^T tiles uh and 2 + uh of every chunk
+// (units 32 uh .. + 31 and 64 + 32 uh .. + 31): in phase 1 it runs 2 of the 4 MFMAs of a group, in phase 2 the two k-steps of each
+// 64-unit slab its tiles cover -- HALF the MFMAs of every stage, the same LDS-DMA stream (so the ring schedule and its vmcnt
+// arithmetic are those of the full mode).  Each wave of a pair ends with a partial 32 x C output tile; the pair swaps column halves
+// through LDS and each finishes (bias, layer scale, residual, mask) its half of the columns.  What it is for: the LAST round of a
+// launch.  One workgroup per CU means 384 row blocks on 256 CUs take two rounds for 1.5 rounds of work; as 256 full + 256 split
+// workgroups the second round costs about half a round (osp_convnext_mlp_fused picks the mix; summation order of the two partials
+// differs from the full mode's, so the two modes agree to f32 rounding, not bit for bit).
+template <int C, bool SPLIT>
+__device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
     typedef MlpSched<C> S;
     constexpr int KS1 = S::KS1, NP = S::NP, UPS = S::UPS, UPC = S::UPC, R = S::R, GPS = S::GPS, NT = C / 32, KH = C / 16;
     constexpr int UNITB = 128 * 64 * 2;                              // bytes per ring slot
+    constexpr int NTL = SPLIT ? 2 : 4;                               // S^T tiles of a chunk this wave owns
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    const int uh = SPLIT ? (wave & 1) : 0;
     const int I = p.I, nchunks = I / 128;
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = SPLIT ? p.nfull * 128 + blk * 64 + (wave >> 1) * 32 : blk * 128 + wave * 32;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)mlp_smem;
 
     // ---- b1 as (hi, lo) bf16 pairs in LDS behind the ring: phase 1 STARTS from the bias through one extra MFMA per tile and chunk,
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
         }
         __syncthreads();
     }
-    const unsigned tab0 = lds0 + R * UNITB + 4 * l31;
+    const unsigned tab0 = lds0 + R * UNITB + 4 * l31 + 128 * uh;
     i32x4 onesf = {half ? 0 : 0x3F803F80, 0, 0, 0};
 
     // ---- staging: wave w writes rows 8 * (4 w + i) + rsub of a unit (i < 4), 16-byte slot pslot of each row
@@ -215,13 +231,19 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[j][i] = 0.f;
-    // fragment read byte offsets inside a unit for k-step ks of the slab: row l31 of a 32-row tile
-    unsigned fo[4];
+    // fragment read byte offsets inside a unit for k-step ks of the slab: row l31 of a 32-row tile (split mode: + this wave's first
+    // tile in phase 1; fo2[] = the two k-steps of a phase-2 slab its tiles cover)
+    unsigned fo[4], fo2[2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fo[ks] = lds0 + 2 * (l31 * 64 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) << 3));
+    fo2[0] = uh ? fo[2] : fo[0]; fo2[1] = uh ? fo[3] : fo[1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fo[ks] += 4096u * (unsigned)uh;
+    }
 
-    f32x16 st[4];
-    bf16x8 pf[4][2];
+    f32x16 st[NTL];
+    bf16x8 pf[NTL][2];
     i32x4 fb[2][4];
     // prologue: what stages 1 .. 3 of a chunk "-1" would have requested = units [0, lo(0)) of chunk 0
     mlp_sfor<0, S::lo(0)>([&](auto uidx) {
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
     });
     for (int c = 0; c < nchunks; ++c) {
         const int ring0 = (c * UPC) & (R - 1);
-        // GELU of half-tile hh: k-step hh of phase 2 = accumulator elements 8 s .. 8 s + 7 of tile t (hh = 2 t + s), rounded to bf16
+        // GELU of half-tile hh: k-step hh of phase 2 = accumulator elements 8 s .. 8 s + 7 of (local) tile t (hh = 2 t + s), rounded to bf16
         auto gelu_elems = [&](auto hidx, auto e0idx, auto e1idx) {         // elements [e0, e1) of half-tile hh
             constexpr int hh = decltype(hidx)::value, t = hh >> 1, s = hh & 1;
 #pragma unroll
@@ -241,6 +263,9 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
         auto stage = [&](auto kidx) {
             constexpr int K = decltype(kidx)::value;
             constexpr bool P1 = K < 2;
+            constexpr int NG = (SPLIT && !P1) ? GPS / 2 : GPS;           // groups of the stage (split phase 2: two of the four k-steps)
+            constexpr int DPG = GPS / NG;                                // LDS-DMA instructions per group
+            constexpr int RPG = (SPLIT && P1) ? 2 : 4;                   // fragment reads (= MFMAs) per group
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::vm(K)) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -249,33 +274,46 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
                 constexpr int gi = decltype(gidx)::value;
                 constexpr int ks = P1 ? gi % 4 : gi / NP;
                 constexpr int u = P1 ? UPS * K + gi / 4 : KS1 + (K - 2) * NP + gi % NP;
-                const unsigned a = fo[ks] + ((ring0 + u) & (R - 1)) * UNITB;
                 i32x4 (&f)[4] = fb[gi & 1];
-                mlp_lds_rd16<0>(f[0], a); mlp_lds_rd16<4096>(f[1], a); mlp_lds_rd16<8192>(f[2], a); mlp_lds_rd16<12288>(f[3], a);
+                if constexpr (SPLIT && P1) {
+                    const unsigned a = fo[ks] + ((ring0 + u) & (R - 1)) * UNITB;
+                    mlp_lds_rd16<0>(f[0], a); mlp_lds_rd16<8192>(f[1], a);
+                } else {
+                    const unsigned a = (SPLIT ? fo2[ks] : fo[ks]) + ((ring0 + u) & (R - 1)) * UNITB;
+                    mlp_lds_rd16<0>(f[0], a); mlp_lds_rd16<4096>(f[1], a); mlp_lds_rd16<8192>(f[2], a); mlp_lds_rd16<12288>(f[3], a);
+                }
             };
             if constexpr (K == 0) {
-                unsigned bt[4];
+                unsigned bt[NTL];
                 const unsigned ta = tab0 + c * 512;
-                asm volatile("ds_read_b32 %0, %1 offset:0" : "=v"(bt[0]) : "v"(ta) : "memory");
-                asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(bt[1]) : "v"(ta) : "memory");
-                asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(bt[2]) : "v"(ta) : "memory");
-                asm volatile("ds_read_b32 %0, %1 offset:384" : "=v"(bt[3]) : "v"(ta) : "memory");
-                rd(std::integral_constant<int, 0>{});
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]) : : "memory");
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT) {
+                    asm volatile("ds_read_b32 %0, %1 offset:0" : "=v"(bt[0]) : "v"(ta) : "memory");
+                    asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(bt[1]) : "v"(ta) : "memory");
+                    rd(std::integral_constant<int, 0>{});
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bt[0]), "+v"(bt[1]) : : "memory");
+                } else {
+                    asm volatile("ds_read_b32 %0, %1 offset:0" : "=v"(bt[0]) : "v"(ta) : "memory");
+                    asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(bt[1]) : "v"(ta) : "memory");
+                    asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(bt[2]) : "v"(ta) : "memory");
+                    asm volatile("ds_read_b32 %0, %1 offset:384" : "=v"(bt[3]) : "v"(ta) : "memory");
+                    rd(std::integral_constant<int, 0>{});
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]) : : "memory");
+                }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < NTL; ++t) {
                     const i32x4 af = {(int)bt[t], 0, 0, 0};
                     st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, onesf), zacc, 0, 0, 0);
                 }
             } else rd(std::integral_constant<int, 0>{});
-            mlp_sfor<0, GPS>([&](auto gidx) {
+            mlp_sfor<0, NG>([&](auto gidx) {
                 constexpr int gi = decltype(gidx)::value;
                 constexpr int ks = P1 ? gi % 4 : gi / NP;
-                issue_nth(kidx, gidx, c);
-                if constexpr (gi + 1 < GPS) rd(std::integral_constant<int, gi + 1>{});
+                mlp_sfor<0, DPG>([&](auto didx) { issue_nth(kidx, std::integral_constant<int, DPG * gi + decltype(didx)::value>{}, c); });
+                if constexpr (gi + 1 < NG) rd(std::integral_constant<int, gi + 1>{});
                 i32x4 (&f)[4] = fb[gi & 1];
-                if constexpr (gi + 1 < GPS) mlp_lds_wait<4>(f); else mlp_lds_wait<0>(f);
+                if constexpr (RPG == 2) { if constexpr (gi + 1 < NG) mlp_lds_wait2<2>(f); else mlp_lds_wait2<0>(f); }
+                else { if constexpr (gi + 1 < NG) mlp_lds_wait<4>(f); else mlp_lds_wait<0>(f); }
                 // The GELU (VALU) is dealt out between the MFMAs it hides under, a few elements at a time: half-tile kk + 1 during the
                 // NP groups of phase-2 k-step kk; half-tile 0 during the last phase-1 group, as its accumulators complete.  (One wave
                 // per SIMD: whatever is not in an MFMA's shadow is serial time.  Emitted as one block after a group, the compiler kept
@@ -283,22 +321,23 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
                 if constexpr (P1) {
                     constexpr int u = UPS * K + gi / 4;
                     constexpr bool LAST = K == 1 && gi == GPS - 1;
-                    mlp_sfor<0, 4>([&](auto tidx) {
+                    mlp_sfor<0, NTL>([&](auto tidx) {
                         constexpr int t = decltype(tidx)::value;
                         st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[t]), hf[4 * u + ks], st[t], 0, 0, 0);
                         if constexpr (LAST && t >= 1)
-                            gelu_elems(std::integral_constant<int, 0>{}, std::integral_constant<int, (t - 1) * 8 / 3>{},
-                                       std::integral_constant<int, t * 8 / 3>{});
+                            gelu_elems(std::integral_constant<int, 0>{}, std::integral_constant<int, (t - 1) * 8 / (NTL - 1)>{},
+                                       std::integral_constant<int, t * 8 / (NTL - 1)>{});
                     });
                 } else {
-                    constexpr int part = gi % NP, kk = 4 * (K - 2) + ks;
+                    // kk: the k-step's index among those this wave runs in the chunk = the half-tile of its OWN S^T tiles it consumes
+                    constexpr int part = gi % NP, kk = (SPLIT ? 2 : 4) * (K - 2) + ks, NKK = 2 * NTL;
                     constexpr int E0 = part * 8 / NP, E1 = (part + 1) * 8 / NP;      // this group's share of half-tile kk + 1
                     mlp_sfor<0, 4>([&](auto iidx) {
                         constexpr int i = decltype(iidx)::value;
                         out[4 * part + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[kk >> 1][kk & 1], __builtin_bit_cast(bf16x8, f[i]),
                                                                                     out[4 * part + i], 0, 0, 0);
                         constexpr int a = E0 + (E1 - E0) * i / 4, b = E0 + (E1 - E0) * (i + 1) / 4;
-                        if constexpr (kk + 1 < 8 && b > a)
+                        if constexpr (kk + 1 < NKK && b > a)
                             gelu_elems(std::integral_constant<int, kk + 1>{}, std::integral_constant<int, a>{}, std::integral_constant<int, b>{});
                     });
                 }
@@ -312,14 +351,54 @@ __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the tail of the schedule (requests nobody reads)
     __syncthreads();                                                  // every wave is done with the ring: it becomes the epilogue's staging
 
-    mlp_epilogue<C, (C == 384 ? 12 : 8)>(p, out, reinterpret_cast<float*>(mlp_smem) + wave * (32 * ((C / 32) % 3 == 0 ? 96 : 64)), m0, lane);
+    constexpr int PATCHF = 32 * ((C / 32) % 3 == 0 ? 96 : 64), NB = (C == 384 ? 12 : 8);
+    float* patch = reinterpret_cast<float*>(mlp_smem) + wave * PATCHF;
+    if constexpr (!SPLIT) mlp_epilogue<C, NB>(p, out, patch, m0, lane);
+    else {
+        // the pair swaps column halves of its partial output tiles: wave uh hands tiles of half 1 - uh over (16 bytes per lane and
+        // instruction, lane-linear: no bank conflicts), adds what the partner left for its own half, finishes that half
+        constexpr int HT = NT / 2, XF = HT * 16 * 64;                 // floats per wave in the exchange area (behind the patches)
+        float4* xw = reinterpret_cast<float4*>(reinterpret_cast<float*>(mlp_smem) + 4 * PATCHF + wave * XF) + lane;
+        const float4* xr = reinterpret_cast<const float4*>(reinterpret_cast<float*>(mlp_smem) + 4 * PATCHF + (wave ^ 1) * XF) + lane;
+        static_assert((4 * PATCHF + 4 * XF) * 4 <= MLP_LDS, "exchange area");
+        auto send = [&](auto sidx) {
+            constexpr int SEND0 = decltype(sidx)::value ? 0 : HT;
+#pragma unroll
+            for (int j = 0; j < HT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xw[(j * 4 + q) * 64] = make_float4(out[SEND0 + j][4 * q], out[SEND0 + j][4 * q + 1], out[SEND0 + j][4 * q + 2], out[SEND0 + j][4 * q + 3]);
+        };
+        auto recv = [&](auto sidx) {
+            constexpr int KEEP0 = decltype(sidx)::value ? HT : 0;
+#pragma unroll
+            for (int j = 0; j < HT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = xr[(j * 4 + q) * 64];
+                    out[KEEP0 + j][4 * q] += v.x; out[KEEP0 + j][4 * q + 1] += v.y; out[KEEP0 + j][4 * q + 2] += v.z; out[KEEP0 + j][4 * q + 3] += v.w;
+                }
+        };
+        constexpr int NQ = NT / ((NT % 3 == 0) ? 3 : 2);              // epilogue passes
+        static_assert(NQ % 2 == 0, "passes split between the pair");
+        if (uh == 0) send(std::integral_constant<int, 0>{}); else send(std::integral_constant<int, 1>{});
+        __syncthreads();
+        if (uh == 0) { recv(std::integral_constant<int, 0>{}); mlp_epilogue<C, NB, 0, NQ / 2>(p, out, patch, m0, lane); }
+        else         { recv(std::integral_constant<int, 1>{}); mlp_epilogue<C, NB, NQ / 2, NQ>(p, out, patch, m0, lane); }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
+    if ((int)blockIdx.x < p.nfull) mlp_body<C, false>(p, (int)blockIdx.x);
+    else mlp_body<C, true>(p, (int)blockIdx.x - p.nfull);
 }
 
 // (A producer / consumer variant of this kernel -- 8 waves, two per SIMD: four waves run phase 1 + GELU and hand the bf16 hidden tile
 // to four phase-2 waves through LDS, GELU deferred by a chunk so that it runs under MFMAs -- was built and measured in round 4:
 // correct on the first run, but the same 3.5 (C = 256) / 4.5 us (C = 384) per 128 hidden units as this kernel for a workgroup that
 // has its CU to itself (tools/probes/mlp_fixed_cost.py (git history)), against 2.0 / 3.0 us of MFMA time.  Two designs with opposite issue
-// structure and the same chunk time: the limiter is not the instruction stream of a wave.  Removed from the library; its source is kept, unbuilt, in tools/probes/mlp_pc_kernel.hip.)
+// structure and the same chunk time: the limiter is not the instruction stream of a wave.  Removed from the library; its source is in git history (commit 99fa51d, tools/probes/mlp_pc_kernel.hip).)
 
 // f32 (N, K) -> bf16 (N, K) with every group of 16 along K stored as [0-3, 8-11, 4-7, 12-15] (the phase-2 operand order above)
 __global__ __launch_bounds__(256) void pack_bf16_kperm16_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int64_t n4) {
@@ -365,7 +444,20 @@ extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float
     p.h = reinterpret_cast<const unsigned short*>(h); p.w1 = reinterpret_cast<const unsigned short*>(w1);
     p.w2p = reinterpret_cast<const unsigned short*>(w2_kperm);
     p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.x = x; p.rowmask = rowmask; p.rowscale = rowscale; p.y = y; p.M = (int)M; p.I = (int)I;
-    const dim3 grid((unsigned)cdiv(M, 128));
+    // Row blocks -> workgroups.  One workgroup per CU (144 KB of LDS): nb blocks of 128 rows run in ceil(nb / CUs) rounds, and a last
+    // round of r <= CUs / 2 blocks leaves half the chip idle for a whole round -- those r blocks go out as 2 r split-mode workgroups
+    // of 64 rows (half the MFMAs per wave, mlp_body<C, true>).  OSP_MLP_SPLIT=0: full mode only (A/B runs, tests).
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const char* es = getenv("OSP_MLP_SPLIT");
+    const int64_t nb = cdiv(M, 128), r = nb % ncu;
+    int64_t nfull = nb, nsplit = 0;
+    if (!(es && es[0] == '0') && r > 0 && 2 * r <= ncu) { nfull = nb - r; nsplit = cdiv(M - 128 * nfull, 64); }
+    p.nfull = (int)nfull;
+    const dim3 grid((unsigned)(nfull + nsplit));
     osp_note_symbol("convnext_mlp_fused_kernel");
     osp_note_flops(4.0 * (double)M * (double)C * (double)I);                                   // two GEMMs of 2 M C I
     osp_note_bytes((double)M * C * (2 + 4 + 4) + 4.0 * (double)C * I + 4.0 * (I + 2 * C));      // h in, x in, y out; both weight packs; biases, gamma

@@ -70,6 +70,34 @@ def test_fused_mlp_matches_restatement_and_two_launch_path(C, I, M, mask):
         assert (y[rowmask == 0] == 0).all()
 
 
+@pytest.mark.parametrize("C,I", [(384, 1152), (256, 1024)])
+@pytest.mark.parametrize("M", [64, 8200, 20000, 40000, 49152 + 77])
+def test_split_mode_tail_equals_full_mode(C, I, M, monkeypatch):
+    """Round 6: the last, at most half-full round of 128-row blocks goes out as 64-row split-mode workgroups (two waves per row tile,
+    each half of a chunk's hidden units, partial output tiles summed through LDS).  Same S^T, same GELU roundings; only the f32
+    summation order of the output differs from the full mode (OSP_MLP_SPLIT=0).  M covers: everything split (64, 8200), nothing
+    split (20000: 157 blocks), a full round + split tail (40000, 49229)."""
+    from optispeech_amd import kernels as K, precision
+    h, x, W1, W2, b1, b2, gamma, rowmask, rowscale = _case(M, C, I, 7 * C + I + M, True)
+    d = lambda t: None if t is None else t.to(DEV)
+    hb = h.to(DEV).to(torch.bfloat16)
+    W1p, W2p = torch.nn.Parameter(W1.to(DEV)), torch.nn.Parameter(W2.to(DEV))
+    args = (hb, W1p, d(b1), W2p, d(b2), d(gamma), d(x), d(rowmask), d(rowscale))
+    precision.set_precision("bf16")
+    try:
+        ys = [K.convnext_mlp_fused(*args) for _ in range(3)]
+        monkeypatch.setenv("OSP_MLP_SPLIT", "0")
+        yf = K.convnext_mlp_fused(*args)
+        torch.cuda.synchronize()
+    finally:
+        precision.set_precision("f32")
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])          # deterministic (no atomics in the pair reduction)
+    scale = yf.abs().max().item()
+    assert (ys[0] - yf).abs().max().item() <= 2e-6 * scale, ((ys[0] - yf).abs().max().item(), scale)
+    ref = _reference(h, x, W1, W2, b1, b2, gamma, rowmask, rowscale)
+    assert (ys[0].cpu().double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+
+
 def test_fused_mlp_is_what_the_no_grad_block_runs(monkeypatch):
     """ConvNeXtBlockFn under no_grad in performance mode = dwconv7+LN kernel + ONE MLP launch, equal to the autograd-capable path."""
     from optispeech_amd import kernels as K, ops, precision
