@@ -135,6 +135,82 @@ __global__ __launch_bounds__(256, (NCH == 1 && FR <= 8) ? 4 : 1) void dwconv7_ln
     }
 }
 
+// C = 384 (the WaveNeXt trunk) on the kernel above is two 256-channel chunks with the upper half of the second one idle: 25 % of the
+// lanes' registers, loads and FMAs are spent on nothing (the loads are unconditional).  Here a lane owns SIX channels -- 4 lane .. + 3
+// of the first 256 as a float4 and 256 + 2 lane, + 1 as a float2 -- so every lane is busy on every row, a row is 6 registers instead
+// of 8, and runs of FR = 16 frames (22 rows requested up front, request amplification 22 / 16 instead of 14 / 8) fit.  Round 6.
+__device__ __forceinline__ float2 f2fma(float2 a, float2 b, float2 c) { return make_float2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
+template <int FR>
+__global__ __launch_bounds__(256) void dwconv7_ln_fwd_c384_kernel(const float* __restrict__ x, const float* __restrict__ dw,
+                                                                  const float* __restrict__ dwb, const float* __restrict__ lnw,
+                                                                  const float* __restrict__ lnb, float eps,
+                                                                  void* __restrict__ h, int h_bf16, float* __restrict__ xhat,
+                                                                  float* __restrict__ rstd_out, int B, int T, int runs_per_utt) {
+    constexpr int C = 384;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int run = blockIdx.x * 4 + wave;
+    if (run >= B * runs_per_utt) return;
+    const int b = run / runs_per_utt, rr = run - b * runs_per_utt;
+    const int t0 = (int)((int64_t)rr * T / runs_per_utt), t1 = (int)((int64_t)(rr + 1) * T / runs_per_utt);
+    const float* xb = x + (int64_t)b * T * C;
+    const int ca = 4 * lane, cb = 256 + 2 * lane;
+    float4 ra[FR + 6];
+    float2 rb[FR + 6];
+#pragma unroll
+    for (int r = 0; r < FR + 6; ++r) {
+        const int t = t0 + r - 3;
+        const bool ok = t >= 0 && t < T;
+        const float* row = xb + (int64_t)(ok ? t : t0) * C;                      // unconditional loads, index select
+        const float4 va = *reinterpret_cast<const float4*>(row + ca);
+        const float2 vb = *reinterpret_cast<const float2*>(row + cb);
+        ra[r] = ok ? va : f4zero();
+        rb[r] = ok ? vb : make_float2(0.f, 0.f);
+    }
+    float4 wa[7]; float2 wb[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        wa[j] = *reinterpret_cast<const float4*>(dw + (int64_t)j * C + ca);
+        wb[j] = *reinterpret_cast<const float2*>(dw + (int64_t)j * C + cb);
+    }
+    const float4 ba = *reinterpret_cast<const float4*>(dwb + ca), gwa = *reinterpret_cast<const float4*>(lnw + ca), gba = *reinterpret_cast<const float4*>(lnb + ca);
+    const float2 bb = *reinterpret_cast<const float2*>(dwb + cb), gwb = *reinterpret_cast<const float2*>(lnw + cb), gbb = *reinterpret_cast<const float2*>(lnb + cb);
+    const float invC = 1.0f / (float)C;
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        const int t = t0 + f;
+        if (t < t1) {                                           // wave-uniform
+            float4 a = ba; float2 c2 = bb;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { a = f4fma(wa[j], ra[f + j], a); c2 = f2fma(wb[j], rb[f + j], c2); }
+            const float mean = wave_sum(f4sum(a) + (c2.x + c2.y)) * invC;
+            a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; c2.x -= mean; c2.y -= mean;
+            const float v = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w) + (c2.x * c2.x + c2.y * c2.y);
+            const float rstd = rsqrtf(wave_sum(v) * invC + eps);
+            const int64_t row = ((int64_t)b * T + t) * C;
+            const float4 na = make_float4(a.x * rstd, a.y * rstd, a.z * rstd, a.w * rstd);
+            const float2 nb = make_float2(c2.x * rstd, c2.y * rstd);
+            if (xhat) {
+                st_stream(reinterpret_cast<float4*>(xhat + row + ca), na);
+                *reinterpret_cast<float2*>(xhat + row + cb) = nb;
+            }
+            const float4 oa = f4fma(na, gwa, gba);
+            const float2 ob = f2fma(nb, gwb, gbb);
+            if (h_bf16) {
+                typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+                v2 p0, p1, p2; p0[0] = (__bf16)oa.x; p0[1] = (__bf16)oa.y; p1[0] = (__bf16)oa.z; p1[1] = (__bf16)oa.w; p2[0] = (__bf16)ob.x; p2[1] = (__bf16)ob.y;
+                unsigned short* hp = reinterpret_cast<unsigned short*>(h) + row;
+                st_stream(reinterpret_cast<uint2*>(hp + ca), make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)));
+                *reinterpret_cast<unsigned*>(hp + cb) = __builtin_bit_cast(unsigned, p2);
+            } else {
+                float* hp = reinterpret_cast<float*>(h) + row;
+                st_stream(reinterpret_cast<float4*>(hp + ca), oa);
+                *reinterpret_cast<float2*>(hp + cb) = ob;
+            }
+            if (rstd_out && lane == 0) rstd_out[(int64_t)b * T + t] = rstd;
+        }
+    }
+}
+
 // h_bf16 != 0: h is written as bf16 (the operand the bf16 pointwise GEMM reads); xhat / rstd stay f32.
 extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* dwb, const float* lnw,
                                   const float* lnb, float eps, void* h, int64_t h_bf16, float* xhat, float* rstd, int64_t B,
@@ -160,6 +236,18 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
 #define L(N, F) do { const int R_ = pick_runs(F); hipLaunchKernelGGL((dwconv7_ln_fwd_kernel<N, F>), dim3((unsigned)cdiv(B * (int64_t)R_, 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, (int)C, R_); } while (0)
     static int fr1 = -1;
     if (fr1 < 0) { fr1 = 8; }      // measured at 32 x 800 x 256 (tools/dwconv_probe.py (git history)): FR 4 / 8 / 16 = 18.7 / 17.2 / 21.5 us with xhat saved
+    // C = 384: six channels per lane (every lane busy), runs of 16 frames from 16 k rows (64 x 772 frames: 36.9 -> 32.5 us, 32 x 800:
+    // 20.7 -> 16.1 us), of 8 below (32 x 64: 8.4 -> 8.2 us; runs of 16 leave SIMDs empty there: 9.9 us).  OSP_DWLN_C384=0: the
+    // two-chunk kernel (A/B runs), = 8 / 12 / 16: that run length.
+    if (C == 384) {
+        const char* e = getenv("OSP_DWLN_C384");
+        const int sel = e ? atoi(e) : (B * T >= 16384 && T >= 16 ? 16 : 8);
+#define L6(F) do { const int R_ = (int)cdiv(T, F); hipLaunchKernelGGL((dwconv7_ln_fwd_c384_kernel<F>), dim3((unsigned)cdiv(B * (int64_t)R_, 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, R_); } while (0)
+        if (sel == 16) { L6(16); OSP_LAUNCH_CHECK(); return OSP_OK; }
+        if (sel == 12) { L6(12); OSP_LAUNCH_CHECK(); return OSP_OK; }
+        if (sel == 8) { L6(8); OSP_LAUNCH_CHECK(); return OSP_OK; }
+#undef L6
+    }
     if (nch == 1) { if (fr1 == 8) L(1, 8); else if (fr1 == 4) L(1, 4); else L(1, 16); } else if (nch == 2) L(2, 8); else if (nch == 3) L(3, 4); else L(4, 4);
 #undef L
     OSP_LAUNCH_CHECK();

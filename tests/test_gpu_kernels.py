@@ -90,7 +90,7 @@ def test_conv_wgrad(nutt, T, cin, taps, n_out):
 
 
 # ------------------------------------------------------------------------------------------------ ConvNeXt
-@pytest.mark.parametrize("B,T,C", [(2, 37, 256), (3, 64, 384), (1, 5, 64), (2, 130, 512)])
+@pytest.mark.parametrize("B,T,C", [(2, 37, 256), (3, 64, 384), (1, 5, 64), (2, 130, 512), (2, 131, 384), (1, 3, 384), (70, 301, 384)])
 def test_dwconv_ln_forward_backward(B, T, C):
     from optispeech_amd import kernels as K
     x = rnd(B, T, C, seed=1).requires_grad_(True)
@@ -103,6 +103,9 @@ def test_dwconv_ln_forward_backward(B, T, C):
     dwn = dw.detach()[:, 0, :].t().contiguous().to(DEV)
     hg, xhat, rstd = K.dwconv7_ln_fwd(x.detach().to(DEV), dwn, dwb.detach().to(DEV), lw.detach().to(DEV), lb.detach().to(DEV), 1e-6, True)
     assert relerr(hg, h) < 1e-5
+    # the no-grad form (bf16 rows for the fused MLP, nothing saved) -- C = 384 has its own kernel (six channels per lane, round 6)
+    hb, _, _ = K.dwconv7_ln_fwd(x.detach().to(DEV), dwn, dwb.detach().to(DEV), lw.detach().to(DEV), lb.detach().to(DEV), 1e-6, False, h_bf16=True)
+    assert torch.equal(hb, hg.to(torch.bfloat16))
     glw, glb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dc = K.layernorm_bwd(dh.to(DEV).view(B * T, C), xhat.view(B * T, C), None, rstd.view(-1), lw.detach().to(DEV), glw, glb)
     gdw, gdb = torch.zeros(7, C, device=DEV), torch.zeros(C, device=DEV)
