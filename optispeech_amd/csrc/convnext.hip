@@ -239,9 +239,13 @@ extern "C" int osp_dwconv7_ln_fwd(const float* x, const float* dw, const float* 
     // C = 384: six channels per lane (every lane busy), runs of 16 frames from 16 k rows (64 x 772 frames: 36.9 -> 32.5 us, 32 x 800:
     // 20.7 -> 16.1 us), of 8 below (32 x 64: 8.4 -> 8.2 us; runs of 16 leave SIMDs empty there: 9.9 us).  OSP_DWLN_C384=0: the
     // two-chunk kernel (A/B runs), = 8 / 12 / 16: that run length.
+    // Taken by the no-grad form (nothing saved: synthesise, the tape-less decoder); a forward that saves x-hat / rstd for a backward stays
+    // on the two-chunk kernel unless the switch names a run length: the two agree to f32 rounding, and the vocoder's gradient norms at
+    // the benchmark size move by ~1 % under ANY such perturbation (bf16 discriminators behind it; tests/test_gpu_fullsize_golden.py
+    // bounds them at 6 % with 5.1 % measured) -- the training step's numbers stay the ones every fixture was accepted on.
     if (C == 384) {
         const char* e = getenv("OSP_DWLN_C384");
-        const int sel = e ? atoi(e) : (B * T >= 16384 && T >= 16 ? 16 : 8);
+        const int sel = e ? atoi(e) : (xhat ? 0 : (B * T >= 16384 && T >= 16 ? 16 : 8));
 #define L6(F) do { const int R_ = (int)cdiv(T, F); hipLaunchKernelGGL((dwconv7_ln_fwd_c384_kernel<F>), dim3((unsigned)cdiv(B * (int64_t)R_, 4)), dim3(256), 0, stream, x, dw, dwb, lnw, lnb, eps, h, (int)h_bf16, xhat, rstd, (int)B, (int)T, R_); } while (0)
         if (sel == 16) { L6(16); OSP_LAUNCH_CHECK(); return OSP_OK; }
         if (sel == 12) { L6(12); OSP_LAUNCH_CHECK(); return OSP_OK; }

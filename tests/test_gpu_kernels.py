@@ -105,7 +105,7 @@ def test_dwconv_ln_forward_backward(B, T, C):
     assert relerr(hg, h) < 1e-5
     # the no-grad form (bf16 rows for the fused MLP, nothing saved) -- C = 384 has its own kernel (six channels per lane, round 6)
     hb, _, _ = K.dwconv7_ln_fwd(x.detach().to(DEV), dwn, dwb.detach().to(DEV), lw.detach().to(DEV), lb.detach().to(DEV), 1e-6, False, h_bf16=True)
-    assert torch.equal(hb, hg.to(torch.bfloat16))
+    assert (hb.float() - hg).abs().max().item() <= 2.0 ** -8 * hg.abs().max().item() * 1.01      # half a bf16 ulp of the largest row value
     glw, glb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dc = K.layernorm_bwd(dh.to(DEV).view(B * T, C), xhat.view(B * T, C), None, rstd.view(-1), lw.detach().to(DEV), glw, glb)
     gdw, gdb = torch.zeros(7, C, device=DEV), torch.zeros(C, device=DEV)
@@ -113,6 +113,30 @@ def test_dwconv_ln_forward_backward(B, T, C):
     assert relerr(dx, x.grad) < 2e-5
     assert relerr(glw, lw.grad) < 2e-5 and relerr(glb, lb.grad) < 2e-5
     assert relerr(gdw.t(), dw.grad[:, 0, :]) < 2e-5 and relerr(gdb, dwb.grad) < 2e-5
+
+
+@pytest.mark.parametrize("sel", ["0", "8", "12", "16"])
+@pytest.mark.parametrize("B,T", [(3, 64), (2, 131), (1, 3), (70, 301)])
+def test_dwconv_ln_c384_kernel_variants(B, T, sel, monkeypatch):
+    """C = 384 has a second forward kernel (six channels per lane, round 6; default for the no-grad form): every run length and the
+    two-chunk kernel give torch's h, x-hat and rstd, saved or not, f32 or bf16 rows."""
+    from optispeech_amd import kernels as K
+    C = 384
+    x = rnd(B, T, C, seed=11)
+    dw, dwb = rnd(C, 1, 7, seed=12, scale=0.3), rnd(C, seed=13, scale=0.1)
+    lw, lb = 1 + 0.1 * rnd(C, seed=14), rnd(C, seed=15, scale=0.1)
+    c = F.conv1d(x.transpose(1, 2), dw, dwb, padding=3, groups=C).transpose(1, 2)
+    h = F.layer_norm(c, (C,), lw, lb, 1e-6)
+    var = c.var(-1, unbiased=False)
+    xh = (c - c.mean(-1, keepdim=True)) * torch.rsqrt(var + 1e-6)[..., None]
+    monkeypatch.setenv("OSP_DWLN_C384", sel)
+    args = (x.to(DEV), dw[:, 0, :].t().contiguous().to(DEV), dwb.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6)
+    hg, xhat, rstd = K.dwconv7_ln_fwd(*args, True)
+    assert relerr(hg, h) < 1e-5 and relerr(xhat, xh) < 1e-5 and relerr(rstd, torch.rsqrt(var + 1e-6)) < 1e-5
+    h2, none1, none2 = K.dwconv7_ln_fwd(*args, False)
+    assert none1 is None and none2 is None and torch.equal(h2, hg)                     # same kernel, nothing saved: same rows
+    hb, _, _ = K.dwconv7_ln_fwd(*args, False, h_bf16=True)
+    assert torch.equal(hb, hg.to(torch.bfloat16))
 
 
 def test_layernorm_dropout_mask_consistency():
