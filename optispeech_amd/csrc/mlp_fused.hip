@@ -34,11 +34,13 @@
 // osp-flags: -fno-slp-vectorize
 #include "gemm_bf16_common.h"
 #include <utility>
+#include <algorithm>
 
 struct MlpP {
     const unsigned short* h; const unsigned short* w1; const unsigned short* w2p;
     const float *b1, *b2, *gamma, *x, *rowmask, *rowscale; float* y; int M, I;
     int nfull;                                                           // workgroups [0, nfull) take 128 rows each, the rest 64 (split mode)
+    const int* rowperm;                                                  // position -> row (unmasked rows first), or NULL: position = row
 };
 
 template <int C> struct MlpSched {
@@ -119,19 +121,21 @@ __device__ __forceinline__ void mlp_epilogue(const MlpP& p, f32x16 (&out)[C / 32
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4;
-                const int m = m0 + r < p.M ? m0 + r : p.M - 1;                   // (clamped: the loads are unconditional)
+                const int mp = m0 + r < p.M ? m0 + r : p.M - 1;                  // (clamped: the loads are unconditional)
+                const int m = p.rowperm ? p.rowperm[mp] : mp;
                 xv[k] = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + q * CP + 4 * c4);
                 rmk[k] = p.rowmask ? p.rowmask[m] : 1.f;
                 rs[k] = p.rowscale ? p.rowscale[m] : 1.f;
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4, m = m0 + r;
+                const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4, mp = m0 + r;
+                const int m = (p.rowperm && mp < p.M) ? p.rowperm[mp] : mp;
                 const float4 v = *reinterpret_cast<const float4*>(patch + r * CP + 4 * c4);
                 float4 yv;
                 yv.x = fmaf(rs[k], v.x, xv[k].x) * rmk[k]; yv.y = fmaf(rs[k], v.y, xv[k].y) * rmk[k];
                 yv.z = fmaf(rs[k], v.z, xv[k].z) * rmk[k]; yv.w = fmaf(rs[k], v.w, xv[k].w) * rmk[k];
-                if (m < p.M) *reinterpret_cast<float4*>(p.y + (int64_t)m * C + q * CP + 4 * c4) = yv;
+                if (mp < p.M) *reinterpret_cast<float4*>(p.y + (int64_t)m * C + q * CP + 4 * c4) = yv;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -163,6 +167,22 @@ __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
     const int I = p.I, nchunks = I / 128;
     const int m0 = SPLIT ? p.nfull * 128 + blk * 64 + (wave >> 1) * 32 : blk * 128 + wave * 32;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)mlp_smem;
+
+    // ---- a row block whose rows are ALL masked (the padding behind an utterance's last frame: a quarter of the rows of the 64-sentence
+    // synthesise benchmark) has y = 0 whatever the MLP gives: write the zeros and leave -- the CU takes the next block (round 6)
+    if (p.rowmask) {
+        constexpr int ROWS = SPLIT ? 64 : 128;
+        const int mb = SPLIT ? p.nfull * 128 + blk * 64 : blk * 128, mr = mb + (tid & (ROWS - 1));
+        const int alive = mr < p.M && p.rowmask[p.rowperm ? p.rowperm[mr] : mr] != 0.f;
+        if (!__syncthreads_or(alive)) {
+            const int nrow = p.M - mb < ROWS ? p.M - mb : ROWS;
+            for (int i = tid; i < nrow * (C / 4); i += 256) {
+                const int r = i / (C / 4), c4 = i - r * (C / 4), m = p.rowperm ? p.rowperm[mb + r] : mb + r;
+                *reinterpret_cast<float4*>(p.y + (int64_t)m * C + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
+    }
 
     // ---- b1 as (hi, lo) bf16 pairs in LDS behind the ring: phase 1 STARTS from the bias through one extra MFMA per tile and chunk,
     // A = [hi(b1[unit]), lo(b1[unit]), 0 ...] (k = 0, 1), B = ones in rows k = 0, 1: hi + lo carries b1 to 2^-17 relative, exact in
@@ -218,7 +238,8 @@ __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
     bf16x8 hf[KH];
     {
         const int m = m0 + l31;
-        const unsigned short* hp = p.h + (int64_t)(m < p.M ? m : 0) * C + 8 * half;
+        const int mrow = m < p.M ? (p.rowperm ? p.rowperm[m] : m) : 0;
+        const unsigned short* hp = p.h + (int64_t)mrow * C + 8 * half;
 #pragma unroll
         for (int s = 0; s < KH; ++s) {
             uint4 v = *reinterpret_cast<const uint4*>(hp + 16 * s);
@@ -432,9 +453,15 @@ static void mlp_attrs() {
 // hidden units stored in the order [0-3, 8-11, 4-7, 12-15]; b1 (I), b2 (C), gamma (C), x / y (M, C) f32; rowmask / rowscale (M) f32 or NULL
 // (rowscale = the DropPath factor of a row's utterance: the training step runs the decoder without a tape, DropPath on).
 // C in {256, 384}, I % 128 == 0.
-extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float* b1, const void* w2_kperm, const float* b2,
-                                      const float* gamma, const float* x, const float* rowmask, const float* rowscale, float* y, int64_t M, int64_t C,
-                                      int64_t I, hipStream_t stream) {
+// rowperm (M int32, or NULL): the order the rows are WALKED in -- position k of the launch is row rowperm[k] of h / x / y / rowmask /
+// rowscale -- with the unmasked rows first (synthesise: a stable partition of the padded batch's frames by the padding mask, made once per
+// call).  Row blocks are then either live throughout or masked throughout (one mixed block), and a masked block writes its zeros and
+// leaves at once: the launch costs what its LIVE rows cost.  live_rows: the number of unmasked rows where the caller knows it (the sum
+// of the utterance lengths, which synthesise's one length sync already brings to the host), -1 otherwise; only the full / split
+// workgroup mix is chosen from it -- any value gives the same output.
+extern "C" int osp_convnext_mlp_fused_live(const void* h, const void* w1, const float* b1, const void* w2_kperm, const float* b2,
+                                           const float* gamma, const float* x, const float* rowmask, const float* rowscale, float* y, int64_t M,
+                                           int64_t C, int64_t I, const int* rowperm, int64_t live_rows, hipStream_t stream) {
     OSP_CHECK_ARG(h && w1 && b1 && w2_kperm && b2 && gamma && x && y, "null argument");
     OSP_CHECK_ARG(M > 0 && M < (1ll << 31) - 256, "row count out of range");
     OSP_CHECK_ARG(C == 256 || C == 384, "channel width must be 256 or 384");
@@ -444,6 +471,7 @@ extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float
     p.h = reinterpret_cast<const unsigned short*>(h); p.w1 = reinterpret_cast<const unsigned short*>(w1);
     p.w2p = reinterpret_cast<const unsigned short*>(w2_kperm);
     p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.x = x; p.rowmask = rowmask; p.rowscale = rowscale; p.y = y; p.M = (int)M; p.I = (int)I;
+    p.rowperm = rowmask ? rowperm : nullptr;
     // Row blocks -> workgroups.  One workgroup per CU (144 KB of LDS): nb blocks of 128 rows run in ceil(nb / CUs) rounds, and a last
     // round of r <= CUs / 2 blocks leaves half the chip idle for a whole round -- those r blocks go out as 2 r split-mode workgroups
     // of 64 rows (half the MFMAs per wave, mlp_body<C, true>).  OSP_MLP_SPLIT=0: full mode only (A/B runs, tests).
@@ -453,9 +481,13 @@ extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const char* es = getenv("OSP_MLP_SPLIT");
-    const int64_t nb = cdiv(M, 128), r = nb % ncu;
+    // With the live rows first (rowperm) and their count known, the rounds are counted in LIVE blocks: the first nb_live; the masked
+    // blocks behind them cost nothing whichever mode they are launched in.
+    const int64_t nb = cdiv(M, 128);
+    const bool hinted = rowmask && rowperm && live_rows > 0 && live_rows < M;
+    const int64_t nb_live = hinted ? cdiv(live_rows, 128) : nb, r_live = nb_live % ncu;
     int64_t nfull = nb, nsplit = 0;
-    if (!(es && es[0] == '0') && r > 0 && 2 * r <= ncu) { nfull = nb - r; nsplit = cdiv(M - 128 * nfull, 64); }
+    if (!(es && es[0] == '0') && r_live > 0 && 2 * r_live <= ncu) { nfull = nb_live - r_live; nsplit = cdiv(M - 128 * nfull, 64); }
     p.nfull = (int)nfull;
     const dim3 grid((unsigned)(nfull + nsplit));
     osp_note_symbol("convnext_mlp_fused_kernel");
@@ -463,6 +495,45 @@ extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float
     osp_note_bytes((double)M * C * (2 + 4 + 4) + 4.0 * (double)C * I + 4.0 * (I + 2 * C));      // h in, x in, y out; both weight packs; biases, gamma
     if (C == 384) hipLaunchKernelGGL((convnext_mlp_fused_kernel<384>), grid, dim3(256), MLP_LDS, stream, p);
     else hipLaunchKernelGGL((convnext_mlp_fused_kernel<256>), grid, dim3(256), MLP_LDS, stream, p);
+    OSP_LAUNCH_CHECK();
+    return OSP_OK;
+}
+
+extern "C" int osp_convnext_mlp_fused(const void* h, const void* w1, const float* b1, const void* w2_kperm, const float* b2,
+                                      const float* gamma, const float* x, const float* rowmask, const float* rowscale, float* y, int64_t M, int64_t C,
+                                      int64_t I, hipStream_t stream) {
+    return osp_convnext_mlp_fused_live(h, w1, b1, w2_kperm, b2, gamma, x, rowmask, rowscale, y, M, C, I, nullptr, -1, stream);
+}
+
+// Row order of a padded batch for osp_convnext_mlp_fused_live: perm[k] = the k-th row of "unmasked rows first, each group in row order"
+// (a stable partition of 0 .. M - 1 by rowmask != 0).  One workgroup: thread t owns rows [t c, (t + 1) c), c = ceil(M / 1024); counts its
+// unmasked rows, an exclusive scan over the 1024 counts in LDS, then writes its rows' positions.  ~10 us at 49 k rows; runs on the
+// stream, nothing read back (capturable), no temporary storage.
+__global__ __launch_bounds__(1024) void row_order_kernel(const float* __restrict__ rowmask, int* __restrict__ perm, int M) {
+    __shared__ int sc[1024];
+    const int t = threadIdx.x, c = (M + 1023) / 1024;
+    const int r0 = t * c < M ? t * c : M, r1 = r0 + c < M ? r0 + c : M;
+    int cnt = 0;
+    for (int r = r0; r < r1; ++r) cnt += rowmask[r] != 0.f;
+    sc[t] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                                  // inclusive scan (Hillis-Steele)
+        const int v = t >= d ? sc[t - d] : 0;
+        __syncthreads();
+        sc[t] += v;
+        __syncthreads();
+    }
+    const int total = sc[1023];
+    int lp = sc[t] - cnt, dp = total + (r0 - lp);                         // next unmasked / masked position of this thread's rows
+    for (int r = r0; r < r1; ++r) {
+        if (rowmask[r] != 0.f) perm[lp++] = r; else perm[dp++] = r;
+    }
+}
+
+extern "C" int osp_row_order(const float* rowmask, int* perm, int64_t M, hipStream_t stream) {
+    OSP_CHECK_ARG(rowmask && perm, "null argument");
+    OSP_CHECK_ARG(M > 0 && M < (1ll << 31) - 1024, "row count out of range");
+    hipLaunchKernelGGL(row_order_kernel, dim3(1), dim3(1024), 0, stream, rowmask, perm, (int)M);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }

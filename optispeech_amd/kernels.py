@@ -1131,6 +1131,39 @@ def param_bf16_kperm16(p):
     return cache[1]
 
 
+#: the padded batch being decoded: set by generator.synthesise around its decoder / vocoder passes (``live_rows``).  The fused MLP's
+#: launches over exactly M rows with a row mask walk the rows in the order "unmasked first" (a stable partition by the mask, made at the
+#: first such launch and kept for the rest of the pass: the mask of a pass does not change) and know how many are unmasked
+_LIVE_ROWS = [None]
+
+
+class live_rows:
+    """``with live_rows(M, n):`` -- the no-grad ConvNeXt MLP launches over M masked rows inside know that n of them are unmasked and
+    walk those first (csrc/mlp_fused.hip: masked row blocks cost nothing).  A hint: n only picks the workgroup mix."""
+
+    def __init__(self, M, n):
+        self.v = {"M": int(M), "n": int(n), "perm": None, "mask": None}
+
+    def __enter__(self):
+        self.old, _LIVE_ROWS[0] = _LIVE_ROWS[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _LIVE_ROWS[0] = self.old
+        return False
+
+
+def _row_order(hint, rowmask):
+    """position -> row, unmasked rows first (int32), for the mask of the running pass (same storage = same mask)."""
+    key = rowmask.data_ptr()                                      # (inside one pass: same storage = same mask; inference tensors carry no version)
+    if hint["perm"] is None or hint["mask"] != key:
+        perm = torch.empty((rowmask.numel(),), device=rowmask.device, dtype=torch.int32)
+        call("osp_row_order", rowmask, perm, rowmask.numel())
+        hint["perm"] = perm
+        hint["mask"], hint["keep"] = key, rowmask                  # (keeps the mask's storage alive: the key cannot be recycled)
+    return hint["perm"]
+
+
 def convnext_mlp_fused(h, W1, b1, W2, b2, gamma, x, rowmask=None, rowscale=None):
     """ConvNeXt block MLP without gradients in one launch (csrc/mlp_fused.hip): y = (x + rowscale * gamma * (W2 gelu(W1 h + b1) + b2)) * rowmask.
     h (M, C) bf16 (dwconv7_ln_fwd(..., h_bf16=True)), x (M, C) f32, W1 (I, C) / W2 (C, I) f32 Parameters; C in {256, 384}, I % 128 == 0."""
@@ -1139,7 +1172,11 @@ def convnext_mlp_fused(h, W1, b1, W2, b2, gamma, x, rowmask=None, rowscale=None)
     assert h.dtype == torch.bfloat16 and h.shape == (M, C) and h.is_contiguous() and x.is_contiguous()
     _f32(x, b1, b2, gamma)
     y = torch.empty_like(x)
-    call("osp_convnext_mlp_fused", h, param_bf16(W1), b1, param_bf16_kperm16(W2), b2, gamma, x, rowmask, rowscale, y, M, C, I)
+    hint = _LIVE_ROWS[0]
+    perm, live = None, -1
+    if hint is not None and hint["M"] == M and rowmask is not None and rowmask.numel() == M and os.environ.get("OSP_MLP_LIVE", "1") != "0":
+        perm, live = _row_order(hint, rowmask), hint["n"]
+    call("osp_convnext_mlp_fused_live", h, param_bf16(W1), b1, param_bf16_kperm16(W2), b2, gamma, x, rowmask, rowscale, y, M, C, I, perm, live)
     return y
 
 

@@ -302,6 +302,12 @@ class OptiSpeechGenerator(nn.Module):
             durations = torch.ones_like(durations)
             y_lengths = durations.sum(dim=1)
             y_max_length = int(y_lengths.max())
+        # the padded batch has B * y_max rows of which ``total`` are frames: the fused ConvNeXt MLP skips fully masked row blocks and
+        # picks its workgroup mix from the count (kernels.live_rows; a hint: any value gives the same output)
+        with K.live_rows(x.shape[0] * y_max_length, total or durations.numel()):
+            return self._synthesise_decode(x, x_lengths, h, durations, pitch, energy, y_lengths, y_max_length, dev, am_t0)
+
+    def _synthesise_decode(self, x, x_lengths, h, durations, pitch, energy, y_lengths, y_max_length, dev, am_t0):
         if self.graph_decode and x.is_cuda:
             # BASELINE.json configs[4] "hipGraph-captured decode": everything after the one length sync is shape-static in
             # (B, T_text, y_max_length) -- upsampler + decoder and the vocoder replay from two captured graphs (two, because

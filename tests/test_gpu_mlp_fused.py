@@ -98,6 +98,55 @@ def test_split_mode_tail_equals_full_mode(C, I, M, monkeypatch):
     assert (ys[0].cpu().double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("C,I", [(384, 1152), (256, 1024)])
+@pytest.mark.parametrize("hint", [None, "exact", "wrong"])
+def test_masked_row_blocks_leave_early(C, I, hint):
+    """Round 6: a padded batch (64 utterances x 772 frames, lengths 384 .. 772: a quarter of the rows masked, as in the synthesise
+    benchmark).  Row blocks that are masked throughout are not computed -- zeros, as the mask would make them -- and the caller's count of
+    live rows (kernels.live_rows) only picks the full / split workgroup mix: with no hint, the exact count or a wrong one the output
+    is the restatement's."""
+    from optispeech_amd import kernels as K, precision
+    B, T = 64, 772
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(384, T + 1, (B,), generator=g); lens[0] = T
+    M = B * T
+    h, x, W1, W2, b1, b2, gamma, _, _ = _case(M, C, I, 31 * C + I, False)
+    rowmask = (torch.arange(T)[None, :] < lens[:, None]).float().reshape(M)
+    ref = _reference(h, x, W1, W2, b1, b2, gamma, rowmask, None)
+    d = lambda t: None if t is None else t.to(DEV)
+    hb = h.to(DEV).to(torch.bfloat16)
+    W1p, W2p = torch.nn.Parameter(W1.to(DEV)), torch.nn.Parameter(W2.to(DEV))
+    args = (hb, W1p, d(b1), W2p, d(b2), d(gamma), d(x), d(rowmask), None)
+    precision.set_precision("bf16")
+    try:
+        if hint is None:
+            y = K.convnext_mlp_fused(*args)
+        else:
+            with K.live_rows(M, int(lens.sum()) if hint == "exact" else 5000):
+                y = K.convnext_mlp_fused(*args)
+        y_nan = torch.full_like(y, float("nan"))
+        torch.cuda.synchronize()
+    finally:
+        precision.set_precision("f32")
+    y = y.cpu().double()
+    scale = ref.abs().max().item()
+    assert torch.isfinite(y).all() and (y[rowmask == 0] == 0).all()
+    assert (y - ref).abs().max().item() <= 4e-3 * scale
+    assert ((y - ref) ** 2).mean().sqrt().item() <= 3e-4 * scale
+
+
+@pytest.mark.parametrize("M", [1, 5, 1023, 1024, 1025, 49344, 200001])
+def test_row_order_is_a_stable_partition(M):
+    from optispeech_amd import kernels as K
+    g = torch.Generator().manual_seed(M)
+    for frac in (0.0, 0.3, 1.0):
+        mask = (torch.rand(M, generator=g) < frac).float().to(DEV)
+        perm = torch.empty(M, dtype=torch.int32, device=DEV)
+        K.call("osp_row_order", mask, perm, M)
+        want = torch.argsort(mask.cpu() <= 0, stable=True).to(torch.int32)
+        assert torch.equal(perm.cpu(), want)
+
+
 def test_fused_mlp_is_what_the_no_grad_block_runs(monkeypatch):
     """ConvNeXtBlockFn under no_grad in performance mode = dwconv7+LN kernel + ONE MLP launch, equal to the autograd-capable path."""
     from optispeech_amd import kernels as K, ops, precision

@@ -99,6 +99,10 @@ REPLACES = {
     "osp_convnext_mlp_fused": "ConvNeXtBlock.forward pwconv1 -> GELU -> pwconv2 -> gamma, residual (+ backbone mask) without gradients, hidden "
                               "activations never in HBM: generator/modules/convnext.py:39-46,99-101 (callers: OptiSpeechGenerator.synthesise "
                               "generator/__init__.py:170-228, WaveNeXt.forward vocoder/wavenext/__init__.py:77-88)",
+    "osp_convnext_mlp_fused_live": "the same, walking the rows in a given order (unmasked rows first) with the caller's count of unmasked rows (synthesise knows the "
+                                   "sum of the utterance lengths after its one length sync, generator/__init__.py:258-262): masked row blocks leave at once",
+    "osp_row_order": "no reference counterpart: the rows of a padded batch in the order 'unmasked first' (a stable partition by the padding mask), "
+                     "which osp_convnext_mlp_fused_live walks",
     "osp_attn_fused_fwd": "MultiHeadedAttention.forward_attention without the (T x T) scores in HBM (no-grad / inference path): _transformer/attention.py:75-101",
     "osp_dwconv_fwd": "depthwise nn.Conv1d(groups = C, odd k) and its input gradient (flip = 1): ConvSeparable modules/layers.py:455-477, _conformer/convolution.py",
     "osp_dwconv_wgrad": "autograd weight / bias gradient of the same depthwise Conv1d",
