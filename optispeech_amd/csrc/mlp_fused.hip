@@ -98,7 +98,7 @@ __device__ __forceinline__ float mlp_gelu(float x) {
 // comes back as one float4 per lane: x in and y out as 16-byte accesses.  All x rows of a pass are REQUESTED before the first is
 // used (the registers the pass's accumulator tiles just vacated hold them): as load / use / store per float4 the pass was a chain
 // of NIT memory latencies, ~20 us per workgroup for the four passes.
-template <int C, int NB, int Q0 = 0, int Q1 = -1>                    // NB: float4s of x in flight per lane (registers); passes [Q0, Q1)
+template <int C, int NB, bool PERM, int Q0 = 0, int Q1 = -1>         // NB: float4s of x in flight per lane (registers); passes [Q0, Q1)
 __device__ __forceinline__ void mlp_epilogue(const MlpP& p, f32x16 (&out)[C / 32], float* patch, int m0, int lane) {
     constexpr int NT = C / 32, TP = (NT % 3 == 0) ? 3 : 2, CP = 32 * TP, Q4 = CP / 4, NIT = 32 * Q4 / 64;
     static_assert(NT % TP == 0 && (32 * Q4) % 64 == 0, "epilogue tiling");
@@ -122,7 +122,7 @@ __device__ __forceinline__ void mlp_epilogue(const MlpP& p, f32x16 (&out)[C / 32
             for (int k = 0; k < NB; ++k) {
                 const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4;
                 const int mp = m0 + r < p.M ? m0 + r : p.M - 1;                  // (clamped: the loads are unconditional)
-                const int m = p.rowperm ? p.rowperm[mp] : mp;
+                const int m = PERM ? p.rowperm[mp] : mp;
                 xv[k] = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + q * CP + 4 * c4);
                 rmk[k] = p.rowmask ? p.rowmask[m] : 1.f;
                 rs[k] = p.rowscale ? p.rowscale[m] : 1.f;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void mlp_epilogue(const MlpP& p, f32x16 (&out)[C / 32
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int idx = (b0 + k) * 64 + lane, r = idx / Q4, c4 = idx - r * Q4, mp = m0 + r;
-                const int m = (p.rowperm && mp < p.M) ? p.rowperm[mp] : mp;
+                const int m = (PERM && mp < p.M) ? p.rowperm[mp] : mp;
                 const float4 v = *reinterpret_cast<const float4*>(patch + r * CP + 4 * c4);
                 float4 yv;
                 yv.x = fmaf(rs[k], v.x, xv[k].x) * rmk[k]; yv.y = fmaf(rs[k], v.y, xv[k].y) * rmk[k];
@@ -155,7 +155,7 @@ extern __shared__ __attribute__((aligned(1024))) unsigned short mlp_smem[];
 // launch.  One workgroup per CU means 384 row blocks on 256 CUs take two rounds for 1.5 rounds of work; as 256 full + 256 split
 // workgroups the second round costs about half a round (osp_convnext_mlp_fused picks the mix; summation order of the two partials
 // differs from the full mode's, so the two modes agree to f32 rounding, not bit for bit).
-template <int C, bool SPLIT>
+template <int C, bool SPLIT, bool PERM>
 __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
     typedef MlpSched<C> S;
     constexpr int KS1 = S::KS1, NP = S::NP, UPS = S::UPS, UPC = S::UPC, R = S::R, GPS = S::GPS, NT = C / 32, KH = C / 16;
@@ -170,14 +170,14 @@ __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
 
     // ---- a row block whose rows are ALL masked (the padding behind an utterance's last frame: a quarter of the rows of the 64-sentence
     // synthesise benchmark) has y = 0 whatever the MLP gives: write the zeros and leave -- the CU takes the next block (round 6)
-    if (p.rowmask) {
+    if constexpr (PERM) {                                              // (the walk order is only given with a row mask)
         constexpr int ROWS = SPLIT ? 64 : 128;
         const int mb = SPLIT ? p.nfull * 128 + blk * 64 : blk * 128, mr = mb + (tid & (ROWS - 1));
-        const int alive = mr < p.M && p.rowmask[p.rowperm ? p.rowperm[mr] : mr] != 0.f;
+        const int alive = mr < p.M && p.rowmask[p.rowperm[mr]] != 0.f;
         if (!__syncthreads_or(alive)) {
             const int nrow = p.M - mb < ROWS ? p.M - mb : ROWS;
             for (int i = tid; i < nrow * (C / 4); i += 256) {
-                const int r = i / (C / 4), c4 = i - r * (C / 4), m = p.rowperm ? p.rowperm[mb + r] : mb + r;
+                const int r = i / (C / 4), c4 = i - r * (C / 4), m = p.rowperm[mb + r];
                 *reinterpret_cast<float4*>(p.y + (int64_t)m * C + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             return;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
     bf16x8 hf[KH];
     {
         const int m = m0 + l31;
-        const int mrow = m < p.M ? (p.rowperm ? p.rowperm[m] : m) : 0;
+        const int mrow = m < p.M ? (PERM ? p.rowperm[m] : m) : 0;
         const unsigned short* hp = p.h + (int64_t)mrow * C + 8 * half;
 #pragma unroll
         for (int s = 0; s < KH; ++s) {
@@ -374,7 +374,7 @@ __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
 
     constexpr int PATCHF = 32 * ((C / 32) % 3 == 0 ? 96 : 64), NB = (C == 384 ? 12 : 8);
     float* patch = reinterpret_cast<float*>(mlp_smem) + wave * PATCHF;
-    if constexpr (!SPLIT) mlp_epilogue<C, NB>(p, out, patch, m0, lane);
+    if constexpr (!SPLIT) mlp_epilogue<C, NB, PERM>(p, out, patch, m0, lane);
     else {
         // the pair swaps column halves of its partial output tiles: wave uh hands tiles of half 1 - uh over (16 bytes per lane and
         // instruction, lane-linear: no bank conflicts), adds what the partner left for its own half, finishes that half
@@ -404,15 +404,17 @@ __device__ __forceinline__ void mlp_body(const MlpP& p, const int blk) {
         static_assert(NQ % 2 == 0, "passes split between the pair");
         if (uh == 0) send(std::integral_constant<int, 0>{}); else send(std::integral_constant<int, 1>{});
         __syncthreads();
-        if (uh == 0) { recv(std::integral_constant<int, 0>{}); mlp_epilogue<C, NB, 0, NQ / 2>(p, out, patch, m0, lane); }
-        else         { recv(std::integral_constant<int, 1>{}); mlp_epilogue<C, NB, NQ / 2, NQ>(p, out, patch, m0, lane); }
+        if (uh == 0) { recv(std::integral_constant<int, 0>{}); mlp_epilogue<C, NB, PERM, 0, NQ / 2>(p, out, patch, m0, lane); }
+        else         { recv(std::integral_constant<int, 1>{}); mlp_epilogue<C, NB, PERM, NQ / 2, NQ>(p, out, patch, m0, lane); }
     }
 }
 
-template <int C>
+// PERM: the rows are walked in the order p.rowperm gives (unmasked rows first) and a row block that is masked throughout leaves at once
+// (osp_convnext_mlp_fused_live with a row order); without it the kernel is the one of the rounds before, instruction for instruction.
+template <int C, bool PERM = false>
 __global__ __launch_bounds__(256) void convnext_mlp_fused_kernel(const MlpP p) {
-    if ((int)blockIdx.x < p.nfull) mlp_body<C, false>(p, (int)blockIdx.x);
-    else mlp_body<C, true>(p, (int)blockIdx.x - p.nfull);
+    if ((int)blockIdx.x < p.nfull) mlp_body<C, false, PERM>(p, (int)blockIdx.x);
+    else mlp_body<C, true, PERM>(p, (int)blockIdx.x - p.nfull);
 }
 
 // (A producer / consumer variant of this kernel -- 8 waves, two per SIMD: four waves run phase 1 + GELU and hand the bf16 hidden tile
@@ -444,8 +446,10 @@ extern "C" int osp_pack_bf16_kperm16(const float* w, void* out, int64_t N, int64
 static void mlp_attrs() {
     static int done = 0;
     if (done) return;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(convnext_mlp_fused_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(convnext_mlp_fused_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(convnext_mlp_fused_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(convnext_mlp_fused_kernel<384, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(convnext_mlp_fused_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(convnext_mlp_fused_kernel<384, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
     done = 1;
 }
 
@@ -493,8 +497,11 @@ extern "C" int osp_convnext_mlp_fused_live(const void* h, const void* w1, const 
     osp_note_symbol("convnext_mlp_fused_kernel");
     osp_note_flops(4.0 * (double)M * (double)C * (double)I);                                   // two GEMMs of 2 M C I
     osp_note_bytes((double)M * C * (2 + 4 + 4) + 4.0 * (double)C * I + 4.0 * (I + 2 * C));      // h in, x in, y out; both weight packs; biases, gamma
-    if (C == 384) hipLaunchKernelGGL((convnext_mlp_fused_kernel<384>), grid, dim3(256), MLP_LDS, stream, p);
-    else hipLaunchKernelGGL((convnext_mlp_fused_kernel<256>), grid, dim3(256), MLP_LDS, stream, p);
+    if (p.rowperm) {
+        if (C == 384) hipLaunchKernelGGL((convnext_mlp_fused_kernel<384, true>), grid, dim3(256), MLP_LDS, stream, p);
+        else hipLaunchKernelGGL((convnext_mlp_fused_kernel<256, true>), grid, dim3(256), MLP_LDS, stream, p);
+    } else if (C == 384) hipLaunchKernelGGL((convnext_mlp_fused_kernel<384, false>), grid, dim3(256), MLP_LDS, stream, p);
+    else hipLaunchKernelGGL((convnext_mlp_fused_kernel<256, false>), grid, dim3(256), MLP_LDS, stream, p);
     OSP_LAUNCH_CHECK();
     return OSP_OK;
 }
