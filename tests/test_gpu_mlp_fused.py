@@ -172,3 +172,40 @@ def test_fused_mlp_is_what_the_no_grad_block_runs(monkeypatch):
         precision.set_precision("f32")
     scale = y2.abs().max().item()
     assert (y - y2.detach()).abs().max().item() <= 4e-3 * scale
+
+
+def test_padded_batch_walk_inside_a_replayed_decode_graph():
+    """The live-row count is baked into a captured decode graph at its first use; the row order is recomputed inside the graph from the
+    mask of the batch being replayed.  A second batch with the same padded shape and other lengths through the SAME graphs gives the
+    eager result of that batch (the count only picks the workgroup mix: f32 summation order of the split mode, nothing else)."""
+    from optispeech_amd import precision
+    from optispeech_amd.config import ModelConfig, make_optispeech
+    from optispeech_amd.values import InferenceInputs
+    precision.set_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        m = make_optispeech(ModelConfig(), batch_size=32, pretraining_steps=0).to(DEV).eval()
+        g = torch.Generator().manual_seed(3)
+        n, Tt = 24, 96
+        dur = torch.randint(4, 9, (n, Tt), generator=g)
+        dur[0] = 8                                                                # sentence 0 is the longest in both batches: same y_max
+        outs = {}
+        for tag, lo in (("a", 70), ("b", 24)):
+            xl = torch.randint(lo, Tt - 8, (n,), generator=g); xl[0] = Tt
+            x = torch.randint(1, 159, (n, Tt), generator=g) * (torch.arange(Tt)[None] < xl[:, None])
+            outs[tag] = InferenceInputs(clean_text="", x=x, x_lengths=xl, d_factor=1.0, p_factor=1.0, e_factor=1.0)
+        res = {}
+        for graph in (True, False):
+            m.generator.graph_decode = graph
+            for tag in ("a", "b", "a"):
+                res[(graph, tag)] = m.synthesise(outs[tag], durations_override=dur)
+        assert len(m.generator._decode_graphs) == 1                                # one capture served all three graph-mode calls
+        for tag in ("a", "b"):
+            og, oe = res[(True, tag)], res[(False, tag)]
+            wg, we = torch.as_tensor(og.wav).double(), torch.as_tensor(oe.wav).double()
+            assert torch.equal(torch.as_tensor(og.wav_lengths), torch.as_tensor(oe.wav_lengths))
+            assert wg.shape == we.shape and torch.isfinite(wg).all()
+            assert (wg - we).abs().max().item() <= 1e-4 * we.abs().max().item(), (tag, (wg - we).abs().max().item(), we.abs().max().item())
+    finally:
+        m.generator.graph_decode = False
+        precision.set_precision("f32")
